@@ -1,0 +1,98 @@
+// Shared device/host helpers for libmfp_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mfp_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define MFP_LDS __attribute__((address_space(3)))
+
+// ----------------------------------------------------------------------------- host errors
+void mfp_set_error(const char* fmt, ...);
+
+#define MFP_CHECK_ARG(cond)                                                        \
+  do {                                                                             \
+    if (!(cond)) {                                                                 \
+      mfp_set_error("%s:%d: argument check failed: %s", __FILE__, __LINE__, #cond); \
+      return MFP_EINVAL;                                                           \
+    }                                                                              \
+  } while (0)
+
+#define MFP_CHECK_LAUNCH()                                                            \
+  do {                                                                                \
+    hipError_t e_ = hipGetLastError();                                                \
+    if (e_ != hipSuccess) {                                                           \
+      mfp_set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return MFP_ELAUNCH;                                                             \
+    }                                                                                 \
+  } while (0)
+
+// ----------------------------------------------------------------------------- bf16 helpers
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {  // round-to-nearest-even
+  unsigned int u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct cdt_traits;
+template <> struct cdt_traits<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct cdt_traits<unsigned short> {
+  static __device__ __forceinline__ float load(const unsigned short* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void store(unsigned short* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// ----------------------------------------------------------------------------- wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ----------------------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG for dropout: the keep mask of element (row, col) of an [M,N] activation is
+// philox(key = seed, ctr = (col, row>>2, offset_lo, offset_hi))[row & 3] so that the MFMA
+// C-fragment (4 consecutive rows of one column per lane) needs one call, and the backward
+// kernel regenerates the identical mask from (seed, offset).
+__device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+  const unsigned int M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  unsigned int hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  unsigned int hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  unsigned int n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned int c0, unsigned int c1,
+                                           unsigned long long offset, unsigned int (&out)[4]) {
+  unsigned int c[4] = {c0, c1, (unsigned int)offset, (unsigned int)(offset >> 32)};
+  unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+// keep iff uniform >= p  ([TF-EXT] tf.nn.dropout keeps where random_uniform >= rate)
+__device__ __forceinline__ bool philox_keep(unsigned int r, float p) {
+  return (float)(r >> 8) * (1.0f / 16777216.0f) >= p;
+}

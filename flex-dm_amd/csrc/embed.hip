@@ -1,0 +1,165 @@
+// Fused multi-attribute embedding gather + element pooling (reference
+// architecture/encoder.py:156-160,167-175,194-199): one pass reads NCOL int32 per element and
+// sums the addressed rows of all (tiny, L2-resident) tables into the element's D-vector.
+// HBM-bound: algorithmic bytes/element = NCOL*4 read + D*4 write (fwd).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ idx,
+                                                        const int* __restrict__ rowoff,
+                                                        const float* __restrict__ tables,
+                                                        float* __restrict__ out, int T, int NCOL, int D) {
+  // thread = (token, 4 consecutive d); D/4 threads per token
+  const int dv = D >> 2;
+  long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)T * dv;
+  for (; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(gid / dv), c = (int)(gid % dv) * 4;
+    const int* it = idx + (long long)t * NCOL;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NCOL; ++j) {
+      const int r = it[j];
+      if (r < 0) continue;
+      float4 v = *reinterpret_cast<const float4*>(tables + (long long)(rowoff[j] + r) * D + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (long long)t * D + c) = acc;
+  }
+}
+
+// Backward: dtables[rowoff[c] + idx[t][c]] += dout[t].  Workgroup = (token chunk, 64-wide d
+// slice); the slice of ALL tables lives in LDS (ROWS*64*4 B) and is accumulated with LDS float
+// atomics (lanes hit distinct addresses; waves may collide), then written as a partial
+// [chunk][ROWS][D]; a second kernel sums the chunks.  No global atomics.
+constexpr int EB_DSLICE = 64;
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ idx,
+                                                        const int* __restrict__ rowoff,
+                                                        const float* __restrict__ dout,
+                                                        float* __restrict__ part, int T, int NCOL,
+                                                        int ROWS, int D, int tok_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];  // [ROWS][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk = blockIdx.x, d0 = blockIdx.y * EB_DSLICE;
+  for (int i = threadIdx.x; i < ROWS * EB_DSLICE; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int t0 = chunk * tok_per_chunk, t1 = min(T, t0 + tok_per_chunk);
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const float g = dout[(long long)t * D + d0 + lane];
+    const int* it = idx + (long long)t * NCOL;
+    for (int j = 0; j < NCOL; ++j) {
+      const int r = it[j];
+      if (r < 0) continue;
+      atomicAdd(&tab[(rowoff[j] + r) * EB_DSLICE + lane], g);
+    }
+  }
+  __syncthreads();
+  float* pout = part + (long long)chunk * ROWS * D;
+  for (int i = threadIdx.x; i < ROWS * EB_DSLICE; i += 256) {
+    int r = i / EB_DSLICE, c = i % EB_DSLICE;
+    pout[(long long)r * D + d0 + c] = tab[i];
+  }
+}
+
+__global__ void embed_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dtables,
+                                        long long n, int nchunks) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += part[(long long)c * n + i];
+  dtables[i] = s;
+}
+
+// rowcode: 1 = all == 10.0 (<MASK>), 2 = all == 0.0 (<UNUSED>); one wave per row of K floats.
+__global__ __launch_bounds__(256) void row_flags_kernel(const float* __restrict__ x,
+                                                        unsigned char* __restrict__ rowcode,
+                                                        int* __restrict__ special_idx, int idx_stride,
+                                                        int T, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const float* xr = x + (long long)row * K;
+  bool all10 = true, all0 = true;
+  for (int c = lane * 4; c < K; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(xr + c);
+    all10 = all10 && v.x == 10.0f && v.y == 10.0f && v.z == 10.0f && v.w == 10.0f;
+    all0 = all0 && v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f;
+  }
+  const bool m = __all(all10), u = __all(all0);
+  if (lane == 0) {
+    const int code = u ? 2 : (m ? 1 : 0);  // unused wins (encoder.py:174-175 order)
+    rowcode[row] = (unsigned char)code;
+    if (special_idx) special_idx[(long long)row * idx_stride] = code - 1;
+  }
+}
+
+int embed_chunks(int T) {
+  int chunks = (T + 255) / 256;  // >= 256 tokens per chunk
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  return chunks;
+}
+
+}  // namespace
+
+extern "C" int mfp_embed_pool_fwd(const int32_t* idx, const int32_t* rowoff, const float* tables,
+                                  float* out, int32_t T, int32_t NCOL, int32_t ROWS, int32_t D,
+                                  mfp_stream_t stream) {
+  MFP_CHECK_ARG(idx && rowoff && tables && out);
+  MFP_CHECK_ARG(T > 0 && NCOL > 0 && ROWS > 0 && D > 0 && D % 4 == 0);
+  long long total = (long long)T * (D / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     idx, rowoff, tables, out, T, NCOL, D);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" size_t mfp_embed_pool_bwd_workspace_bytes(int32_t T, int32_t NCOL, int32_t ROWS, int32_t D) {
+  (void)NCOL;
+  return (size_t)embed_chunks(T) * ROWS * D * sizeof(float);
+}
+
+extern "C" int mfp_embed_pool_bwd(const int32_t* idx, const int32_t* rowoff, const float* dout,
+                                  float* dtables, void* workspace, size_t workspace_bytes, int32_t T,
+                                  int32_t NCOL, int32_t ROWS, int32_t D, mfp_stream_t stream) {
+  MFP_CHECK_ARG(idx && rowoff && dout && dtables);
+  MFP_CHECK_ARG(T > 0 && NCOL > 0 && ROWS > 0 && D > 0 && D % EB_DSLICE == 0);
+  const size_t lds = (size_t)ROWS * EB_DSLICE * sizeof(float);
+  MFP_CHECK_ARG(lds <= 160 * 1024);
+  if (!workspace || workspace_bytes < mfp_embed_pool_bwd_workspace_bytes(T, NCOL, ROWS, D)) {
+    mfp_set_error("mfp_embed_pool_bwd: workspace too small");
+    return MFP_EWORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int chunks = embed_chunks(T);
+  const int tpc = (T + chunks - 1) / chunks;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_embed_pool_bwd: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+  }
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(chunks, D / EB_DSLICE), dim3(256), lds, st, idx, rowoff,
+                     dout, part, T, NCOL, ROWS, D, tpc);
+  MFP_CHECK_LAUNCH();
+  long long n = (long long)ROWS * D;
+  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, st, part,
+                     dtables, n, chunks);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_row_flags(const float* x, uint8_t* rowcode, int32_t* special_idx, int32_t idx_stride,
+                             int32_t T, int32_t K, mfp_stream_t stream) {
+  MFP_CHECK_ARG(x && rowcode && T > 0 && K > 0 && K % 4 == 0);
+  hipLaunchKernelGGL(row_flags_kernel, dim3((T + 3) / 4), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, rowcode, special_idx, idx_stride, T, K);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

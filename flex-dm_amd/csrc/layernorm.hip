@@ -1,0 +1,210 @@
+// LayerNorm forward / backward (Keras LayerNormalization(), eps 1e-3; reference
+// architecture/transformer.py:172-173,216,222).  HBM-bound: one wave per token row, float4
+// loads, wavefront-wide shuffle reductions; mean/rstd saved (8 B/row) for the backward.
+//   fwd bytes/row: D*4 read + D*e write (+8);  bwd: D*(4 + e + 4[dres]) read + D*4 write.
+#include "common.h"
+
+namespace {
+
+
+template <typename TOUT, int NVEC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     TOUT* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int T, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const float* xr = x + (long long)row * D;
+  float v[NVEC * 4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVEC; ++i) {
+    const int c = lane * 4 + i * 256;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D) t = *reinterpret_cast<const float4*>(xr + c);
+    v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    s += t.x + t.y + t.z + t.w;
+  }
+  s = wave_sum(s);
+  const float mu = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVEC; ++i) {
+    if (lane * 4 + i * 256 < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float d = v[4 * i + e] - mu; q += d * d; }
+    }
+  }
+  q = wave_sum(q);
+  const float rs = rsqrtf(q / (float)D + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  TOUT* yr = y + (long long)row * D;
+#pragma unroll
+  for (int i = 0; i < NVEC; ++i) {
+    const int c = lane * 4 + i * 256, j = 4 * i;
+    if (c >= D) continue;
+    float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float o0 = (v[j] - mu) * rs * g.x + b.x, o1 = (v[j + 1] - mu) * rs * g.y + b.y;
+    float o2 = (v[j + 2] - mu) * rs * g.z + b.z, o3 = (v[j + 3] - mu) * rs * g.w + b.w;
+    if constexpr (sizeof(TOUT) == 4) {
+      *reinterpret_cast<float4*>(yr + c) = make_float4(o0, o1, o2, o3);
+    } else {
+      u32x2 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+      *reinterpret_cast<u32x2*>(yr + c) = pk;
+    }
+  }
+}
+
+constexpr int LN_BWD_ROWS = 64;  // rows per workgroup (4 waves x 16 rows)
+
+template <typename TDY, int NVEC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
+                                                     const float* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ part,
+                                                     int T, int D) {
+  // part: [gridDim.x][2][D]  (dgamma partial, dbeta partial)
+  __shared__ float red[4][2][NVEC * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[NVEC * 4], db[NVEC * 4];
+#pragma unroll
+  for (int j = 0; j < NVEC * 4; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  const int row0 = blockIdx.x * LN_BWD_ROWS;
+  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+    const int row = row0 + rr;
+    if (row >= T) break;
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + (long long)row * D;
+    const TDY* dyr = dy + (long long)row * D;
+    float xh[NVEC * 4], gy[NVEC * 4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int c = lane * 4 + i * 256, j = 4 * i;
+      if (c >= D) { xh[j] = xh[j + 1] = xh[j + 2] = xh[j + 3] = 0.f; gy[j] = gy[j + 1] = gy[j + 2] = gy[j + 3] = 0.f; continue; }
+      float4 xv = *reinterpret_cast<const float4*>(xr + c);
+      float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      float d0, d1, d2, d3;
+      if constexpr (sizeof(TDY) == 4) {
+        float4 t = *reinterpret_cast<const float4*>(dyr + c);
+        d0 = t.x; d1 = t.y; d2 = t.z; d3 = t.w;
+      } else {
+        u32x2 t = *reinterpret_cast<const u32x2*>(dyr + c);
+        d0 = bf16_to_f32((unsigned short)(t[0] & 0xffff)); d1 = bf16_to_f32((unsigned short)(t[0] >> 16));
+        d2 = bf16_to_f32((unsigned short)(t[1] & 0xffff)); d3 = bf16_to_f32((unsigned short)(t[1] >> 16));
+      }
+      xh[j] = (xv.x - mu) * rs; xh[j + 1] = (xv.y - mu) * rs;
+      xh[j + 2] = (xv.z - mu) * rs; xh[j + 3] = (xv.w - mu) * rs;
+      dg[j] += d0 * xh[j]; dg[j + 1] += d1 * xh[j + 1]; dg[j + 2] += d2 * xh[j + 2]; dg[j + 3] += d3 * xh[j + 3];
+      db[j] += d0; db[j + 1] += d1; db[j + 2] += d2; db[j + 3] += d3;
+      gy[j] = d0 * g.x; gy[j + 1] = d1 * g.y; gy[j + 2] = d2 * g.z; gy[j + 3] = d3 * g.w;
+      s1 += gy[j] + gy[j + 1] + gy[j + 2] + gy[j + 3];
+      s2 += gy[j] * xh[j] + gy[j + 1] * xh[j + 1] + gy[j + 2] * xh[j + 2] + gy[j + 3] * xh[j + 3];
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    float* dxr = dx + (long long)row * D;
+    const float* drr = dres ? dres + (long long)row * D : nullptr;
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int c = lane * 4 + i * 256, j = 4 * i;
+      if (c >= D) continue;
+      float4 o;
+      o.x = rs * (gy[j] - s1 - xh[j] * s2);
+      o.y = rs * (gy[j + 1] - s1 - xh[j + 1] * s2);
+      o.z = rs * (gy[j + 2] - s1 - xh[j + 2] * s2);
+      o.w = rs * (gy[j + 3] - s1 - xh[j + 3] * s2);
+      if (drr) {
+        float4 r = *reinterpret_cast<const float4*>(drr + c);
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      *reinterpret_cast<float4*>(dxr + c) = o;
+    }
+  }
+  // cross-wave reduction of the dgamma/dbeta partials
+#pragma unroll
+  for (int i = 0; i < NVEC; ++i) {
+    const int c = lane * 4 + i * 256, j = 4 * i;
+    if (c >= D) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][0][c + e] = dg[j + e]; red[wave][1][c + e] = db[j + e]; }
+  }
+  __syncthreads();
+  float* pout = part + (long long)blockIdx.x * 2 * D;
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    int which = c / D, col = c % D;
+    pout[c] = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+  }
+}
+
+// out[c] = sum_p part[p][c], c < ncols
+__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                       float* __restrict__ out1, int nparts, int D) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * D) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long long)p * 2 * D + c];
+  if (c < D) out0[c] = s; else out1[c - D] = s;
+}
+
+}  // namespace
+
+extern "C" int mfp_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y,
+                                 float* mean, float* rstd, int32_t T, int32_t D, float eps,
+                                 int32_t out_dtype, mfp_stream_t stream) {
+  MFP_CHECK_ARG(x && gamma && beta && y && mean && rstd);
+  MFP_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((T + 3) / 4), block(256);
+  MFP_CHECK_ARG(out_dtype == MFP_F32 || out_dtype == MFP_BF16);
+  const int nvec = (D + 255) / 256;
+#define LN_FWD(TT, NV) hipLaunchKernelGGL((ln_fwd_kernel<TT, NV>), grid, block, 0, st, x, gamma, beta, (TT*)y, mean, rstd, T, D, eps)
+  if (out_dtype == MFP_F32) {
+    if (nvec == 1) LN_FWD(float, 1); else if (nvec == 2) LN_FWD(float, 2); else LN_FWD(float, 4);
+  } else {
+    if (nvec == 1) LN_FWD(unsigned short, 1); else if (nvec == 2) LN_FWD(unsigned short, 2); else LN_FWD(unsigned short, 4);
+  }
+#undef LN_FWD
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D) {
+  size_t nblk = (size_t)(T + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+  return nblk * 2 * D * sizeof(float);
+}
+
+extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, const float* dres, float* dx, float* dgamma,
+                                 float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
+                                 int32_t D, int32_t dy_dtype, mfp_stream_t stream) {
+  MFP_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta);
+  MFP_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024);
+  if (!workspace || workspace_bytes < mfp_layernorm_bwd_workspace_bytes(T, D)) {
+    mfp_set_error("mfp_layernorm_bwd: workspace too small");
+    return MFP_EWORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int nblk = (T + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+  float* part = reinterpret_cast<float*>(workspace);
+  MFP_CHECK_ARG(dy_dtype == MFP_F32 || dy_dtype == MFP_BF16);
+  const int nvec = (D + 255) / 256;
+#define LN_BWD(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D)
+  if (dy_dtype == MFP_F32) {
+    if (nvec == 1) LN_BWD(float, 1); else if (nvec == 2) LN_BWD(float, 2); else LN_BWD(float, 4);
+  } else {
+    if (nvec == 1) LN_BWD(unsigned short, 1); else if (nvec == 2) LN_BWD(unsigned short, 2); else LN_BWD(unsigned short, 4);
+  }
+#undef LN_BWD
+  MFP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, part, dgamma,
+                     dbeta, nblk, D);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

@@ -1,0 +1,256 @@
+// Optimizer + small streaming kernels of the train step.
+//  * mfp_adam_keras: Keras Adam + per-variable clipnorm + L2 regularisers fused over one flat
+//    parameter buffer (reference train.py:71-77; architecture/utils.py:8-22; [TF-EXT] Keras
+//    OptimizerV2 Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), eps=1e-7 outside the sqrt; clipnorm =
+//    per-variable tf.clip_by_norm).  HBM-bound: 16 B read + 12 B (+2 B bf16 shadow) written per
+//    parameter, plus an 8 B/parameter norm pass.
+//  * mfp_dropout_bwd: regenerates the Philox keep mask of MFP_GEMM_DROPOUT and emits the
+//    (cdt) gradient of the Dense output together with its column sums (= bias gradient).
+#include "common.h"
+
+namespace {
+
+constexpr int ADAM_CHUNK = 4096;  // elements per workgroup
+
+// stats[seg][0] += sum (g*gs + 2*l2*w)^2 ; stats[seg][1] += sum w^2
+__global__ __launch_bounds__(256) void adam_norm_kernel(const float* __restrict__ w,
+                                                        const float* __restrict__ g,
+                                                        const int* __restrict__ chunk_seg,
+                                                        const long long* __restrict__ chunk_beg,
+                                                        const int* __restrict__ chunk_len,
+                                                        const float* __restrict__ seg_l2,
+                                                        float* __restrict__ stats, float grad_scale) {
+  __shared__ float red[2][4];
+  const int seg = chunk_seg[blockIdx.x];
+  const long long beg = chunk_beg[blockIdx.x];
+  const int len = chunk_len[blockIdx.x];
+  const float l2 = seg_l2[seg];
+  float sg = 0.f, sw = 0.f;
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const float wi = w[beg + i];
+    const float gi = g[beg + i] * grad_scale + 2.f * l2 * wi;
+    sg += gi * gi; sw += wi * wi;
+  }
+  sg = wave_sum(sg); sw = wave_sum(sw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = sg; red[1][wave] = sw; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    atomicAdd(&stats[seg * 2 + threadIdx.x], s);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          unsigned short* __restrict__ shadow,
+                                                          const int* __restrict__ chunk_seg,
+                                                          const long long* __restrict__ chunk_beg,
+                                                          const int* __restrict__ chunk_len,
+                                                          const float* __restrict__ seg_l2,
+                                                          const float* __restrict__ stats,
+                                                          const int* __restrict__ step_t, float lr, float b1,
+                                                          float b2, float eps, float clipnorm, float grad_scale) {
+  const int seg = chunk_seg[blockIdx.x];
+  const long long beg = chunk_beg[blockIdx.x];
+  const int len = chunk_len[blockIdx.x];
+  const float l2 = seg_l2[seg];
+  const float t = (float)(*step_t);  // already incremented (1-based)
+  const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  float clip = 1.f;
+  if (clipnorm > 0.f) clip = clipnorm / fmaxf(sqrtf(stats[seg * 2]), clipnorm);
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const long long o = beg + i;
+    const float wi = w[o];
+    const float gi = (g[o] * grad_scale + 2.f * l2 * wi) * clip;
+    const float mi = b1 * m[o] + (1.f - b1) * gi;
+    const float vi = b2 * v[o] + (1.f - b2) * gi * gi;
+    const float wn = wi - lr_t * mi / (sqrtf(vi) + eps);
+    m[o] = mi; v[o] = vi; w[o] = wn;
+    if (shadow) shadow[o] = f32_to_bf16(wn);
+  }
+}
+
+__global__ void step_inc_kernel(int* step_t, float* stats, int nstats) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *step_t += 1;
+  if (i < nstats) stats[i] = 0.f;
+}
+
+__global__ void cast_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 v = *reinterpret_cast<const float4*>(src + i);
+    u32x2 pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    *reinterpret_cast<u32x2*>(dst + i) = pk;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long j = n & ~3ll; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+}
+
+// thread = (column c, 4-row group): matches the MFMA C-fragment keyed Philox stream.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dx, TOUT* __restrict__ dy,
+                                                          float* __restrict__ colsum_part, int M, int N,
+                                                          float p, unsigned long long seed,
+                                                          unsigned long long offset, int rows_per_block) {
+  // block handles columns [blockIdx.x*256, +256) and rows [blockIdx.y*rows_per_block, ...)
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  if (c >= N) return;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float cs = 0.f;
+  for (int r = r0; r < r1; r += 4) {
+    unsigned int rnd[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (p > 0.f) philox4x32(seed, (unsigned int)c, (unsigned int)(r >> 2), offset, rnd);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (r + e >= r1) break;
+      const long long o = (long long)(r + e) * N + c;
+      float v = dx[o];
+      if (p > 0.f) v = philox_keep(rnd[e], p) ? v * inv_keep : 0.f;
+      cdt_traits<TOUT>::store(dy + o, v);
+      cs += v;
+    }
+  }
+  colsum_part[(long long)blockIdx.y * N + c] = cs;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ part, int M,
+                                                     int N, int ld, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  if (c >= N) return;
+  float cs = 0.f;
+  for (int r = r0; r < r1; ++r) cs += cdt_traits<T>::load(X + (long long)r * ld + c);
+  part[(long long)blockIdx.y * N + c] = cs;
+}
+
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int nparts) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long long)p * N + c];
+  out[c] = s;
+}
+
+}  // namespace
+
+// The chunk table (segment id, start, length per <=4096-element chunk) is static per model: it
+// is built once on the host into caller memory and uploaded by the caller (no library state).
+extern "C" int64_t mfp_adam_num_chunks(const int32_t* seg_off_host, int32_t nseg) {
+  int64_t n = 0;
+  for (int s = 0; s < nseg; ++s) {
+    int64_t len = (int64_t)seg_off_host[s + 1] - seg_off_host[s];
+    n += (len + ADAM_CHUNK - 1) / ADAM_CHUNK;
+  }
+  return n;
+}
+
+// Fills host arrays (caller copies them to the device once): chunk_seg int32[nchunks],
+// chunk_beg int64[nchunks], chunk_len int32[nchunks].
+extern "C" int mfp_adam_chunk_table(const int32_t* seg_off_host, int32_t nseg, int32_t* chunk_seg,
+                                    int64_t* chunk_beg, int32_t* chunk_len) {
+  MFP_CHECK_ARG(seg_off_host && chunk_seg && chunk_beg && chunk_len && nseg > 0);
+  int64_t k = 0;
+  for (int s = 0; s < nseg; ++s) {
+    int64_t beg = seg_off_host[s], end = seg_off_host[s + 1];
+    for (int64_t b = beg; b < end; b += ADAM_CHUNK) {
+      chunk_seg[k] = s; chunk_beg[k] = b;
+      chunk_len[k] = (int32_t)((end - b) < ADAM_CHUNK ? (end - b) : ADAM_CHUNK);
+      ++k;
+    }
+  }
+  return MFP_OK;
+}
+
+extern "C" int mfp_adam_keras(float* w, const float* g, float* m, float* v, uint16_t* shadow,
+                                     const int32_t* chunk_seg, const int64_t* chunk_beg,
+                                     const int32_t* chunk_len, int64_t nchunks, const float* seg_l2,
+                                     float* stats, int32_t nseg, int32_t* step_t, float lr, float beta1,
+                                     float beta2, float eps, float clipnorm, float grad_scale,
+                                     mfp_stream_t stream) {
+  MFP_CHECK_ARG(w && g && m && v && chunk_seg && chunk_beg && chunk_len && seg_l2 && stats && step_t);
+  MFP_CHECK_ARG(nchunks > 0 && nseg > 0);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(step_inc_kernel, dim3((2 * nseg + 255) / 256), dim3(256), 0, st, step_t, stats, 2 * nseg);
+  MFP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(adam_norm_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, w, g, chunk_seg,
+                     reinterpret_cast<const long long*>(chunk_beg), chunk_len, seg_l2, stats, grad_scale);
+  MFP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, w, g, m, v, shadow,
+                     chunk_seg, reinterpret_cast<const long long*>(chunk_beg), chunk_len, seg_l2, stats,
+                     step_t, lr, beta1, beta2, eps, clipnorm, grad_scale);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, mfp_stream_t stream) {
+  MFP_CHECK_ARG(src && dst && n > 0);
+  MFP_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0);
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst,
+                     (long long)n);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+static int rows_per_block_for(int M) {
+  int rpb = ((M + 255) / 256 + 3) & ~3;  // <= 256 row blocks, multiple of 4 (Philox row groups)
+  if (rpb < 4) rpb = 4;
+  return rpb;
+}
+
+extern "C" size_t mfp_colsum_workspace_bytes(int32_t M, int32_t N) {
+  int rpb = rows_per_block_for(M);
+  return (size_t)((M + rpb - 1) / rpb) * N * sizeof(float);
+}
+
+extern "C" int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* workspace,
+                               size_t workspace_bytes, int32_t M, int32_t N, float p, uint64_t seed,
+                               uint64_t offset, int32_t out_dtype, mfp_stream_t stream) {
+  MFP_CHECK_ARG(dx && dy && colsum && M > 0 && N > 0 && p >= 0.f && p < 1.f);
+  MFP_CHECK_ARG(out_dtype == MFP_F32 || out_dtype == MFP_BF16);
+  if (!workspace || workspace_bytes < mfp_colsum_workspace_bytes(M, N)) {
+    mfp_set_error("mfp_dropout_bwd: workspace too small");
+    return MFP_EWORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = rows_per_block_for(M), nrb = (M + rpb - 1) / rpb;
+  dim3 grid((N + 255) / 256, nrb);
+  float* part = reinterpret_cast<float*>(workspace);
+  if (out_dtype == MFP_F32)
+    hipLaunchKernelGGL(dropout_bwd_kernel<float>, grid, dim3(256), 0, st, dx, (float*)dy, part, M, N, p, seed, offset, rpb);
+  else
+    hipLaunchKernelGGL(dropout_bwd_kernel<unsigned short>, grid, dim3(256), 0, st, dx, (unsigned short*)dy, part, M, N, p, seed, offset, rpb);
+  MFP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, colsum, N, nrb);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_colsum(const void* X, float* colsum, void* workspace, size_t workspace_bytes, int32_t M,
+                          int32_t N, int32_t ld, int32_t dtype, mfp_stream_t stream) {
+  MFP_CHECK_ARG(X && colsum && M > 0 && N > 0 && ld >= N);
+  MFP_CHECK_ARG(dtype == MFP_F32 || dtype == MFP_BF16);
+  if (!workspace || workspace_bytes < mfp_colsum_workspace_bytes(M, N)) {
+    mfp_set_error("mfp_colsum: workspace too small");
+    return MFP_EWORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = rows_per_block_for(M), nrb = (M + rpb - 1) / rpb;
+  dim3 grid((N + 255) / 256, nrb);
+  float* part = reinterpret_cast<float*>(workspace);
+  if (dtype == MFP_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, part, M, N, ld, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short*)X, part, M, N, ld, rpb);
+  MFP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, colsum, N, nrb);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

@@ -1,0 +1,285 @@
+"""Tensor-level wrappers over the C-ABI (no autograd here; see ``mfp.hip.functions``).
+
+PyTorch-ROCm is plumbing only: it owns device memory (caching allocator) and the stream; every
+wrapper passes ``tensor.data_ptr()`` + ``torch.cuda.current_stream().cuda_stream`` to the
+library and never computes anything itself.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_B, GEMM_DROPOUT, GEMM_RELU, GEMM_RELU_BWD,
+               GEMM_RESIDUAL, GEMM_ROWSKIP, GEMM_ROWSKIP_B, MFP_BF16, MFP_F32, GemmArgs, LossKey,
+               check, load)
+
+_DT = {torch.float32: MFP_F32, torch.bfloat16: MFP_BF16}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError("unsupported compute dtype %s (float32 or bfloat16)" % dtype) from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmfp_hip ops need HIP device tensors (got %s); there is no CPU "
+                           "fallback on the product path" % t.device)
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------- workspace
+_workspaces: Dict[torch.device, List[torch.Tensor]] = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (stream-ordered reuse; old buffers are kept alive so
+    pointers baked into a captured hipGraph stay valid)."""
+    device = torch.device(device)
+    lst = _workspaces.setdefault(device, [])
+    if not lst or lst[-1].numel() < nbytes:
+        lst.append(torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device))
+    return lst[-1]
+
+
+# ------------------------------------------------------------------------------------ GEMM
+def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: bool, b_kmajor: bool,
+         out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+         bias: Optional[torch.Tensor] = None, relu: bool = False,
+         residual: Optional[torch.Tensor] = None, dropout: Optional[Tuple[float, int, int]] = None,
+         accum: bool = False, rowskip: Optional[torch.Tensor] = None,
+         relu_bwd_aux: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None,
+         rowskip_b: Optional[torch.Tensor] = None, splitk: int = 1,
+         lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None) -> torch.Tensor:
+    """``out[M,N] = epilogue(op(A) @ op(B))`` -- see ``mfp_gemm`` in include/mfp_hip.h."""
+    lib = load()
+    assert A.dtype == B.dtype, (A.dtype, B.dtype)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
+    a = GemmArgs()
+    a.A, a.B, a.C = _ptr(A), _ptr(B), _ptr(out)
+    a.M, a.N, a.K = M, N, K
+    a.lda = lda if lda is not None else (K if a_kmajor else M)
+    a.ldb = ldb if ldb is not None else (K if b_kmajor else N)
+    a.ldc = ldc if ldc is not None else N
+    a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
+    a.in_dtype, a.out_dtype = dt_code(A.dtype), dt_code(out.dtype)
+    flags = 0
+    if bias is not None:
+        flags |= GEMM_BIAS
+        a.bias = _ptr(bias)
+    if relu:
+        flags |= GEMM_RELU
+    if residual is not None:
+        flags |= GEMM_RESIDUAL
+        a.residual = _ptr(residual)
+    if dropout is not None and dropout[0] > 0.0:
+        flags |= GEMM_DROPOUT
+        a.dropout_p, a.seed, a.offset = float(dropout[0]), int(dropout[1]), int(dropout[2])
+    if accum:
+        flags |= GEMM_ACCUM
+    if rowskip is not None:
+        flags |= GEMM_ROWSKIP
+        a.rowcode = _ptr(rowskip)
+    if relu_bwd_aux is not None:
+        flags |= GEMM_RELU_BWD
+        a.aux = _ptr(relu_bwd_aux)
+    if colsum is not None:
+        flags |= GEMM_COLSUM_B
+        a.colsum = _ptr(colsum)
+    if rowskip_b is not None:
+        flags |= GEMM_ROWSKIP_B
+        a.rowcode = _ptr(rowskip_b)
+    a.flags, a.splitk = flags, splitk
+    nbytes = lib.mfp_gemm_workspace_bytes(ctypes.byref(a))
+    if nbytes:
+        ws = workspace(nbytes, A.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib.mfp_gemm(ctypes.byref(a), _stream()), "mfp_gemm")
+    return out
+
+
+def wgrad_splitk(T: int, M: int, N: int) -> int:
+    """Split the token contraction so that ~2 workgroups per CU are in flight."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    sk = max(1, min(64, 512 // max(tiles, 1)))
+    while sk > 1 and T // sk < 256:
+        sk //= 2
+    return sk
+
+
+# ------------------------------------------------------------------------------- LayerNorm
+LN_EPS = 1e-3  # Keras LayerNormalization() default [TF-EXT]
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype):
+    lib = load()
+    T, D = x.shape
+    y = torch.empty((T, D), dtype=out_dtype, device=x.device)
+    mean = torch.empty((T,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((T,), dtype=torch.float32, device=x.device)
+    check(lib.mfp_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), T, D,
+                                LN_EPS, dt_code(out_dtype), _stream()), "mfp_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,
+                  dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load()
+    T, D = x.shape
+    if dx is None:
+        dx = torch.empty((T, D), dtype=torch.float32, device=x.device)
+    nbytes = lib.mfp_layernorm_bwd_workspace_bytes(T, D)
+    ws = workspace(nbytes, x.device)
+    check(lib.mfp_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
+                                _ptr(dx), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), ws.numel(), T, D,
+                                dt_code(dy.dtype), _stream()), "mfp_layernorm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------- attention
+def attention_fwd(qkv: torch.Tensor, nvalid: torch.Tensor, B: int, S: int, H: int):
+    lib = load()
+    D = qkv.shape[1] // 3
+    out = torch.empty((B * S, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    check(lib.mfp_attention_fwd(_ptr(qkv), _ptr(nvalid), _ptr(out), _ptr(lse), B, S, H, D // H,
+                                dt_code(qkv.dtype), _stream()), "mfp_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, nvalid, out, dout, lse, B: int, S: int, H: int) -> torch.Tensor:
+    lib = load()
+    D = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    check(lib.mfp_attention_bwd(_ptr(qkv), _ptr(nvalid), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv),
+                                B, S, H, D // H, dt_code(qkv.dtype), _stream()), "mfp_attention_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------- embedding
+def embed_pool_fwd(idx: torch.Tensor, rowoff: torch.Tensor, tables: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    T, NCOL = idx.shape
+    ROWS, D = tables.shape
+    out = torch.empty((T, D), dtype=torch.float32, device=idx.device)
+    check(lib.mfp_embed_pool_fwd(_ptr(idx), _ptr(rowoff), _ptr(tables), _ptr(out), T, NCOL, ROWS, D,
+                                 _stream()), "mfp_embed_pool_fwd")
+    return out
+
+
+def embed_pool_bwd(idx, rowoff, dout: torch.Tensor, dtables: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    T, NCOL = idx.shape
+    ROWS, D = dtables.shape
+    nbytes = lib.mfp_embed_pool_bwd_workspace_bytes(T, NCOL, ROWS, D)
+    ws = workspace(nbytes, idx.device)
+    check(lib.mfp_embed_pool_bwd(_ptr(idx), _ptr(rowoff), _ptr(dout), _ptr(dtables), ws.data_ptr(),
+                                 ws.numel(), T, NCOL, ROWS, D, _stream()), "mfp_embed_pool_bwd")
+    return dtables
+
+
+def row_flags(x: torch.Tensor, rowcode: torch.Tensor, special_idx: Optional[torch.Tensor] = None,
+              idx_stride: int = 1):
+    """x f32 [T,K] -> rowcode u8 [T]; optionally special_idx[t*stride] = rowcode-1."""
+    lib = load()
+    T, K = x.shape
+    check(lib.mfp_row_flags(_ptr(x), _ptr(rowcode), _ptr(special_idx), idx_stride, T, K, _stream()),
+          "mfp_row_flags")
+    return rowcode
+
+
+# ---------------------------------------------------------------------------------- losses
+def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tensor, B: int, S: int,
+                 dl_dtype: Optional[torch.dtype], sums: Optional[torch.Tensor] = None,
+                 dlogits: Optional[torch.Tensor] = None):
+    """keys: dicts with col_off, n_feat, n_class, is_numerical, target, mask, cond_idx,
+    cond_stride, cond_bits.  Returns (sums [nkeys,3], dlogits or None)."""
+    lib = load()
+    ld = logits.shape[1]
+    arr = (LossKey * len(keys))()
+    for i, k in enumerate(keys):
+        arr[i].col_off, arr[i].n_feat, arr[i].n_class = k["col_off"], k["n_feat"], k["n_class"]
+        arr[i].is_numerical = int(k["is_numerical"])
+        arr[i].target, arr[i].mask = _ptr(k["target"]), _ptr(k["mask"])
+        arr[i].cond_idx = _ptr(k.get("cond_idx"))
+        arr[i].cond_stride = k.get("cond_stride", 1)
+        arr[i].cond_bits = k.get("cond_bits", 0xFFFFFFFF)
+    if sums is None:
+        sums = torch.empty((len(keys), 3), dtype=torch.float32, device=logits.device)
+    if dl_dtype is not None and dlogits is None:
+        dlogits = torch.zeros(logits.shape, dtype=dl_dtype, device=logits.device)
+    code = dt_code(dlogits.dtype) if dlogits is not None else MFP_F32
+    check(lib.mfp_loss_fwd_bwd(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid), _ptr(sums),
+                               B, S, code, _stream()), "mfp_loss_fwd_bwd")
+    return sums, dlogits
+
+
+# ------------------------------------------------------------------------------- optimizer
+class AdamChunks:
+    """Static chunk table of a flat parameter buffer (see mfp_adam_chunk_table)."""
+
+    def __init__(self, seg_off: Sequence[int], device):
+        lib = load()
+        nseg = len(seg_off) - 1
+        off = (ctypes.c_int32 * (nseg + 1))(*seg_off)
+        n = lib.mfp_adam_num_chunks(off, nseg)
+        cs, cb, cl = (ctypes.c_int32 * n)(), (ctypes.c_int64 * n)(), (ctypes.c_int32 * n)()
+        check(lib.mfp_adam_chunk_table(off, nseg, cs, cb, cl), "mfp_adam_chunk_table")
+        self.nseg, self.nchunks = nseg, n
+        self.chunk_seg = torch.tensor(list(cs), dtype=torch.int32, device=device)
+        self.chunk_beg = torch.tensor(list(cb), dtype=torch.int64, device=device)
+        self.chunk_len = torch.tensor(list(cl), dtype=torch.int32, device=device)
+
+
+def adam_keras(w, g, m, v, shadow: Optional[torch.Tensor], chunks: AdamChunks, seg_l2: torch.Tensor,
+               stats: torch.Tensor, step_t: torch.Tensor, lr: float, beta1: float = 0.9,
+               beta2: float = 0.999, eps: float = 1e-7, clipnorm: float = 1.0, grad_scale: float = 1.0):
+    lib = load()
+    check(lib.mfp_adam_keras(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(chunks.chunk_seg),
+                             _ptr(chunks.chunk_beg), _ptr(chunks.chunk_len), chunks.nchunks,
+                             _ptr(seg_l2), _ptr(stats), chunks.nseg, _ptr(step_t), lr, beta1, beta2, eps,
+                             clipnorm if clipnorm is not None else 0.0, grad_scale, _stream()),
+          "mfp_adam_keras")
+
+
+def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
+    lib = load()
+    check(lib.mfp_cast_f32_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), "mfp_cast_f32_bf16")
+    return dst
+
+
+def dropout_bwd(dx: torch.Tensor, out_dtype: torch.dtype, colsum: torch.Tensor, p: float, seed: int,
+                offset: int) -> torch.Tensor:
+    lib = load()
+    M, N = dx.shape
+    dy = torch.empty((M, N), dtype=out_dtype, device=dx.device)
+    ws = workspace(lib.mfp_colsum_workspace_bytes(M, N), dx.device)
+    check(lib.mfp_dropout_bwd(_ptr(dx), _ptr(dy), _ptr(colsum), ws.data_ptr(), ws.numel(), M, N, float(p),
+                              int(seed), int(offset), dt_code(out_dtype), _stream()), "mfp_dropout_bwd")
+    return dy
+
+
+def colsum(X: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int] = None) -> torch.Tensor:
+    lib = load()
+    ws = workspace(lib.mfp_colsum_workspace_bytes(M, N), X.device)
+    check(lib.mfp_colsum(_ptr(X), _ptr(out), ws.data_ptr(), ws.numel(), M, N, ld or N, dt_code(X.dtype),
+                         _stream()), "mfp_colsum")
+    return out
+
+
+def tr_probe(byte_addr: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    out = torch.empty((64, 4), dtype=torch.int16, device=byte_addr.device)
+    check(lib.mfp_debug_tr_probe(_ptr(byte_addr), _ptr(out), _stream()), "mfp_debug_tr_probe")
+    return out

@@ -1,0 +1,199 @@
+/*
+ * libmfp_hip.so -- C-ABI of the MI355X (gfx950) kernel library for the MFP hot path.
+ *
+ * The reference (CyberAgentAILab/flex-dm) is pure Python on TensorFlow/Keras and has no FFI
+ * of its own; the arithmetic each entry point replaces lives in stock TF ops called from the
+ * reference lines cited per function below (paths relative to /root/reference/src/mfp/mfp/).
+ * SURVEY.md §8(b) fixes the convention:
+ *   - extern "C", plain pointers + sizes, no C++/torch types in any signature;
+ *   - every entry returns 0 or a negative MFP_E* code; mfp_last_error() gives the text;
+ *   - never allocates, never synchronises, never owns: the caller (PyTorch-ROCm caching
+ *     allocator) owns every buffer including workspaces; launches go on the caller's stream;
+ *   - thread-safe for distinct streams; no global mutable state.
+ * All pointers are DEVICE pointers unless a comment says "host".
+ * "cdt" = compute dtype of the activations between kernels: MFP_F32 or MFP_BF16.
+ */
+#ifndef MFP_HIP_H
+#define MFP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mfp_stream_t; /* hipStream_t */
+
+enum { MFP_F32 = 0, MFP_BF16 = 1 };
+
+enum {
+  MFP_OK = 0,
+  MFP_EINVAL = -1,    /* bad argument / unsupported shape */
+  MFP_ELAUNCH = -2,   /* hipGetLastError() after launch */
+  MFP_EWORKSPACE = -3 /* workspace too small */
+};
+
+const char* mfp_last_error(void);
+int mfp_version(void);
+
+/* ---------------------------------------------------------------------------------- GEMM
+ * One MFMA tile kernel with epilogue flags.
+ * C[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] ).  Operand storage:
+ *   a_kmajor=1: A stored [M][lda] (k contiguous);  0: A stored [K][lda] (m contiguous)
+ *   b_kmajor=1: B stored [N][ldb] (k contiguous);  0: B stored [K][ldb] (n contiguous)
+ * Forward Dense (transformer.py:85-98,163-169; encoder.py:88-92; decoder.py:39-43):
+ *   a_kmajor=1,b_kmajor=0 with B = Keras kernel (in,out).  dgrad: a_kmajor=1,b_kmajor=1.
+ *   wgrad: a_kmajor=0,b_kmajor=0 (contraction over tokens), split-K via `splitk`.
+ * Constraints: N%8==0, K%8==0 (kmajor operands), lda/ldb/ldc %8==0; M free.
+ */
+enum {
+  MFP_GEMM_BIAS = 1,        /* + bias[n] (f32) */
+  MFP_GEMM_RELU = 2,        /* max(.,0) after bias */
+  MFP_GEMM_RESIDUAL = 4,    /* + residual[m][n] (f32, ld = ldc) after dropout */
+  MFP_GEMM_DROPOUT = 8,     /* inverted dropout on (acc+bias) before the residual add */
+  MFP_GEMM_ACCUM = 16,      /* C += result (C f32) */
+  MFP_GEMM_ROWSKIP = 32,    /* rows with rowcode[m]!=0 contribute 0 (encoder.py:174-175) */
+  MFP_GEMM_RELU_BWD = 64,   /* result *= (aux[m][n] > 0), aux in cdt, ld = ldc */
+  MFP_GEMM_COLSUM_B = 128,  /* wgrad only: also colsum[n] = sum_k B[k][n] (bias grad) */
+  MFP_GEMM_ROWSKIP_B = 256  /* wgrad only: rows k of B with rowcode[k]!=0 count as zero */
+};
+
+typedef struct mfp_gemm_args {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  const float* residual;
+  const void* aux;
+  const uint8_t* rowcode;
+  float* colsum;        /* [N] f32, MFP_GEMM_COLSUM_B */
+  void* workspace;      /* wgrad split-K partials: splitk*M*N (+ splitk*N) floats */
+  size_t workspace_bytes;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t a_kmajor, b_kmajor;
+  int32_t in_dtype;     /* dtype of A and B (MFP_F32 -> exact f32 MFMA, MFP_BF16) */
+  int32_t out_dtype;    /* dtype of C */
+  int32_t flags;
+  int32_t splitk;       /* >=1; >1 only with a_kmajor=0,b_kmajor=0 */
+  float dropout_p;
+  uint64_t seed;
+  uint64_t offset;
+} mfp_gemm_args;
+
+int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);
+size_t mfp_gemm_workspace_bytes(const mfp_gemm_args* args /*host*/);
+
+/* --------------------------------------------------------------------------- LayerNorm
+ * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
+ * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.
+ */
+int mfp_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y,
+                      float* mean, float* rstd, int32_t T, int32_t D, float eps,
+                      int32_t out_dtype, mfp_stream_t stream);
+/* dx[t] = (dres ? dres[t] : 0) + LN'(dy)[t]; dgamma/dbeta f32 [D].
+ * workspace: mfp_layernorm_bwd_workspace_bytes(T,D). dx may alias dres. */
+int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, float* dx, float* dgamma,
+                      float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
+                      int32_t D, int32_t dy_dtype, mfp_stream_t stream);
+size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D);
+
+/* --------------------------------------------------------------------------- attention
+ * MultiHeadSelfAttention.attention (transformer.py:60-76) fused: softmax(QK^T/sqrt(hd) +
+ * -1e9*(1-keymask)) V per (document, head); no (B,H,S,S) round trip.
+ * qkv cdt [B*S, 3*D] rows = tokens, columns [q | k | v], head h = columns h*hd..;
+ * nvalid int32 [B] = number of valid keys per document (= length+1, mask.py:29);
+ * out cdt [B*S, D]; lse f32 [B,H,S].  hd in {16,32,64}; S <= 256.
+ */
+int mfp_attention_fwd(const void* qkv, const int32_t* nvalid, void* out, float* lse, int32_t B,
+                      int32_t S, int32_t H, int32_t hd, int32_t dtype, mfp_stream_t stream);
+int mfp_attention_bwd(const void* qkv, const int32_t* nvalid, const void* out, const void* dout,
+                      const float* lse, void* dqkv, int32_t B, int32_t S, int32_t H, int32_t hd,
+                      int32_t dtype, mfp_stream_t stream);
+
+/* ------------------------------------------------------------- embedding gather + pooling
+ * Encoder categorical path (encoder.py:156-160,194-199): out[t] = sum_c tables[rowoff[c] +
+ * idx[t][c]] over NCOL index columns (idx < 0 -> column skipped: used for the <MASK>/<UNUSED>
+ * special rows of numerical attributes, encoder.py:167-175).  idx int32 [T,NCOL];
+ * rowoff int32 [NCOL]; tables f32 [ROWS,D]; out f32 [T,D].
+ */
+int mfp_embed_pool_fwd(const int32_t* idx, const int32_t* rowoff, const float* tables, float* out,
+                       int32_t T, int32_t NCOL, int32_t ROWS, int32_t D, mfp_stream_t stream);
+int mfp_embed_pool_bwd(const int32_t* idx, const int32_t* rowoff, const float* dout,
+                       float* dtables, void* workspace, size_t workspace_bytes, int32_t T,
+                       int32_t NCOL, int32_t ROWS, int32_t D, mfp_stream_t stream);
+size_t mfp_embed_pool_bwd_workspace_bytes(int32_t T, int32_t NCOL, int32_t ROWS, int32_t D);
+/* rowcode[t] = 1 if all(x[t]==10.0) (<MASK>), 2 if all(x[t]==0.0) (<UNUSED>, wins), else 0
+ * (encoder.py:165-166; masking.py:8-9); special_idx[t*stride] = rowcode-1 (or -1). */
+int mfp_row_flags(const float* x, uint8_t* rowcode, int32_t* special_idx, int32_t idx_stride,
+                  int32_t T, int32_t K, mfp_stream_t stream);
+
+/* ------------------------------------------------------------------------------ losses
+ * LossLayer (metrics.py:213-299) fused per attribute: weight(t) = mfp_mask[t] &&
+ * cond(type[t]) && s < nvalid[b]; loss/score/den summed over tokens; d(logits) written
+ * scaled by 1/B (mean over B, metrics.py:277).  Categorical: compute_categorical_mfp_metric
+ * (metrics.py:36-49) incl. Keras clip(p,1e-7,1-1e-7)->log->renormalise.  Numerical:
+ * compute_continuous_mfp_metric (metrics.py:52-57), loss x512 (metrics.py:247-248).
+ */
+typedef struct mfp_loss_key {
+  int32_t col_off;        /* first column of this head in the logits row */
+  int32_t n_feat;         /* N (1, or 3 for color); numerical: 1 */
+  int32_t n_class;        /* C; numerical: vector width (512) */
+  int32_t is_numerical;
+  const void* target;     /* int32 [T, n_feat] or f32 [T, n_class] */
+  const uint8_t* mask;    /* mfp mask [T] */
+  const int32_t* cond_idx;/* [T] values of the loss_condition key (stride cond_stride) or NULL */
+  int32_t cond_stride;
+  uint32_t cond_bits;     /* bit v set <=> condition mask[v] true */
+} mfp_loss_key;
+
+#define MFP_MAX_LOSS_KEYS 16
+/* logits f32 [T, ld]; dlogits cdt [T, ld] (may be NULL: metrics only);
+ * sums f32 [nkeys][3] = {loss_sum (already / B), score_sum, den_sum}, zeroed by the call. */
+int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys /*host*/,
+                     int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
+                     int32_t dl_dtype, mfp_stream_t stream);
+
+/* --------------------------------------------------------------------------- optimizer
+ * Keras Adam + per-variable clipnorm + L2 regularisers (train.py:71-77; utils.py:8-22), fused
+ * over flat f32 buffers w,g,m,v that hold nseg variables back to back.  The buffers are cut
+ * into <=4096-element chunks that never straddle a variable; the (static per model) chunk
+ * table is built once on the host with mfp_adam_chunk_table() and uploaded by the caller.
+ *   g_eff = g*grad_scale + 2*l2[seg]*w                 (L2 regulariser gradient)
+ *   g_eff *= clipnorm / max(||g_eff||_seg, clipnorm)   (Keras clipnorm, per variable)
+ *   Keras Adam with lr_t = lr*sqrt(1-b2^t)/(1-b1^t), eps outside the sqrt.
+ * stats f32 [nseg][2] receives {||g_eff||^2, sum w^2} (pre-update; sum w^2 gives the L2 loss).
+ * shadow (bf16 copy of the updated weights, same layout) may be NULL.
+ * step_t: device int32 scalar, incremented by the call before use (1-based).
+ */
+int64_t mfp_adam_num_chunks(const int32_t* seg_off /*host [nseg+1]*/, int32_t nseg);
+int mfp_adam_chunk_table(const int32_t* seg_off /*host*/, int32_t nseg, int32_t* chunk_seg /*host*/,
+                         int64_t* chunk_beg /*host*/, int32_t* chunk_len /*host*/);
+int mfp_adam_keras(float* w, const float* g, float* m, float* v, uint16_t* shadow,
+                   const int32_t* chunk_seg, const int64_t* chunk_beg, const int32_t* chunk_len,
+                   int64_t nchunks, const float* seg_l2, float* stats, int32_t nseg, int32_t* step_t,
+                   float lr, float beta1, float beta2, float eps, float clipnorm, float grad_scale,
+                   mfp_stream_t stream);
+int mfp_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, mfp_stream_t stream);
+
+/* dy = cdt( keep(seed,offset)[m][n] ? dx[m][n]/(1-p) : 0 ), colsum[n] = sum_m dy (bias grad).
+ * Same Philox stream as MFP_GEMM_DROPOUT for equal (seed, offset); p == 0 -> plain cast.
+ * workspace: mfp_colsum_workspace_bytes(M, N). */
+size_t mfp_colsum_workspace_bytes(int32_t M, int32_t N);
+int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* workspace, size_t workspace_bytes,
+                    int32_t M, int32_t N, float p, uint64_t seed, uint64_t offset, int32_t out_dtype,
+                    mfp_stream_t stream);
+/* colsum[n] = sum_m X[m][n] for a cdt matrix (bias gradients). */
+int mfp_colsum(const void* X, float* colsum, void* workspace, size_t workspace_bytes, int32_t M,
+               int32_t N, int32_t ld, int32_t dtype, mfp_stream_t stream);
+
+/* Hardware probe (tests only): lane mapping of ds_read_b64_tr_b16.  byte_addr int32 [64]
+ * (8-byte aligned offsets into a 4 KiB LDS image whose b16 element e holds e); out u16 [64][4]. */
+int mfp_debug_tr_probe(const int32_t* byte_addr, uint16_t* out, mfp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFP_HIP_H */

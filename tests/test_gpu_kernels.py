@@ -1,0 +1,392 @@
+"""GPU parity tests: every HIP kernel, called through the C-ABI, against the CPU oracle.
+
+Tolerances: f32 path 1e-4 abs on O(1) values (exact-f32 MFMA, different summation order);
+bf16 path = deviation from the f32 oracle with bf16-rounded operands, 2e-2 relative.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from mfp.hip import ops
+    return ops
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def assert_close(got, want, atol, rtol, what=""):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), "%s: max err %.3e (tol %.1e/%.1e), %d/%d bad, worst want=%.4f got=%.4f" % (
+        what, err.max().item(), atol, rtol, int(bad.sum()), bad.numel(),
+        want.flatten()[err.argmax()].item(), got.flatten()[err.argmax()].item())
+
+
+# ---------------------------------------------------------------------------- hardware probe
+def test_tr_read_lane_mapping():
+    """ds_read_b64_tr_b16: out[lane i][j] = in[lane 4j + i/4][i%4] per 16-lane group."""
+    ops = _ops()
+    lanes = torch.arange(64)
+    # (a) linear addresses: lane l -> byte 8*l
+    out = ops.tr_probe((lanes * 8).to(torch.int32).to(DEV)).cpu().to(torch.int64)
+    l = lanes[:, None]
+    j = torch.arange(4)[None, :]
+    assert torch.equal(out, (l & 15) + j * 16 + (l >> 4) * 64)
+    # (b) the row-strided pattern the kernels use: rows of 40 elements
+    ld = 40
+    li, lg = lanes & 15, lanes >> 4
+    addr = ((8 * lg + (li >> 2)) * ld + (li & 3) * 4) * 2
+    out = ops.tr_probe(addr.to(torch.int32).to(DEV)).cpu().to(torch.int64)
+    want = (8 * lg[:, None] + j) * ld + li[:, None]  # element [k = 8g + j][col = i]
+    assert torch.equal(out, want)
+
+
+# ------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(256, 128, 64), (200, 136, 72), (128, 256, 512), (1000, 376, 128), (64, 8, 8)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain(dtype, layout, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    if layout == "wgrad" and M % 8:
+        pytest.skip("wgrad needs M % 8 == 0")
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    if dtype == torch.bfloat16:
+        A, Bm = bf16_round(A), bf16_round(Bm)
+    want = A.double() @ Bm.double()
+    if layout == "fwd":
+        a_dev, b_dev, ak, bk = A, Bm, True, False
+    elif layout == "dgrad":
+        a_dev, b_dev, ak, bk = A, Bm.t().contiguous(), True, True
+    else:
+        a_dev, b_dev, ak, bk = A.t().contiguous(), Bm, False, False
+    got = ops.gemm(a_dev.to(DEV, dtype), b_dev.to(DEV, dtype), M, N, K, a_kmajor=ak, b_kmajor=bk,
+                   out_dtype=torch.float32, splitk=3 if layout == "wgrad" else 1)
+    assert_close(got, want, 2e-4 * math.sqrt(K), 1e-5, "gemm %s %s" % (layout, dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 256, 128
+    A, W = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) * 0.1
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    if dtype == torch.bfloat16:
+        A, W = bf16_round(A), bf16_round(W)
+    Ad, Wd = A.to(DEV, dtype), W.to(DEV, dtype)
+    base = A.double() @ W.double() + bias.double()
+    tol = dict(atol=3e-4, rtol=1e-5)
+    # bias + relu -> cdt output
+    got = ops.gemm(Ad, Wd, M, N, K, a_kmajor=True, b_kmajor=False, bias=bias.to(DEV), relu=True, out_dtype=dtype)
+    want = base.clamp(min=0)
+    if dtype == torch.bfloat16:
+        assert_close(got, want, 1e-2, 1e-2, "bias+relu bf16 out")
+    else:
+        assert_close(got, want, what="bias+relu", **tol)
+    # bias + residual (f32 out)
+    got = ops.gemm(Ad, Wd, M, N, K, a_kmajor=True, b_kmajor=False, bias=bias.to(DEV), residual=res.to(DEV),
+                   out_dtype=torch.float32)
+    assert_close(got, base + res.double(), what="bias+residual", **tol)
+    # accumulate + rowskip
+    code = (torch.rand(M, generator=g) < 0.3).to(torch.uint8)
+    C0 = torch.randn(M, N, generator=g)
+    out = C0.clone().to(DEV)
+    ops.gemm(Ad, Wd, M, N, K, a_kmajor=True, b_kmajor=False, bias=bias.to(DEV), out=out, accum=True,
+             rowskip=code.to(DEV))
+    want = C0.double() + base * (code == 0)[:, None]
+    assert_close(out, want, what="accum+rowskip", **tol)
+    # dgrad with relu mask
+    H = torch.randn(M, K, generator=g)
+    dY = torch.randn(M, N, generator=g)
+    if dtype == torch.bfloat16:
+        dY = bf16_round(dY)
+    got = ops.gemm(dY.to(DEV, dtype), Wd, M, K, N, a_kmajor=True, b_kmajor=True, out_dtype=dtype,
+                   relu_bwd_aux=H.to(DEV, dtype))
+    want = (dY.double() @ W.double().t()) * (H.to(dtype).double() > 0)
+    if dtype == torch.bfloat16:
+        assert_close(got, want, 2e-2, 1e-2, "relu_bwd bf16")
+    else:
+        assert_close(got, want, what="relu_bwd", **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_wgrad_colsum_rowskip(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    T, M, N = 1500, 128, 264
+    X, dY = torch.randn(T, M, generator=g), torch.randn(T, N, generator=g)
+    if dtype == torch.bfloat16:
+        X, dY = bf16_round(X), bf16_round(dY)
+    code = (torch.rand(T, generator=g) < 0.25).to(torch.uint8)
+    keep = (code == 0).double()[:, None]
+    colsum = torch.empty(N, device=DEV)
+    got = ops.gemm(X.to(DEV, dtype), dY.to(DEV, dtype), M, N, T, a_kmajor=False, b_kmajor=False,
+                   out_dtype=torch.float32, colsum=colsum, rowskip_b=code.to(DEV), splitk=5)
+    assert_close(got, X.double().t() @ (dY.double() * keep), 2e-3, 1e-5, "wgrad")
+    assert_close(colsum, (dY.double() * keep).sum(0), 2e-3, 1e-5, "colsum")
+
+
+def test_gemm_dropout_matches_dropout_bwd():
+    ops = _ops()
+    M, N, K, p, seed, off = 512, 256, 64, 0.1, 1234, 77
+    A = torch.randn(M, K).to(DEV)
+    W = torch.randn(K, N).to(DEV)
+    plain = ops.gemm(A, W, M, N, K, a_kmajor=True, b_kmajor=False)
+    dropped = ops.gemm(A, W, M, N, K, a_kmajor=True, b_kmajor=False, dropout=(p, seed, off))
+    colsum = torch.empty(N, device=DEV)
+    via_bwd = ops.dropout_bwd(plain, torch.float32, colsum, p, seed, off)
+    assert torch.equal(dropped, via_bwd)  # identical Philox stream
+    keep = (dropped != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.01
+    assert_close(colsum, via_bwd.double().sum(0).cpu(), 1e-2, 1e-5, "dropout colsum")
+    kept = dropped != 0
+    assert_close(dropped[kept], plain[kept] / (1 - p), 1e-5, 1e-5, "scale")
+    other = ops.gemm(A, W, M, N, K, a_kmajor=True, b_kmajor=False, dropout=(p, seed, off + 1))
+    assert not torch.equal(other, dropped)
+
+
+# ------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,D", [(37, 128), (1000, 256), (130, 512)])
+def test_layernorm(dtype, T, D):
+    ops = _ops()
+    g = torch.Generator().manual_seed(T + D)
+    x = (torch.randn(T, D, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(D, generator=g)).requires_grad_(True)
+    mean = x.mean(-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(-1, keepdim=True)
+    y = (x - mean) / torch.sqrt(var + 1e-3) * gamma + beta
+    dy = torch.randn(T, D, generator=g)
+    if dtype == torch.bfloat16:
+        dy = bf16_round(dy)
+    dres = torch.randn(T, D, generator=g)
+    y.backward(dy)
+    yd, md, rd = ops.layernorm_fwd(x.detach().to(DEV), gamma.detach().to(DEV), beta.detach().to(DEV), dtype)
+    if dtype == torch.float32:
+        assert_close(yd, y, 1e-5, 1e-5, "ln fwd")
+    else:
+        assert_close(yd, y, 2e-2, 1e-2, "ln fwd bf16")
+    assert_close(md, mean[:, 0], 1e-5, 1e-5, "mean")
+    dg, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV, dtype), x.detach().to(DEV), gamma.detach().to(DEV), md, rd,
+                           dres.to(DEV), dg, db)
+    assert_close(dx, x.grad + dres, 2e-5, 1e-5, "ln dx")
+    assert_close(dg, gamma.grad, 1e-3, 1e-5, "ln dgamma")
+    assert_close(db, beta.grad, 1e-3, 1e-5, "ln dbeta")
+
+
+# ------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, nvalid, B, S, H):
+    D = qkv.shape[1] // 3
+    hd = D // H
+    q, k, v = [t.reshape(B, S, H, hd).permute(0, 2, 1, 3) for t in qkv.split(D, dim=1)]
+    score = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    mask = (torch.arange(S)[None, :] < nvalid[:, None]).to(qkv.dtype)[:, None, None, :]
+    score = score + -1e9 * (1.0 - mask)
+    w = torch.softmax(score, dim=-1)
+    return (w @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,H,hd", [(2, 32, 8, 16), (3, 128, 8, 32), (2, 50, 8, 32), (1, 7, 4, 32),
+                                       (2, 256, 2, 64), (2, 100, 2, 16)])
+def test_attention(dtype, B, S, H, hd):
+    ops = _ops()
+    if dtype == torch.float32 and S * (hd + 1) * 16 > 150 * 1024:
+        pytest.skip("f32 parity kernel LDS limit")
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    D = H * hd
+    qkv = torch.randn(B * S, 3 * D, generator=g)
+    dout = torch.randn(B * S, D, generator=g)
+    if dtype == torch.bfloat16:
+        qkv, dout = bf16_round(qkv), bf16_round(dout)
+    nvalid = torch.randint(1, S + 1, (B,), generator=g)
+    nvalid[0] = S
+    qkv64 = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qkv64, nvalid, B, S, H)
+    ref.backward(dout.double())
+    nv = nvalid.to(torch.int32).to(DEV)
+    out, lse = ops.attention_fwd(qkv.to(DEV, dtype), nv, B, S, H)
+    if dtype == torch.float32:
+        assert_close(out, ref, 2e-5, 1e-5, "attn fwd")
+    else:
+        assert_close(out, ref, 2e-2, 2e-2, "attn fwd bf16")
+    # backward consumes the kernel's own forward output (as the train step does)
+    dqkv = ops.attention_bwd(qkv.to(DEV, dtype), nv, out, dout.to(DEV, dtype), lse, B, S, H)
+    if dtype == torch.float32:
+        assert_close(dqkv, qkv64.grad, 5e-5, 1e-4, "attn bwd")
+    else:
+        assert_close(dqkv, qkv64.grad, 6e-2, 3e-2, "attn bwd bf16")
+
+
+# ------------------------------------------------------------------------------- embedding
+def test_embed_pool_and_row_flags():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    T, D = 700, 128
+    sizes = [9, 66, 66, 10, 18, 18, 18, 2, 2]
+    rowoff = torch.tensor([0, 9, 75, 141, 151, 151, 151, 169, 171], dtype=torch.int32)
+    ROWS = 173
+    tables = torch.randn(ROWS, D, generator=g)
+    idx = torch.stack([torch.randint(0, s, (T,), generator=g) for s in sizes], dim=1).to(torch.int32)
+    idx[:, 7] = torch.randint(-1, 2, (T,), generator=g)  # special columns may be skipped
+    idx[:, 8] = torch.randint(-1, 2, (T,), generator=g)
+    want = torch.zeros(T, D, dtype=torch.float64)
+    for c in range(len(sizes)):
+        ok = idx[:, c] >= 0
+        want[ok] += tables.double()[(rowoff[c] + idx[ok, c]).long()]
+    got = ops.embed_pool_fwd(idx.to(DEV), rowoff.to(DEV), tables.to(DEV))
+    assert_close(got, want, 1e-5, 1e-6, "embed fwd")
+    dout = torch.randn(T, D, generator=g)
+    dwant = torch.zeros(ROWS, D, dtype=torch.float64)
+    for c in range(len(sizes)):
+        ok = idx[:, c] >= 0
+        dwant.index_add_(0, (rowoff[c] + idx[ok, c]).long(), dout.double()[ok])
+    dt = torch.full((ROWS, D), float("nan"), device=DEV)
+    ops.embed_pool_bwd(idx.to(DEV), rowoff.to(DEV), dout.to(DEV), dt)
+    assert_close(dt, dwant, 2e-4, 1e-5, "embed bwd")
+    # row flags
+    x = torch.randn(T, 512, generator=g)
+    x[::5] = 10.0
+    x[1::7] = 0.0
+    x[3, 0] = 0.0
+    code = torch.empty(T, dtype=torch.uint8, device=DEV)
+    sp = torch.full((T, 3), 7, dtype=torch.int32, device=DEV)
+    ops.row_flags(x.to(DEV), code, sp[:, 1:], 3)
+    want_code = torch.where((x == 0.0).all(1), 2, torch.where((x == 10.0).all(1), 1, 0))
+    assert torch.equal(code.cpu().long(), want_code)
+    assert torch.equal(sp[:, 1].cpu().long(), want_code - 1)
+    assert (sp[:, 0] == 7).all() and (sp[:, 2] == 7).all()
+
+
+# ---------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("dl_dtype", [torch.float32, torch.bfloat16])
+def test_losses_vs_oracle(dl_dtype):
+    ops = _ops()
+    from oracle import torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    ic = make_input_columns("crello")
+    B, S = 5, 12
+    batch = synthetic_batch(ic, B, S, seed=4, ragged=True)
+    g = torch.Generator().manual_seed(9)
+    keys = [k for k, c in ic.items() if c.get("is_sequence") and not c.get("demo_only")]
+    pred, masks = {}, {}
+    col, layout = 0, {}
+    for k in keys:
+        c = ic[k]
+        n = c["shape"][-1] * c["input_dim"] if c["type"] == "categorical" else c["shape"][-1]
+        layout[k] = (col, n)
+        col += n
+    U = (col + 7) // 8 * 8
+    logits = torch.randn(B * S, U, generator=g) * 3
+    logits[0, :7] = torch.tensor([40.0, -40, 0, 0, 0, 0, 0])  # forces the 1e-7 clip branch
+    for k in keys:
+        c = ic[k]
+        o, n = layout[k]
+        sl = logits[:, o:o + n].reshape(B, S, -1)
+        pred[k] = (sl.reshape(B, S, c["shape"][-1], c["input_dim"]) if c["type"] == "categorical" else sl
+                   ).double().requires_grad_(True)
+        masks[k] = torch.rand(B, S, generator=g) < 0.6
+    masks["opacity"][:] = False  # den == 0 -> score 1.0 path
+    y64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    loss_total, losses, scores, metrics = torch_ref.loss_layer(ic, y64, pred, masks, S)
+    loss_total.backward()
+    descr = []
+    types = batch["type"].to(DEV)
+    dev_keep = [types]
+    for k in keys:
+        c = ic[k]
+        o, n = layout[k]
+        tgt = batch[k].to(DEV).contiguous()
+        msk = masks[k].to(torch.uint8).to(DEV).contiguous()
+        dev_keep += [tgt, msk]
+        d = dict(col_off=o, n_feat=c["shape"][-1] if c["type"] == "categorical" else 1,
+                 n_class=c["input_dim"] if c["type"] == "categorical" else c["shape"][-1],
+                 is_numerical=c["type"] != "categorical", target=tgt, mask=msk)
+        if "loss_condition" in c:
+            bits = sum(1 << i for i, f in enumerate(c["loss_condition"]["mask"]) if f)
+            d.update(cond_idx=types, cond_stride=1, cond_bits=bits)
+        descr.append(d)
+    nvalid = (batch["length"].reshape(-1) + 1).to(torch.int32).to(DEV)
+    sums, dl = ops.loss_fwd_bwd(logits.to(DEV), descr, nvalid, B, S, dl_dtype)
+    sums = sums.cpu().double()
+    for i, k in enumerate(keys):
+        assert abs(sums[i, 0].item() - float(losses[k])) < 1e-4 * max(1.0, abs(float(losses[k]))), k
+        assert abs(sums[i, 1].item() - float(scores[k + "_score_num"])) < 1e-4, k
+        assert abs(sums[i, 2].item() - float(scores[k + "_score_den"])) < 1e-6, k
+        o, n = layout[k]
+        want = pred[k].grad.reshape(B * S, n)
+        if dl_dtype == torch.float32:
+            assert_close(dl[:, o:o + n], want, 1e-6, 1e-4, "dlogits " + k)
+        else:
+            assert_close(dl[:, o:o + n], want, 1e-4, 1e-2, "dlogits bf16 " + k)
+    assert (dl[:, col:] == 0).all()
+
+
+# ------------------------------------------------------------------------------- optimizer
+def test_adam_keras_vs_oracle():
+    ops = _ops()
+    from oracle import np_ref
+    rng = np.random.default_rng(0)
+    sizes = [5000, 7, 4096, 12289, 256]
+    l2 = [1e-2, 1e-2, 0.0, 1e-2, 0.0]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    n = int(off[-1])
+    w = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    wd, md, vd = [torch.from_numpy(a.copy()).to(DEV) for a in (w, m, v)]
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    chunks = ops.AdamChunks(off.tolist(), DEV)
+    seg_l2 = torch.tensor(l2, dtype=torch.float32, device=DEV)
+    stats = torch.empty(len(sizes), 2, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    w64, m64, v64 = w.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in range(1, 4):
+        gnp = (rng.standard_normal(n) * (10.0 if t == 2 else 0.01)).astype(np.float32)
+        ops.adam_keras(wd, torch.from_numpy(gnp).to(DEV), md, vd, shadow, chunks, seg_l2, stats, step,
+                       lr=1e-2, clipnorm=1.0, grad_scale=0.5)
+        wsq = []
+        for s in range(len(sizes)):
+            sl = slice(off[s], off[s + 1])
+            ge = gnp[sl].astype(np.float64) * 0.5 + 2 * l2[s] * w64[sl]
+            wsq.append((w64[sl] ** 2).sum())
+            gc = np_ref.clip_by_norm(ge, 1.0)
+            w64[sl], m64[sl], v64[sl] = np_ref.adam_keras_step(w64[sl], gc, m64[sl], v64[sl], t, lr=1e-2)
+        assert int(step.item()) == t
+        np.testing.assert_allclose(stats[:, 1].cpu().numpy(), np.array(wsq), rtol=1e-4)
+        np.testing.assert_allclose(wd.cpu().numpy(), w64, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(md.cpu().numpy(), m64, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(vd.cpu().numpy(), v64, rtol=1e-4, atol=1e-10)
+    assert torch.equal(shadow.cpu(), wd.cpu().to(torch.bfloat16))
+
+
+def test_cast_and_colsum():
+    ops = _ops()
+    x = torch.randn(1003, 264)
+    xd = x.to(DEV)
+    dst = torch.empty(x.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(xd.reshape(-1), dst)
+    assert torch.equal(dst.cpu(), x.reshape(-1).to(torch.bfloat16))
+    out = torch.empty(264, device=DEV)
+    ops.colsum(xd, out, 1003, 264)
+    assert_close(out, x.double().sum(0), 1e-3, 1e-5, "colsum f32")
+    ops.colsum(dst.reshape(1003, 264), out, 1003, 264)
+    assert_close(out, x.to(torch.bfloat16).double().sum(0), 1e-3, 1e-5, "colsum bf16")
