@@ -30,11 +30,12 @@ struct GemmParams {
   const void* A; const void* B; void* C;
   const float* bias; const float* residual; const void* aux; const unsigned char* rowcode;
   float* ws;       // split-K partial C [splitk][M][N]
-  float* ws_col;   // split-K partial colsum [splitk][N]
+  float* ws_col;   // split-K partial colsum [splitk][M]
   int M, N, K, lda, ldb, ldc;
   int out_bf16, flags, kchunk;
   float dropout_p;
   unsigned long long seed, offset;
+  const int* step_ptr;
   int tiles_m, tiles_n;
 };
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   constexpr int A_CH = A_ROWS * A_CPR / NT, B_CH = B_ROWS * B_CPR / NT;
   __shared__ __attribute__((aligned(16))) T As[A_ROWS * LDA_S];
   __shared__ __attribute__((aligned(16))) T Bs[B_ROWS * LDB_S];
-  __shared__ float colsum_s[BN];
+  __shared__ float colsum_s[BM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bool do_colsum = (p.flags & MFP_GEMM_COLSUM_B) && tm == 0;
-  const bool rowskip_b = (p.flags & MFP_GEMM_ROWSKIP_B) != 0;
+  const bool do_colsum = (p.flags & MFP_GEMM_COLSUM_A) && tn == 0;
+  const bool rowskip_a = (p.flags & MFP_GEMM_ROWSKIP_A) != 0;
   float csum[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) csum[e] = 0.f;
@@ -103,7 +104,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
         ra[c] = load_chunk(Ag, (long long)m * p.lda + k, m < p.M && k < kend);
       } else {
         int k = k0 + row, m = m0 + col;
-        ra[c] = load_chunk(Ag, (long long)k * p.lda + m, k < kend && m < p.M);
+        bool ok = k < kend && m < p.M;
+        if (rowskip_a && ok) ok = p.rowcode[k] == 0;
+        ra[c] = load_chunk(Ag, (long long)k * p.lda + m, ok);
       }
     }
 #pragma unroll
@@ -114,9 +117,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
         rb[c] = load_chunk(Bg, (long long)n * p.ldb + k, n < p.N && k < kend);
       } else {
         int k = k0 + row, n = n0 + col;
-        bool ok = k < kend && n < p.N;
-        if (rowskip_b && ok) ok = p.rowcode[k] == 0;
-        rb[c] = load_chunk(Bg, (long long)k * p.ldb + n, ok);
+        rb[c] = load_chunk(Bg, (long long)k * p.ldb + n, k < kend && n < p.N);
       }
     }
   };
@@ -125,25 +126,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     for (int c = 0; c < A_CH; ++c) {
       int ch = tid + c * NT, row = ch / A_CPR, col = (ch % A_CPR) * EPC;
       *reinterpret_cast<u32x4*>(&As[row * LDA_S + col]) = ra[c];
-    }
-#pragma unroll
-    for (int c = 0; c < B_CH; ++c) {
-      int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
-      *reinterpret_cast<u32x4*>(&Bs[row * LDB_S + col]) = rb[c];
-      if (!B_KMAJOR && do_colsum) {
-        // B_CPR chunks per row and NT % B_CPR == 0: a thread always owns the same columns.
+      if (!A_KMAJOR && do_colsum) {
+        // A_CPR chunks per row and NT % A_CPR == 0: a thread always owns the same columns.
         if (IS_BF16) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            unsigned int w = rb[c][e];
+            unsigned int w = ra[c][e];
             csum[2 * e] += bf16_to_f32((unsigned short)(w & 0xffffu));
             csum[2 * e + 1] += bf16_to_f32((unsigned short)(w >> 16));
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) csum[e] += __uint_as_float(rb[c][e]);
+          for (int e = 0; e < 4; ++e) csum[e] += __uint_as_float(ra[c][e]);
         }
       }
+    }
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
+      *reinterpret_cast<u32x4*>(&Bs[row * LDB_S + col]) = rb[c];
     }
   };
 
@@ -207,16 +208,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     }
   }
 
-  // ---- bias-gradient column sums of B (wgrad, m-tile 0 only)
-  if (!B_KMAJOR && do_colsum) {
-    if (tid < BN) colsum_s[tid] = 0.f;
+  // ---- bias-gradient column sums of A = dY (wgrad, n-tile 0 only)
+  if (!A_KMAJOR && do_colsum) {
+    if (tid < BM) colsum_s[tid] = 0.f;
     __syncthreads();
-    // every thread owns EPC columns starting at (tid % B_CPR) * EPC (same for all its chunks)
-    int col = (tid % B_CPR) * EPC;
+    // every thread owns EPC columns starting at (tid % A_CPR) * EPC (same for all its chunks)
+    int col = (tid % A_CPR) * EPC;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) atomicAdd(&colsum_s[col + e], csum[e]);
     __syncthreads();
-    if (tid < BN && n0 + tid < p.N) p.ws_col[(long long)kz * p.N + n0 + tid] = colsum_s[tid];
+    if (tid < BM && m0 + tid < p.M) p.ws_col[(long long)kz * p.M + m0 + tid] = colsum_s[tid];
   }
 
   // ---- epilogue
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   }
 
   const float inv_keep = (flags & MFP_GEMM_DROPOUT) ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const unsigned long long rng_off = p.offset + (p.step_ptr ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
       if (col >= p.N || row >= p.M) continue;
       float bias = (flags & MFP_GEMM_BIAS) ? p.bias[col] : 0.f;
       unsigned int rnd[4] = {0u, 0u, 0u, 0u};
-      if (flags & MFP_GEMM_DROPOUT) philox4x32(p.seed, (unsigned int)col, (unsigned int)(row >> 2), p.offset, rnd);
+      if (flags & MFP_GEMM_DROPOUT) philox4x32(p.seed, (unsigned int)col, (unsigned int)(row >> 2), rng_off, rnd);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (row + r >= p.M) break;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     }
 }
 
-// out[m][n] (+)= sum_z ws[z][m][n];  colsum[n] = sum_z ws_col[z][n]
+// out[m][n] (+)= sum_z ws[z][m][n];  colsum[m] = sum_z ws_col[z][m]
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_col,
                                      float* __restrict__ C, float* __restrict__ colsum, int M, int N,
                                      int ldc, int splitk, int accum) {
@@ -288,10 +290,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
     *c = accum ? *c + s : s;
   }
   if (colsum != nullptr) {
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
       float s = 0.f;
-      for (int z = 0; z < splitk; ++z) s += ws_col[(long long)z * N + n];
-      colsum[n] = s;
+      for (int z = 0; z < splitk; ++z) s += ws_col[(long long)z * M + m];
+      colsum[m] = s;
     }
   }
 }
@@ -312,7 +314,7 @@ int launch_gemm(const mfp_gemm_args* a, const GemmParams& p, dim3 grid, hipStrea
 }
 
 bool uses_workspace(const mfp_gemm_args* a) {
-  return a->splitk > 1 || (a->flags & (MFP_GEMM_COLSUM_B | MFP_GEMM_ROWSKIP_B));
+  return a->splitk > 1 || (a->flags & (MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A));
 }
 
 }  // namespace
@@ -320,7 +322,7 @@ bool uses_workspace(const mfp_gemm_args* a) {
 extern "C" size_t mfp_gemm_workspace_bytes(const mfp_gemm_args* a) {
   if (!uses_workspace(a)) return 0;
   int sk = a->splitk < 1 ? 1 : a->splitk;
-  return ((size_t)sk * a->M * a->N + (size_t)sk * a->N) * sizeof(float);
+  return ((size_t)sk * a->M * a->N + (size_t)sk * a->M) * sizeof(float);
 }
 
 extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
@@ -337,9 +339,9 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   const int splitk = a->splitk < 1 ? 1 : a->splitk;
   const bool wgrad = !a->a_kmajor && !a->b_kmajor;
   MFP_CHECK_ARG(splitk == 1 || wgrad);
-  if (a->flags & (MFP_GEMM_COLSUM_B | MFP_GEMM_ROWSKIP_B)) MFP_CHECK_ARG(wgrad);
-  if (a->flags & MFP_GEMM_COLSUM_B) MFP_CHECK_ARG(a->colsum != nullptr);
-  if (a->flags & (MFP_GEMM_ROWSKIP | MFP_GEMM_ROWSKIP_B)) MFP_CHECK_ARG(a->rowcode != nullptr);
+  if (a->flags & (MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A)) MFP_CHECK_ARG(wgrad);
+  if (a->flags & MFP_GEMM_COLSUM_A) MFP_CHECK_ARG(a->colsum != nullptr);
+  if (a->flags & (MFP_GEMM_ROWSKIP | MFP_GEMM_ROWSKIP_A)) MFP_CHECK_ARG(a->rowcode != nullptr);
   if (a->flags & MFP_GEMM_BIAS) MFP_CHECK_ARG(a->bias != nullptr);
   if (a->flags & MFP_GEMM_RESIDUAL) MFP_CHECK_ARG(a->residual != nullptr);
   if (a->flags & MFP_GEMM_RELU_BWD) MFP_CHECK_ARG(a->aux != nullptr);
@@ -348,7 +350,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   const bool ws_path = uses_workspace(a);
   if (ws_path) {
     MFP_CHECK_ARG(a->out_dtype == MFP_F32);
-    MFP_CHECK_ARG((a->flags & ~(MFP_GEMM_COLSUM_B | MFP_GEMM_ROWSKIP_B | MFP_GEMM_ACCUM)) == 0);
+    MFP_CHECK_ARG((a->flags & ~(MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A | MFP_GEMM_ACCUM)) == 0);
     if (a->workspace == nullptr || a->workspace_bytes < mfp_gemm_workspace_bytes(a)) {
       mfp_set_error("mfp_gemm: workspace too small (%zu < %zu)", a->workspace_bytes,
                     mfp_gemm_workspace_bytes(a));
@@ -362,7 +364,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   p.ws_col = ws_path ? p.ws + (size_t)splitk * a->M * a->N : nullptr;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
   p.out_bf16 = a->out_dtype == MFP_BF16; p.flags = a->flags;
-  p.dropout_p = a->dropout_p; p.seed = a->seed; p.offset = a->offset;
+  p.dropout_p = a->dropout_p; p.seed = a->seed; p.offset = a->offset; p.step_ptr = a->step_ptr;
   p.tiles_m = (a->M + BM - 1) / BM; p.tiles_n = (a->N + BN - 1) / BN;
   const int bk = a->in_dtype == MFP_BF16 ? GemmCfg<unsigned short>::BK : GemmCfg<float>::BK;
   int kchunk = (a->K + splitk - 1) / splitk;
@@ -380,7 +382,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ws_col,
                        reinterpret_cast<float*>(a->C),
-                       (a->flags & MFP_GEMM_COLSUM_B) ? a->colsum : nullptr, a->M, a->N, a->ldc,
+                       (a->flags & MFP_GEMM_COLSUM_A) ? a->colsum : nullptr, a->M, a->N, a->ldc,
                        splitk, (a->flags & MFP_GEMM_ACCUM) ? 1 : 0);
     MFP_CHECK_LAUNCH();
   }

@@ -94,7 +94,9 @@ template <typename TOUT>
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dx, TOUT* __restrict__ dy,
                                                           float* __restrict__ colsum_part, int M, int N,
                                                           float p, unsigned long long seed,
-                                                          unsigned long long offset, int rows_per_block) {
+                                                          unsigned long long offset0, const int* step_ptr,
+                                                          int rows_per_block) {
+  const unsigned long long offset = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
   // block handles columns [blockIdx.x*256, +256) and rows [blockIdx.y*rows_per_block, ...)
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -212,7 +214,8 @@ extern "C" size_t mfp_colsum_workspace_bytes(int32_t M, int32_t N) {
 
 extern "C" int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* workspace,
                                size_t workspace_bytes, int32_t M, int32_t N, float p, uint64_t seed,
-                               uint64_t offset, int32_t out_dtype, mfp_stream_t stream) {
+                               uint64_t offset, const int32_t* step_ptr, int32_t out_dtype,
+                               mfp_stream_t stream) {
   MFP_CHECK_ARG(dx && dy && colsum && M > 0 && N > 0 && p >= 0.f && p < 1.f);
   MFP_CHECK_ARG(out_dtype == MFP_F32 || out_dtype == MFP_BF16);
   if (!workspace || workspace_bytes < mfp_colsum_workspace_bytes(M, N)) {
@@ -224,9 +227,9 @@ extern "C" int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* w
   dim3 grid((N + 255) / 256, nrb);
   float* part = reinterpret_cast<float*>(workspace);
   if (out_dtype == MFP_F32)
-    hipLaunchKernelGGL(dropout_bwd_kernel<float>, grid, dim3(256), 0, st, dx, (float*)dy, part, M, N, p, seed, offset, rpb);
+    hipLaunchKernelGGL(dropout_bwd_kernel<float>, grid, dim3(256), 0, st, dx, (float*)dy, part, M, N, p, seed, offset, step_ptr, rpb);
   else
-    hipLaunchKernelGGL(dropout_bwd_kernel<unsigned short>, grid, dim3(256), 0, st, dx, (unsigned short*)dy, part, M, N, p, seed, offset, rpb);
+    hipLaunchKernelGGL(dropout_bwd_kernel<unsigned short>, grid, dim3(256), 0, st, dx, (unsigned short*)dy, part, M, N, p, seed, offset, step_ptr, rpb);
   MFP_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, colsum, N, nrb);
   MFP_CHECK_LAUNCH();

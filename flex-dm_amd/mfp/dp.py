@@ -1,0 +1,77 @@
+"""Single-node data parallelism: one process per GPU, RCCL (torch.distributed "nccl") over xGMI.
+
+The reference has no distributed code (train.py:25 is a commented-out MirroredStrategy); this
+is new.  Documents are independent, so the minibatch is sharded on the batch axis with no
+data-path collective; the only exchange is ONE sum all-reduce of the flat f32 gradient buffer
+per step.  Semantics match the single-GPU step on the global batch:
+
+* each rank's LossLayer uses mean over its B/N documents -> averaging gradients over ranks
+  equals the global mean (equal shards);
+* the L2 regulariser gradient and the per-variable clipnorm are applied AFTER averaging
+  (inside the fused Adam kernel, via ``grad_scale = 1/N``);
+* metric numerators/denominators and loss sums are all-reduced for reporting.
+"""
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> int:
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); returns world size."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 1
+    if not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+    return dist.get_world_size()
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_gradients(flat_grad: torch.Tensor, async_op: bool = False):
+    """Sum the flat gradient over ranks in place.  The 1/N factor is folded into the optimizer
+    (``AdamKeras.step(grad_scale=1/N)``) so no extra pass over the buffer is needed."""
+    if world_size() == 1:
+        return None
+    return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def allreduce_sums(sums: torch.Tensor) -> torch.Tensor:
+    """Loss / score sums for metrics: loss column is a per-rank batch mean -> average it;
+    score numerators and denominators are plain sums."""
+    n = world_size()
+    if n == 1:
+        return sums
+    out = sums.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    out[:, 0] /= n
+    return out
+
+
+def broadcast_parameters(flat_w: torch.Tensor, src: int = 0):
+    if world_size() > 1:
+        dist.broadcast(flat_w, src=src)
+
+
+def shard_batch(batch: dict, r: Optional[int] = None, n: Optional[int] = None) -> dict:
+    """Rank r's slice of a global batch (axis 0), equal shards."""
+    r = rank() if r is None else r
+    n = world_size() if n is None else n
+    if n == 1:
+        return batch
+    out = {}
+    for k, v in batch.items():
+        B = v.shape[0]
+        assert B % n == 0, "global batch %d not divisible by world size %d" % (B, n)
+        out[k] = v[r * (B // n):(r + 1) * (B // n)]
+    return out

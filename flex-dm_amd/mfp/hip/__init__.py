@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_s
 MFP_F32, MFP_BF16 = 0, 1
 
 GEMM_BIAS, GEMM_RELU, GEMM_RESIDUAL, GEMM_DROPOUT = 1, 2, 4, 8
-GEMM_ACCUM, GEMM_ROWSKIP, GEMM_RELU_BWD, GEMM_COLSUM_B, GEMM_ROWSKIP_B = 16, 32, 64, 128, 256
+GEMM_ACCUM, GEMM_ROWSKIP, GEMM_RELU_BWD, GEMM_COLSUM_A, GEMM_ROWSKIP_A = 16, 32, 64, 128, 256
 MAX_LOSS_KEYS = 16
 
 LIB_NAME = "libmfp_hip.so"
@@ -38,7 +38,7 @@ class GemmArgs(Structure):
         ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
         ("a_kmajor", c_int32), ("b_kmajor", c_int32),
         ("in_dtype", c_int32), ("out_dtype", c_int32), ("flags", c_int32), ("splitk", c_int32),
-        ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64),
+        ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64), ("step_ptr", c_void_p),
     ]
 
 
@@ -76,7 +76,7 @@ SIGNATURES = {
     "mfp_cast_f32_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mfp_colsum_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mfp_dropout_bwd": (c_int32, [c_void_p] * 4 + [c_size_t, c_int32, c_int32, c_float, c_uint64,
-                                                   c_uint64, c_int32, c_void_p]),
+                                                   c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_colsum": (c_int32, [c_void_p] * 3 + [c_size_t] + [c_int32] * 4 + [c_void_p]),
     "mfp_debug_tr_probe": (c_int32, [c_void_p, c_void_p, c_void_p]),
 }

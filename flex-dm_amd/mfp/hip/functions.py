@@ -1,0 +1,216 @@
+"""``torch.autograd.Function`` wrappers: one per reference Layer on the hot path.
+
+Autograd only chains the activation gradient (element stream ``x``) between these nodes;
+parameter gradients are written by the kernels straight into ``ParamStore.g`` (each variable is
+produced exactly once per step, so the writes are assignments, never accumulations).
+
+    EncoderFn      <-> Encoder.call          (reference architecture/encoder.py:147-199)
+    BlockFn        <-> DeepSVGBlock.call     (architecture/transformer.py:211-229)
+    DecoderFn      <-> Decoder.call          (architecture/decoder.py:95-111)
+    DecoderLossFn  <-> Decoder.call + LossLayer.call fused for the train step
+                                             (decoder.py:95-111 + models/metrics.py:213-299)
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+NUM_HEADS = 8
+
+
+class StepCtx:
+    """Per-call constants shared by the Functions of one forward pass."""
+
+    def __init__(self, store, B: int, S: int, nvalid: torch.Tensor, training: bool, dropout: float,
+                 seed: int, step_ptr: Optional[torch.Tensor]):
+        self.store, self.B, self.S, self.T = store, B, S, B * S
+        self.nvalid = nvalid
+        self.training = training
+        self.p = float(dropout) if training else 0.0
+        self.seed = int(seed)
+        self.step_ptr = step_ptr
+        self.cdt = store.compute_dtype
+
+    def to_cdt(self, x: torch.Tensor) -> torch.Tensor:
+        if self.cdt == torch.float32:
+            return x
+        out = torch.empty(x.shape, dtype=self.cdt, device=x.device)
+        ops.cast_bf16(x.reshape(-1), out.reshape(-1))
+        return out
+
+
+# ------------------------------------------------------------------------------------ encoder
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, anchor, ctx: StepCtx, cat_inputs: List[torch.Tensor], num_inputs: List[torch.Tensor]):
+        st, L = ctx.store, ctx.store.layout
+        T, D = ctx.T, L.D
+        dev = anchor.device
+        n_num = len(L.num_keys)
+        cols = [t.reshape(T, -1).to(torch.int32) for t in cat_inputs]
+        if n_num:
+            cols.append(torch.empty((T, n_num), dtype=torch.int32, device=dev))
+        idx_all = torch.cat(cols, dim=1) if len(cols) > 1 else cols[0].contiguous()
+        assert idx_all.shape[1] == len(L.idx_cols)
+        codes, xs = [], []
+        for j, k in enumerate(L.num_keys):
+            x = num_inputs[j].reshape(T, -1).contiguous()
+            code = torch.empty((T,), dtype=torch.uint8, device=dev)
+            ops.row_flags(x, code, idx_all[:, L.special_col[k]:], idx_all.shape[1])
+            codes.append(code)
+            xs.append(ctx.to_cdt(x))
+        h = ops.embed_pool_fwd(idx_all, st.rowoff, st.tables())
+        for j, k in enumerate(L.num_keys):
+            width = xs[j].shape[1]
+            ops.gemm(xs[j], st.cw("encoder/input_%s/kernel" % k), T, D, width, a_kmajor=True, b_kmajor=True,
+                     out=h, accum=True, rowskip=codes[j], bias=st.weight("encoder/input_%s/bias" % k))
+        fctx.ctx = ctx
+        fctx.saved = (idx_all, codes, xs)
+        return h
+
+    @staticmethod
+    def backward(fctx, dh):
+        ctx = fctx.ctx
+        st, L = ctx.store, ctx.store.layout
+        idx_all, codes, xs = fctx.saved
+        dh = dh.contiguous()
+        T, D = ctx.T, L.D
+        ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
+        if L.num_keys:
+            dh_c = ctx.to_cdt(dh)
+            for j, k in enumerate(L.num_keys):
+                width = xs[j].shape[1]
+                ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
+                         out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
+                         colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
+        fctx.saved = None
+        return None, None, None, None
+
+
+# -------------------------------------------------------------------------------------- block
+class BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, x, ctx: StepCtx, i: int):
+        st = ctx.store
+        D = st.layout.D
+        T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
+        p = "blocks/seq2seq_%d/" % i
+        x = x.contiguous()
+        y1, mean1, rstd1 = ops.layernorm_fwd(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), cdt)
+        qkv = ops.gemm(y1, st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D, a_kmajor=True,
+                       b_kmajor=True, bias=st.span(st.w, p + "attn/dense_query/bias", 3 * D), out_dtype=cdt)
+        a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
+        x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
+                      bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
+                      dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
+        y2, mean2, rstd2 = ops.layernorm_fwd(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"), cdt)
+        h = ops.gemm(y2, st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, a_kmajor=True, b_kmajor=True,
+                     bias=st.weight(p + "mlp/dense_0/bias"), relu=True, out_dtype=cdt)
+        x2 = ops.gemm(h, st.cw(p + "mlp/dense_1/kernel"), T, D, 2 * D, a_kmajor=True, b_kmajor=True,
+                      bias=st.weight(p + "mlp/dense_1/bias"), residual=x1,
+                      dropout=(ctx.p, ctx.seed, 2 * i + 2), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
+        fctx.ctx, fctx.i = ctx, i
+        fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
+        return x2
+
+    @staticmethod
+    def backward(fctx, dx2):
+        ctx, i = fctx.ctx, fctx.i
+        st = ctx.store
+        D = st.layout.D
+        T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
+        p = "blocks/seq2seq_%d/" % i
+        x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = fctx.saved
+        dx2 = dx2.contiguous()
+        sk = ops.wgrad_splitk
+        # ---- MLP: x2 = x1 + drop(h W2 + b2)
+        d_o2 = ops.dropout_bwd(dx2, cdt, st.grad(p + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * i + 2, ctx.step_ptr)
+        dh = ops.gemm(d_o2, st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True, b_kmajor=False,
+                      out_dtype=cdt, relu_bwd_aux=h)
+        ops.gemm(d_o2, h, D, 2 * D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_1/kernel"),
+                 splitk=sk(T, D, 2 * D))
+        ops.gemm(dh, y2, 2 * D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_0/kernel"),
+                 colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
+        dy2 = ops.gemm(dh, st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True, b_kmajor=False, out_dtype=cdt)
+        dx1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
+                                st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"))
+        # ---- attention: x1 = x + drop(a Wo + bo)
+        d_o1 = ops.dropout_bwd(dx1, cdt, st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
+                               ctx.step_ptr)
+        da = ops.gemm(d_o1, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=False,
+                      out_dtype=cdt)
+        ops.gemm(d_o1, a, D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "attn/combine_heads/kernel"),
+                 splitk=sk(T, D, D))
+        dqkv = ops.attention_bwd(qkv, ctx.nvalid, a, da, lse, B, S, NUM_HEADS)
+        ops.gemm(dqkv, y1, 3 * D, D, T, a_kmajor=False, b_kmajor=False,
+                 out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D),
+                 colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D), splitk=sk(T, 3 * D, D))
+        dy1 = ops.gemm(dqkv, st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D, 3 * D, a_kmajor=True,
+                       b_kmajor=False, out_dtype=cdt)
+        dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
+                               st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"))
+        fctx.saved = None
+        return dx, None, None
+
+
+# ------------------------------------------------------------------------------------ decoder
+def _heads_fwd(ctx: StepCtx, h_c: torch.Tensor) -> torch.Tensor:
+    st, L = ctx.store, ctx.store.layout
+    first = next(iter(L.columns))
+    return ops.gemm(h_c, st.cw("decoder/decoder_%s/kernel" % first, rows=L.Upad), ctx.T, L.Upad, L.D,
+                    a_kmajor=True, b_kmajor=True, out_dtype=torch.float32,
+                    bias=st.span(st.w, "decoder/decoder_%s/bias" % first, L.Upad))
+
+
+def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Tensor:
+    st, L = ctx.store, ctx.store.layout
+    first = next(iter(L.columns))
+    T, D, U = ctx.T, L.D, L.Upad
+    dh = ops.gemm(dl_c, st.cw("decoder/decoder_%s/kernel" % first, rows=U), T, D, U, a_kmajor=True,
+                  b_kmajor=False, out_dtype=torch.float32)
+    ops.gemm(dl_c, h_c, U, D, T, a_kmajor=False, b_kmajor=False,
+             out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
+             colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U), splitk=ops.wgrad_splitk(T, U, D))
+    return dh
+
+
+class DecoderFn(torch.autograd.Function):
+    """Heads only: returns the concatenated logits ``[T][Upad]`` (f32)."""
+
+    @staticmethod
+    def forward(fctx, h, ctx: StepCtx):
+        h_c = ctx.to_cdt(h.contiguous())
+        fctx.ctx, fctx.saved = ctx, h_c
+        return _heads_fwd(ctx, h_c)
+
+    @staticmethod
+    def backward(fctx, dlogits):
+        ctx = fctx.ctx
+        dh = _heads_bwd(ctx, ctx.to_cdt(dlogits.contiguous()), fctx.saved)
+        fctx.saved = None
+        return dh, None
+
+
+class DecoderLossFn(torch.autograd.Function):
+    """Heads + fused LossLayer.  Returns ``(loss_total, sums[nkeys,3], logits)``; the backward
+    assumes the conventional unit upstream gradient on ``loss_total``."""
+
+    @staticmethod
+    def forward(fctx, h, ctx: StepCtx, keys: List[dict]):
+        h_c = ctx.to_cdt(h.contiguous())
+        logits = _heads_fwd(ctx, h_c)
+        sums, dl = ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt)
+        fctx.ctx, fctx.saved = ctx, (h_c, dl)
+        fctx.mark_non_differentiable(sums, logits)
+        return sums[:, 0].sum(), sums, logits
+
+    @staticmethod
+    def backward(fctx, dloss, dsums, dlogits):
+        ctx = fctx.ctx
+        h_c, dl = fctx.saved
+        dh = _heads_bwd(ctx, dl, h_c)
+        fctx.saved = None
+        return dh, None, None

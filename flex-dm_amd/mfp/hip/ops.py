@@ -11,8 +11,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_B, GEMM_DROPOUT, GEMM_RELU, GEMM_RELU_BWD,
-               GEMM_RESIDUAL, GEMM_ROWSKIP, GEMM_ROWSKIP_B, MFP_BF16, MFP_F32, GemmArgs, LossKey,
+from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_A, GEMM_DROPOUT, GEMM_RELU, GEMM_RELU_BWD,
+               GEMM_RESIDUAL, GEMM_ROWSKIP, GEMM_ROWSKIP_A, MFP_BF16, MFP_F32, GemmArgs, LossKey,
                check, load)
 
 _DT = {torch.float32: MFP_F32, torch.bfloat16: MFP_BF16}
@@ -59,7 +59,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
          residual: Optional[torch.Tensor] = None, dropout: Optional[Tuple[float, int, int]] = None,
          accum: bool = False, rowskip: Optional[torch.Tensor] = None,
          relu_bwd_aux: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None,
-         rowskip_b: Optional[torch.Tensor] = None, splitk: int = 1,
+         rowskip_a: Optional[torch.Tensor] = None, splitk: int = 1,
+         step_ptr: Optional[torch.Tensor] = None,
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None) -> torch.Tensor:
     """``out[M,N] = epilogue(op(A) @ op(B))`` -- see ``mfp_gemm`` in include/mfp_hip.h."""
     lib = load()
@@ -86,6 +87,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
     if dropout is not None and dropout[0] > 0.0:
         flags |= GEMM_DROPOUT
         a.dropout_p, a.seed, a.offset = float(dropout[0]), int(dropout[1]), int(dropout[2])
+        a.step_ptr = _ptr(step_ptr)
     if accum:
         flags |= GEMM_ACCUM
     if rowskip is not None:
@@ -95,11 +97,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
         flags |= GEMM_RELU_BWD
         a.aux = _ptr(relu_bwd_aux)
     if colsum is not None:
-        flags |= GEMM_COLSUM_B
+        flags |= GEMM_COLSUM_A
         a.colsum = _ptr(colsum)
-    if rowskip_b is not None:
-        flags |= GEMM_ROWSKIP_B
-        a.rowcode = _ptr(rowskip_b)
+    if rowskip_a is not None:
+        flags |= GEMM_ROWSKIP_A
+        a.rowcode = _ptr(rowskip_a)
     a.flags, a.splitk = flags, splitk
     nbytes = lib.mfp_gemm_workspace_bytes(ctypes.byref(a))
     if nbytes:
@@ -260,13 +262,13 @@ def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
 
 
 def dropout_bwd(dx: torch.Tensor, out_dtype: torch.dtype, colsum: torch.Tensor, p: float, seed: int,
-                offset: int) -> torch.Tensor:
+                offset: int, step_ptr: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = load()
     M, N = dx.shape
     dy = torch.empty((M, N), dtype=out_dtype, device=dx.device)
     ws = workspace(lib.mfp_colsum_workspace_bytes(M, N), dx.device)
     check(lib.mfp_dropout_bwd(_ptr(dx), _ptr(dy), _ptr(colsum), ws.data_ptr(), ws.numel(), M, N, float(p),
-                              int(seed), int(offset), dt_code(out_dtype), _stream()), "mfp_dropout_bwd")
+                              int(seed), int(offset), _ptr(step_ptr), dt_code(out_dtype), _stream()), "mfp_dropout_bwd")
     return dy
 
 

@@ -1,0 +1,113 @@
+"""LossLayer: per-attribute masked CE / MSE losses and scores (reference models/metrics.py).
+
+``LossLayer.call`` (metrics.py:173-299) is one fused HIP launch pair (``mfp_loss_fwd_bwd``): the
+per-key loss, score numerator and denominator come back as a ``[nkeys][3]`` tensor and the
+Keras metric names / definitions are reproduced from it:
+
+* ``<key>_loss``  = mean over B of sum over (S, N) of weighted loss          (metrics.py:265-277)
+* ``<key>_score`` = score_sum / den_sum, 1.0 when den == 0                    (metrics.py:279-281)
+* ``total_score`` = sum of <key>_score / len(ALL input_columns)               (metrics.py:298)
+* returned ``[scores]`` holds ``<key>_score_num`` / ``<key>_score_den``        (metrics.py:287-288)
+
+``BeautyLayer`` / ``LayoutMetricLayer`` / ``mae_from_logits`` are unused by train.py and eval.py
+ and are not provided.  The RICO position-sorted variant (``sort_flag``,
+metrics.py:180-211) is a "next" row: accepted only when no flag is set.
+"""
+from typing import Dict, List, Union
+
+import torch
+
+from mfp.data.spec import get_valid_input_columns
+from mfp.hip import ops
+
+
+def loss_key_names(input_columns: Dict) -> List[str]:
+    return [k for k, c in input_columns.items()
+            if not c.get("demo_only", False) and c.get("is_sequence", False)]
+
+
+def build_loss_keys(input_columns: Dict, head_cols: Dict, y_true: Dict, mfp_masks: Dict) -> List[dict]:
+    """Descriptors for ``mfp_loss_fwd_bwd`` (one per sequence attribute, LossLayer order)."""
+    keys = []
+    for key in loss_key_names(input_columns):
+        column = input_columns[key]
+        off, units = head_cols[key]
+        categorical = column["type"] == "categorical"
+        target = y_true[key]
+        if categorical:
+            target = target.to(torch.int32)
+        else:
+            target = target.to(torch.float32)
+        mask = mfp_masks[key]
+        mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        d = dict(col_off=off,
+                 n_feat=column["shape"][-1] if categorical else 1,
+                 n_class=column["input_dim"] if categorical else column["shape"][-1],
+                 is_numerical=not categorical,
+                 target=target.contiguous(), mask=mask.contiguous())
+        if "loss_condition" in column:
+            cond = column["loss_condition"]
+            assert len(cond["mask"]) <= 32, "loss_condition vocabularies above 32 entries unsupported"
+            ck = y_true[cond["key"]].to(torch.int32).contiguous()
+            d.update(cond_idx=ck, cond_stride=ck.shape[-1],
+                     cond_bits=sum(1 << i for i, f in enumerate(cond["mask"]) if f))
+        keys.append(d)
+    return keys
+
+
+def metrics_from_sums(input_columns: Dict, sums: torch.Tensor):
+    """-> (losses{key}, scores{key_score_num/_den}, metrics{...}) from the [nkeys][3] sums."""
+    names = loss_key_names(input_columns)
+    den = sums[:, 2]
+    normalized = torch.where(den == 0.0, torch.ones_like(den), sums[:, 1] / den.clamp(min=1e-30))
+    losses, scores, metrics = {}, {}, {}
+    for i, key in enumerate(names):
+        metrics[key + "_score"] = normalized[i]
+        scores[key + "_score_num"] = sums[i, 1]
+        scores[key + "_score_den"] = sums[i, 2]
+        losses[key] = sums[i, 0]
+    for key, loss in losses.items():
+        metrics[key + "_loss"] = loss
+    metrics["total_score"] = normalized.sum() / len(input_columns)
+    return losses, scores, metrics
+
+
+class LossLayer:
+    def __init__(self, input_columns: Dict, name: str = "loss_layer", predict_context: bool = False,
+                 **kwargs):
+        if predict_context:
+            raise NotImplementedError("predict_context is off the MFP hot path")
+        self.name = name
+        self._input_columns = input_columns
+        self._valid_input_columns = get_valid_input_columns(input_columns)
+        self.losses: List[torch.Tensor] = []
+        self.metrics: Dict[str, torch.Tensor] = {}
+        col, self._head_cols = 0, {}
+        for k, c in self._valid_input_columns.items():
+            units = c["shape"][-1] * c["input_dim"] if c["type"] == "categorical" else c["shape"][-1]
+            self._head_cols[k] = (col, units)
+            col += units
+        self._U = col
+
+    def _flat_logits(self, y_pred: Dict, B: int, S: int) -> torch.Tensor:
+        flat = y_pred.get("_flat_logits")
+        if flat is not None and flat.shape[0] == B * S:
+            return flat
+        parts = [y_pred[k][:, :S].reshape(B * S, -1).to(torch.float32) for k in self._head_cols]
+        return torch.cat(parts, dim=1).contiguous()
+
+    def __call__(self, inputs, training=False, sort_flag: Union[bool, torch.Tensor] = None,
+                 ignore_sort: str = None):
+        y_true, y_pred, mfp_masks = inputs
+        if torch.is_tensor(sort_flag) and bool(sort_flag.any()):
+            raise NotImplementedError("position-sorted RICO loss (metrics.py:180-211) is a 'next' row")
+        first = next(iter(self._head_cols))
+        B, S = y_true[first].shape[:2]
+        logits = self._flat_logits(y_pred, B, S)
+        nvalid = (y_true["length"].reshape(-1) + 1).to(torch.int32)
+        keys = build_loss_keys(self._input_columns, self._head_cols, y_true, mfp_masks)
+        sums, _ = ops.loss_fwd_bwd(logits, keys, nvalid, B, S, None)
+        losses, scores, metrics = metrics_from_sums(self._input_columns, sums)
+        self.losses = [sums[:, 0].sum()]
+        self.metrics = metrics
+        return [scores]

@@ -1,0 +1,431 @@
+"""MFP task wrapper: task sampling, masking, model call, loss hookup, merge (reference
+models/mfp.py) plus the Keras-like ``compile / fit / evaluate / save_weights / load_weights``
+surface that reference train.py:67-97 and eval.py:169-172 use.
+
+The compute (``self.model`` and the loss) runs in HIP kernels; this file is host logic.  What is
+new relative to the reference: ``train_step`` (what Keras' ``Model.train_step`` did implicitly),
+optional hipGraph capture of the whole step, and data-parallel gradient averaging (mfp.dp).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from mfp import dp
+from mfp.data.spec import get_attribute_groups, get_dataset_name
+from mfp.models.architecture.mask import get_seq_mask
+from mfp.models.masking import (apply_token, elem_masking, feat_masking, filter_padding,
+                                get_task_names, random_masking)
+from mfp.models.metrics import LossLayer, build_loss_keys, loss_key_names, metrics_from_sums
+from mfp.models.model import Model
+from mfp.models.tensor_utils import shuffle_inputs, sort_inputs
+from mfp.optim import AdamKeras
+
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.INFO)
+
+
+def get_task_probs(task_names: List[str], masking_method: str) -> List[float]:
+    """reference mfp.py:34-43 (the Categorical's probabilities)."""
+    used_names = masking_method.split("_")
+    probs = [1.0 if name in used_names else 0.0 for name in task_names]
+    probs_total = sum(probs)
+    assert probs_total > 0.0
+    probs = [p / probs_total for p in probs]
+    logger.info([item for item in zip(task_names, probs)])
+    return probs
+
+
+def merge_inputs_and_prediction(inputs, input_columns, masks, prediction):
+    """reference mfp.py:46-69."""
+    for key, column in input_columns.items():
+        if column.get("demo_only", False):
+            continue
+        if not column["is_sequence"]:
+            prediction[key] = inputs[key]
+        elif key not in masks.keys():
+            continue
+        elif column["type"] == "numerical":
+            cond = masks[key][..., None]
+            prediction[key] = torch.where(cond, prediction[key], inputs[key].to(prediction[key].dtype))
+        else:
+            gt = torch.nn.functional.one_hot(inputs[key].to(torch.int64), column["input_dim"])
+            cond = masks[key][..., None, None]
+            prediction[key] = torch.where(cond, prediction[key], gt.to(prediction[key].dtype))
+    for key, column in input_columns.items():
+        if column.get("demo_only", False) and key in inputs:
+            prediction[key] = inputs[key]
+    return prediction
+
+
+def preprocess_for_test(inputs, input_columns, masks, tasks=None):
+    """reference mfp.py:72-92."""
+    S = inputs["left"].shape[1]
+    seq_mask = get_seq_mask(inputs["length"], maxlen=S)
+    filtered_inputs = filter_padding(inputs, input_columns, seq_mask)
+    modified_inputs = {}
+    for key, column in input_columns.items():
+        if not column["is_sequence"]:
+            modified_inputs[key] = filtered_inputs[key]
+            continue
+        modified_inputs[key] = apply_token(filtered_inputs[key], column, masks[key], "masked")
+    if tasks is None:
+        tasks = torch.zeros(inputs["left"].shape[0], device=inputs["left"].device)
+    modified_inputs["task"] = tasks[..., None]
+    return modified_inputs
+
+
+def preprocess_for_train(inputs: Dict[str, torch.Tensor], input_columns: Dict, tasks: torch.Tensor,
+                         is_autoreg: bool = False, input_dtype: str = "set",
+                         active_tasks: Optional[List[int]] = None, generator=None):
+    """reference mfp.py:95-138.  ``active_tasks`` (new, optional) lists the task ids that can
+    occur (non-zero sampling probability); variants of other tasks are never selected by the
+    ``where`` below, so they are not computed at all."""
+    assert tasks.dim() == 1
+    attribute_groups = get_attribute_groups(input_columns.keys())
+    if is_autoreg or input_dtype == "shuffled_set":
+        inputs = shuffle_inputs(inputs)
+    elif input_dtype == "sorted_set":
+        inputs = sort_inputs(inputs, input_columns)
+    S = inputs["left"].shape[1]
+    seq_mask = get_seq_mask(inputs["length"], maxlen=S)
+    filtered_inputs = filter_padding(inputs, input_columns, seq_mask)
+
+    def wanted(i):
+        return active_tasks is None or i in active_tasks
+
+    if wanted(0):
+        modified_inputs, masks = random_masking(filtered_inputs, input_columns, seq_mask, generator=generator)
+    else:  # task 0 never sampled: start from the unmodified inputs / all-False masks
+        modified_inputs = dict(filtered_inputs)
+        masks = {k: (torch.zeros_like(seq_mask) if c["is_sequence"] else None)
+                 for k, c in input_columns.items()}
+        masks = {k: v for k, v in masks.items() if v is not None}
+    data = []
+    data.append(elem_masking(filtered_inputs, input_columns, seq_mask, is_autoreg, generator)
+                if wanted(1) else None)
+    for gi, attribute_group in enumerate(attribute_groups.values()):
+        data.append(feat_masking(filtered_inputs, input_columns, seq_mask, attribute_group)
+                    if wanted(gi + 2) else None)
+    for key in list(modified_inputs.keys()):
+        for i, item in enumerate(data):
+            if item is None:
+                continue
+            modified_inputs_tmp, masks_tmp = item
+            cond = tasks == (i + 1)
+            if input_columns[key]["is_sequence"]:
+                cond = cond[..., None]
+            modified_inputs[key] = torch.where(cond[..., None], modified_inputs_tmp[key], modified_inputs[key])
+            if input_columns[key]["is_sequence"]:
+                masks[key] = torch.where(cond, masks_tmp[key], masks[key])
+    modified_inputs["task"] = tasks[..., None]
+    return inputs, modified_inputs, masks
+
+
+def iterative_decode(model, masks, inputs, input_columns, modified_inputs, num_iter):
+    """MaskGIT-like decoding (reference mfp.py:141-207)."""
+    masks = dict(masks)
+    S = inputs["left"].shape[1]
+    seq_mask = get_seq_mask(inputs["length"], maxlen=S)
+    filtered_inputs = filter_padding(inputs, input_columns, seq_mask)
+    categorical_keys = [k for k, v in input_columns.items()
+                        if v["is_sequence"] and v.get("type", None) == "categorical"]
+    num_masked = sum(masks[k].to(torch.int64).sum(-1) for k in categorical_keys)
+    num_update_per_iter = torch.round(num_masked.double() / num_iter).to(torch.int64)
+    final_outputs, outputs = None, None
+    for i in range(num_iter):
+        outputs = model(modified_inputs, training=False)
+        outputs.pop("_flat_logits", None)
+        if i == 0:
+            final_outputs = dict(outputs)
+        confidence = {
+            k: torch.where(masks[k], torch.softmax(outputs[k], dim=-1).max(dim=-1).values.mean(dim=-1),
+                           torch.zeros((), device=masks[k].device))
+            for k in categorical_keys
+        }
+        confidence_sorted = torch.sort(torch.cat([confidence[k] for k in categorical_keys], dim=-1),
+                                       dim=-1, descending=True).values
+        idx = num_update_per_iter.clamp(max=confidence_sorted.shape[1] - 1)
+        threshold = torch.gather(confidence_sorted, 1, idx[:, None])[:, 0]
+        for key in categorical_keys:
+            pred = outputs[key].argmax(dim=-1).to(filtered_inputs[key].dtype)
+            update_field = (confidence[key] >= threshold[:, None]) & (confidence[key] > 0)
+            filtered_inputs[key] = torch.where(update_field[:, :, None], pred, filtered_inputs[key])
+            masks[key] = torch.where(masks[key] == update_field, torch.zeros_like(masks[key]), masks[key])
+            if i > 0:
+                final_outputs[key] = torch.where(update_field[:, :, None, None], outputs[key], final_outputs[key])
+        for key, column in input_columns.items():
+            if column["is_sequence"]:
+                modified_inputs[key] = apply_token(filtered_inputs[key], column, masks[key], "masked")
+    for key in ["image_embedding", "text_embedding"]:
+        if key in outputs:
+            final_outputs[key] = outputs[key]
+    return final_outputs
+
+
+class MFP:
+    """MFP trainer (reference mfp.py:210-347)."""
+
+    def __init__(self, input_columns: Dict, num_blocks: int = 4, block_type: str = "deepsvg",
+                 masking_method: str = "random", seq_type: str = "default", arch_type: str = "oneshot",
+                 context: Optional[str] = None, input_dtype: str = "set", name: str = "mfp",
+                 use_elemwise_noise: bool = False, **kwargs):
+        assert arch_type == "oneshot"
+        if seq_type != "default":
+            raise NotImplementedError("seq_type=%r: only 'default' is on the MFP hot path" % seq_type)
+        self.name = name
+        self.arch_type, self.context, self.input_dtype = arch_type, context, input_dtype
+        self._all_input_columns = input_columns
+        self.input_columns = {k: v for (k, v) in input_columns.items() if not v.get("demo_only", False)}
+        self.is_autoreg = False
+        kwargs.pop("kl", None)
+        self.model = Model(input_columns=input_columns, num_blocks=num_blocks, block_type=block_type,
+                           context=context, input_dtype=input_dtype,
+                           use_elemwise_noise=use_elemwise_noise, **kwargs)
+        self.loss_layer = LossLayer(input_columns)
+        self.task_names = get_task_names(input_columns)
+        self.task_probs = get_task_probs(self.task_names, masking_method)
+        self._active_tasks = [i for i, p in enumerate(self.task_probs) if p > 0.0]
+        self._task_probs_dev = torch.tensor(self.task_probs, dtype=torch.float32, device=self.model.store.device)
+        self.sort_pos = get_dataset_name(input_columns.keys()) == "rico"
+        self.optimizer: Optional[AdamKeras] = None
+        self.stop_training = False
+        self._graph = None
+        self.last_sums = None
+
+    # ------------------------------------------------------------------ reference call surface
+    def sample_tasks(self, B: int) -> torch.Tensor:
+        """tfp Categorical(logits=log probs).sample(B) (mfp.py:301) -> int32 (B,)."""
+        return torch.multinomial(self._task_probs_dev, B, replacement=True).to(torch.int32)
+
+    def __call__(self, inputs, training=False, demo_args=None):
+        is_demo = True if demo_args else False
+        B = inputs["left"].shape[0]
+        tasks = self.sample_tasks(B)
+        if is_demo:
+            targets = inputs
+            masks = demo_args["masks"]
+            modified_inputs = preprocess_for_test(inputs, self.input_columns, masks, demo_args.get("tasks", tasks))
+        else:
+            targets, modified_inputs, masks = preprocess_for_train(
+                inputs, self.input_columns, tasks, is_autoreg=self.is_autoreg,
+                input_dtype=self.input_dtype, active_tasks=self._active_tasks)
+        iter_decode = False
+        if is_demo:
+            num_iter = demo_args.get("num_iter", 1)
+            iter_decode = num_iter > 1
+        with torch.set_grad_enabled(False):
+            if iter_decode:
+                outputs = iterative_decode(self.model, masks, inputs, self.input_columns, modified_inputs, num_iter)
+            else:
+                outputs = self.model(modified_inputs, training)
+        if not is_demo:
+            if self.sort_pos:
+                ind = self.task_names.index("pos")
+                self.loss_layer((targets, outputs, masks), training, (tasks == ind))
+            else:
+                self.loss_layer((targets, outputs, masks), training)
+        outputs.pop("_flat_logits", None)
+        outputs = {k: v.clone() if torch.is_tensor(v) else v for k, v in outputs.items()}
+        outputs = merge_inputs_and_prediction(inputs, self.input_columns, masks, outputs)
+        outputs["tasks"] = tasks
+        return outputs
+
+    # ------------------------------------------------------------------ training
+    def compile(self, optimizer=None, run_eagerly=True, learning_rate: float = 1e-4, clipnorm: float = 1.0,
+                **kwargs):
+        """``compile(optimizer=Adam(lr, clipnorm=1.0), run_eagerly=True)`` (train.py:71-77);
+        ``compile(optimizer="adam")`` as eval.py:170 does before load_weights."""
+        if isinstance(optimizer, AdamKeras):
+            self.optimizer = optimizer
+        else:
+            self.optimizer = AdamKeras(self.model.store, learning_rate=learning_rate, clipnorm=clipnorm)
+        self.model.step_ptr = self.optimizer.step_t
+
+    def _forward_backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        B = batch["left"].shape[0]
+        tasks = self.sample_tasks(B)
+        if self.sort_pos and self.task_names.index("pos") in self._active_tasks:
+            raise NotImplementedError("RICO position-sorted training loss is a 'next' row (SURVEY.md §8f-4)")
+        targets, modified_inputs, masks = preprocess_for_train(
+            batch, self.input_columns, tasks, is_autoreg=self.is_autoreg, input_dtype=self.input_dtype,
+            active_tasks=self._active_tasks)
+        keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, targets, masks)
+        loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True)
+        loss.backward()
+        return sums
+
+    def _apply(self):
+        n = dp.world_size()
+        dp.allreduce_gradients(self.model.store.g)
+        self.optimizer.step(grad_scale=1.0 / n)
+
+    def train_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """masking -> fwd -> losses -> bwd -> (all-reduce) -> clipnorm + L2 + Adam.
+        Returns the device tensor ``sums [nkeys][3]`` (no host sync)."""
+        assert self.optimizer is not None, "call compile() first"
+        if self._graph is not None:
+            return self._graph(batch)
+        sums = self._forward_backward(batch)
+        self._apply()
+        self.last_sums = sums
+        return sums
+
+    def capture_train_step(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2):
+        """Capture the whole train step into hipGraphs (launch-bound inner loop: ~10^2 kernels of
+        ~10 us).  With world_size > 1 the step is two graphs with the RCCL all-reduce between."""
+        assert self.optimizer is not None, "call compile() first"
+        static = {k: v.clone() for k, v in example_batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._forward_backward(static)
+                self._apply()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        multi = dp.world_size() > 1
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            static_sums = self._forward_backward(static)
+            if not multi:
+                self._apply()
+        g2 = None
+        if multi:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self.optimizer.step(grad_scale=1.0 / dp.world_size())
+
+        def replay(batch):
+            for k, v in batch.items():
+                if k in static and v.data_ptr() != static[k].data_ptr():
+                    static[k].copy_(v, non_blocking=True)
+            g1.replay()
+            if multi:
+                dp.allreduce_gradients(self.model.store.g)
+                g2.replay()
+            self.last_sums = static_sums
+            return static_sums
+
+        self._graph = replay
+        self._graph_objs = (g1, g2, static, static_sums)
+        return replay
+
+    def test_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Keras test_step: MFP.call(training=False) still re-masks (is_demo False)."""
+        with torch.no_grad():
+            B = batch["left"].shape[0]
+            tasks = self.sample_tasks(B)
+            targets, modified_inputs, masks = preprocess_for_train(
+                batch, self.input_columns, tasks, input_dtype=self.input_dtype, active_tasks=self._active_tasks)
+            outputs = self.model(modified_inputs, training=False)
+            self.loss_layer((targets, outputs, masks), False)
+            keys = loss_key_names(self._all_input_columns)
+            m = self.loss_layer.metrics
+            return torch.stack([torch.stack([m[k + "_loss"], m[k + "_score"], m[k + "_score"] * 0 + 1])
+                                for k in keys])
+
+    @property
+    def metrics_names(self) -> List[str]:
+        keys = loss_key_names(self._all_input_columns)
+        return ["loss"] + [k + "_score" for k in keys] + [k + "_loss" for k in keys] + ["total_score"]
+
+    def metrics_dict(self, sums: torch.Tensor, include_reg: bool = True) -> Dict[str, float]:
+        sums = dp.allreduce_sums(sums)
+        losses, scores, metrics = metrics_from_sums(self._all_input_columns, sums)
+        out = {k: float(v) for k, v in metrics.items()}
+        loss = float(sums[:, 0].sum())
+        if include_reg and self.optimizer is not None:
+            loss += float(self.optimizer.reg_loss())
+        out["loss"] = loss
+        return out
+
+    def fit(self, dataset, steps_per_epoch=None, epochs=1, validation_data=None, validation_steps=None,
+            validation_freq=1, callbacks=None, verbose=2, use_graph: bool = False):
+        callbacks = callbacks or []
+        history = []
+        it = iter(dataset)
+        for epoch in range(epochs):
+            acc, n = None, 0
+            for _ in range(steps_per_epoch or len(dataset)):
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    it = iter(dataset)
+                    batch = next(it)
+                batch = dp.shard_batch(batch)
+                if use_graph and self._graph is None:
+                    self.capture_train_step(batch)
+                sums = self.train_step(batch)
+                acc = sums.clone() if acc is None else acc + sums
+                n += 1
+            logs = self.metrics_dict(_mean_sums(acc, n))
+            if validation_data is not None and (epoch + 1) % max(1, validation_freq) == 0:
+                val = self.evaluate(validation_data, steps=validation_steps, return_dict=True)
+                logs.update({"val_" + k: v for k, v in val.items()})
+            history.append(logs)
+            if verbose and dp.rank() == 0:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) +
+                      " - ".join("%s: %.4f" % (k, v) for k, v in logs.items()
+                                 if k in ("loss", "total_score", "val_loss", "val_total_score")), flush=True)
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs, self)
+            if self.stop_training:
+                break
+        return history
+
+    def evaluate(self, dataset, batch_size=None, steps=None, return_dict=False):
+        acc, n = None, 0
+        for i, batch in enumerate(dataset):
+            if steps is not None and i >= steps:
+                break
+            s = self.test_step(dp.shard_batch(batch))
+            acc = s.clone() if acc is None else acc + s
+            n += 1
+        res = _metrics_from_eval(self._all_input_columns, acc, n)
+        if return_dict:
+            return res
+        return [res[k] for k in self.metrics_names]
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_weights(self, path: str):
+        """Own format (safetensors) under the reference's file layout
+        ``job_dir/checkpoints/{best,final}.ckpt*`` (train.py:34-35,95-97)."""
+        from safetensors.torch import save_file
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        if dp.rank() == 0:
+            save_file(dict(self.model.store.state_dict()), path + ".safetensors")
+
+    def load_weights(self, path: str):
+        from safetensors.torch import load_file
+        p = path if path.endswith(".safetensors") else path + ".safetensors"
+        if not os.path.exists(p):
+            raise FileNotFoundError(
+                "%s not found (TF-checkpoint import is a 'next' row, SURVEY.md §8f-2)" % p)
+        self.model.store.load_state_dict(load_file(p))
+        return self
+
+
+def _mean_sums(acc: torch.Tensor, n: int) -> torch.Tensor:
+    out = acc.clone()
+    out[:, 0] /= max(n, 1)   # per-step batch means -> epoch mean; num/den stay sums
+    return out
+
+
+def _metrics_from_eval(input_columns, acc, n):
+    keys = loss_key_names(input_columns)
+    out = {}
+    if acc is None:
+        return {k: float("nan") for k in ["loss"] + [x + "_score" for x in keys] + [x + "_loss" for x in keys] + ["total_score"]}
+    mean = acc / max(n, 1)
+    total = 0.0
+    for i, k in enumerate(keys):
+        out[k + "_loss"] = float(mean[i, 0])
+        out[k + "_score"] = float(mean[i, 1])
+        total += float(mean[i, 1])
+    out["loss"] = float(mean[:, 0].sum())
+    out["total_score"] = total / len(input_columns)
+    return out

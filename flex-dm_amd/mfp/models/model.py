@@ -1,0 +1,72 @@
+"""``Model`` = Encoder -> Blocks -> Decoder (reference models/model.py:9-52, ``_OneShot``/``Model``).
+
+The baselines in the reference's model.py (VanillaTransformer, AutoReg, BART) are unreachable
+from train.py/eval.py (mfp.py:230 asserts ``arch_type == "oneshot"``) and are not provided.
+New, additive constructor arguments: ``dtype`` ("fp32" parity path / "bf16" MFMA path),
+``device``, ``seed``.
+"""
+from typing import Dict, Optional, Union
+
+import torch
+
+from mfp.hip.functions import DecoderLossFn, StepCtx
+from mfp.models.architecture.decoder import Decoder, split_logits
+from mfp.models.architecture.encoder import Encoder
+from mfp.models.architecture.transformer import Blocks
+from mfp.models.params import ModelLayout, ParamStore
+
+DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def _first_seq_key(input_columns):
+    for k, c in input_columns.items():
+        if c.get("is_sequence") and not c.get("demo_only"):
+            return k
+    raise ValueError("no sequence column")
+
+
+class Model:
+    def __init__(self, input_columns: Dict, num_blocks: int = 4, block_type: str = "deepsvg",
+                 context: Union[str, None] = None, input_dtype: str = "set",
+                 use_elemwise_noise: bool = False, latent_dim: int = 256, dropout: float = 0.1,
+                 l2: Optional[float] = None, dtype: str = "fp32", device: str = "cuda", seed: int = 0,
+                 **kwargs):
+        self.arch_type = "oneshot"
+        self.input_columns = input_columns
+        self.dropout, self.seed = dropout, seed
+        self.layout = ModelLayout(input_columns, latent_dim, num_blocks)
+        self.store = ParamStore(self.layout, device, DTYPES[dtype], l2=l2, seed=seed)
+        self.blocks = Blocks(self.store, num_blocks=num_blocks, block_type=block_type,
+                             latent_dim=latent_dim, dropout=dropout, l2=l2)
+        self.encoder = Encoder(input_columns, self.store, context=context, input_dtype=input_dtype,
+                               use_elemwise_noise=use_elemwise_noise, latent_dim=latent_dim,
+                               dropout=dropout, l2=l2)
+        self.decoder = Decoder(input_columns, self.store, context=context, latent_dim=latent_dim,
+                               dropout=dropout, l2=l2)
+        self.step_ptr = None  # device int32 step counter (set by the optimizer) for dropout offsets
+        self._first = _first_seq_key(input_columns)
+
+    def make_ctx(self, inputs: Dict, training: bool) -> StepCtx:
+        B, S = inputs[self._first].shape[:2]
+        nvalid = (inputs["length"].reshape(-1) + 1).to(torch.int32)
+        return StepCtx(self.store, B, S, nvalid, training, self.dropout, self.seed, self.step_ptr)
+
+    def hidden(self, inputs: Dict, training: bool = False, ctx: Optional[StepCtx] = None):
+        ctx = ctx or self.make_ctx(inputs, training)
+        h, mask = self.encoder(inputs, ctx)
+        h = self.blocks(h, mask, ctx)
+        return h, ctx
+
+    def __call__(self, inputs: Dict, training: bool = False) -> Dict[str, torch.Tensor]:
+        """_OneShot.call (model.py:26-30): dict of per-attribute logits."""
+        h, ctx = self.hidden(inputs, training)
+        return self.decoder(h, ctx)
+
+    def forward_loss(self, inputs: Dict, loss_keys, training: bool = True):
+        """Train-step path: heads + LossLayer fused.  Returns (loss_total, sums, outputs)."""
+        h, ctx = self.hidden(inputs, training)
+        B, S, D = h.shape
+        loss, sums, logits = DecoderLossFn.apply(h.reshape(B * S, D), ctx, loss_keys)
+        outputs = split_logits(logits, self.layout, self.input_columns, B, S)
+        outputs["_flat_logits"] = logits
+        return loss, sums, outputs

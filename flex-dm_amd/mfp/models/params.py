@@ -1,0 +1,251 @@
+"""Flat parameter storage for the MFP model.
+
+All trainable variables of Encoder / Blocks / Decoder (reference architecture/encoder.py:72-92,
+transformer.py:43-57,161-173, decoder.py:33-43) live back to back in ONE float32 buffer ``w``
+with matching gradient ``g`` and Adam slots ``m``/``v`` (+ an optional bf16 shadow of ``w``
+for the MFMA operands).  Reasons, all MI355X-side:
+
+* one fused multi-tensor Adam / clipnorm / L2 pass over HBM instead of ~70 variables x ~10
+  eager ops;
+* one RCCL all-reduce over the flat gradient for data parallelism;
+* GEMM weights are consumed in place (pointer + offset), no per-step concatenation.
+
+Dense kernels are stored TRANSPOSED, ``[out][in]`` (Keras: ``[in][out]``), so that the fused
+QKV matrix ``[3D][D]`` and the concatenated decoder heads ``[U][D]`` are contiguous row blocks
+per Keras variable -- Keras' ``clipnorm`` and L2 regulariser act per variable
+(architecture/utils.py:8-22; train.py:71-75).  ``state_dict()`` / ``load_state_dict()`` use
+Keras names and Keras shapes (transposing on the way) -- the checkpoint surface.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from mfp.data.spec import get_valid_input_columns
+
+NUM_HEADS = 8  # transformer.py:147, never overridden by Blocks (transformer.py:263-270)
+
+
+class Segment:
+    __slots__ = ("name", "offset", "shape", "l2", "transposed", "size")
+
+    def __init__(self, name, offset, shape, l2, transposed):
+        self.name, self.offset, self.shape, self.l2, self.transposed = name, offset, tuple(shape), l2, transposed
+        self.size = int(np.prod(shape))
+
+
+class ModelLayout:
+    """Static description of the flat buffer for one (input_columns, D, L) configuration."""
+
+    def __init__(self, input_columns: Dict, latent_dim: int, num_blocks: int):
+        D = latent_dim
+        assert D % NUM_HEADS == 0, "embedding dimension = %d should be divisible by number of heads = %d" % (
+            D, NUM_HEADS)  # ValueError text of transformer.py:48-52
+        assert D % 64 == 0, "latent_dim must be a multiple of 64 for the gfx950 kernels"
+        self.D, self.L = D, num_blocks
+        self.columns = get_valid_input_columns(input_columns, False)
+        self.cat_keys = [k for k, c in self.columns.items() if c["type"] == "categorical"]
+        self.num_keys = [k for k, c in self.columns.items() if c["type"] == "numerical"]
+        self.segments: "OrderedDict[str, Segment]" = OrderedDict()
+        self._cursor = 0
+
+        # ---- encoder tables: categorical tables in column order, then the 2-row special tables
+        self.table_start = self._cursor
+        self.idx_cols: List[Tuple[str, int]] = []   # (key, feature index) per index column
+        self.rowoff: List[int] = []
+        rows = 0
+        for k in self.cat_keys:
+            c = self.columns[k]
+            n_rows = c["input_dim"] + 2                       # +<MASK>, <UNUSED> (encoder.py:76)
+            self._add("encoder/input_%s/embeddings" % k, (n_rows, D), True, False)
+            for f in range(c["shape"][-1]):
+                self.idx_cols.append((k, f))
+                self.rowoff.append(rows)
+            rows += n_rows
+        self.special_col: Dict[str, int] = {}
+        for k in self.num_keys:
+            self._add("encoder/input_%s_special/embeddings" % k, (2, D), True, False)
+            self.special_col[k] = len(self.idx_cols)
+            self.idx_cols.append((k, -1))
+            self.rowoff.append(rows)
+            rows += 2
+        self.table_rows = rows
+        for k in self.num_keys:
+            width = self.columns[k]["shape"][-1]
+            assert width % 8 == 0
+            self._add("encoder/input_%s/kernel" % k, (D, width), True, True)
+            self._add("encoder/input_%s/bias" % k, (D,), True, False)
+
+        # ---- transformer blocks
+        for i in range(num_blocks):
+            p = "blocks/seq2seq_%d/" % i
+            for n in ("dense_query", "dense_key", "dense_value"):     # rows [3D][D] contiguous
+                self._add(p + "attn/%s/kernel" % n, (D, D), True, True)
+            for n in ("dense_query", "dense_key", "dense_value"):     # [3D] contiguous
+                self._add(p + "attn/%s/bias" % n, (D,), True, False)
+            self._add(p + "attn/combine_heads/kernel", (D, D), True, True)
+            self._add(p + "attn/combine_heads/bias", (D,), True, False)
+            self._add(p + "norm1/gamma", (D,), False, False)
+            self._add(p + "norm1/beta", (D,), False, False)
+            self._add(p + "mlp/dense_0/kernel", (2 * D, D), True, True)
+            self._add(p + "mlp/dense_0/bias", (2 * D,), True, False)
+            self._add(p + "mlp/dense_1/kernel", (D, 2 * D), True, True)
+            self._add(p + "mlp/dense_1/bias", (D,), True, False)
+            self._add(p + "norm2/gamma", (D,), False, False)
+            self._add(p + "norm2/beta", (D,), False, False)
+
+        # ---- decoder heads: rows [Upad][D] + bias [Upad]; per key a row block
+        self.head_cols: Dict[str, Tuple[int, int]] = {}
+        col = 0
+        self.heads_start = self._cursor
+        for k, c in self.columns.items():
+            units = c["shape"][-1] * c["input_dim"] if c["type"] == "categorical" else c["shape"][-1]
+            self._add("decoder/decoder_%s/kernel" % k, (units, D), True, True)
+            self.head_cols[k] = (col, units)
+            col += units
+        self.U = col
+        self.Upad = (col + 7) // 8 * 8
+        if self.Upad > self.U:
+            self._add("decoder/_pad/kernel", (self.Upad - self.U, D), False, False)
+        self.heads_bias_start = self._cursor
+        for k in self.columns:
+            self._add("decoder/decoder_%s/bias" % k, (self.head_cols[k][1],), True, False)
+        if self.Upad > self.U:
+            self._add("decoder/_pad/bias", (self.Upad - self.U,), False, False)
+        self.numel = self._cursor
+        assert self.numel % 8 == 0
+
+    def _add(self, name, shape, l2, transposed):
+        seg = Segment(name, self._cursor, shape, l2, transposed)
+        self.segments[name] = seg
+        self._cursor += seg.size
+
+    def seg_offsets(self) -> List[int]:
+        return [s.offset for s in self.segments.values()] + [self.numel]
+
+
+class ParamStore:
+    """Device buffers + named views for one model instance."""
+
+    def __init__(self, layout: ModelLayout, device, compute_dtype: torch.dtype = torch.float32,
+                 l2: Optional[float] = 1e-2, seed: int = 0):
+        self.layout = layout
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        n = layout.numel
+        self.w = torch.zeros(n, dtype=torch.float32, device=device)
+        self.g = torch.zeros(n, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(n, dtype=torch.bfloat16, device=device) \
+            if compute_dtype == torch.bfloat16 else None
+        self.l2 = l2
+        self.seg_l2 = torch.tensor([(l2 or 0.0) if s.l2 else 0.0 for s in layout.segments.values()],
+                                   dtype=torch.float32, device=device)
+        self.rowoff = torch.tensor(layout.rowoff, dtype=torch.int32, device=device)
+        # autograd anchor: the custom Functions need one differentiable input even when the data
+        # inputs are integer indices; parameter gradients bypass autograd and land in ``g``.
+        self.anchor = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
+        self.init_keras(seed)
+
+    # ------------------------------------------------------------------ views
+    def _view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        s = self.layout.segments[name]
+        return buf[s.offset:s.offset + s.size].view(s.shape)
+
+    def weight(self, name: str) -> torch.Tensor:
+        return self._view(self.w, name)
+
+    def grad(self, name: str) -> torch.Tensor:
+        return self._view(self.g, name)
+
+    def cw(self, name: str, rows: Optional[int] = None) -> torch.Tensor:
+        """Compute-dtype view of a GEMM weight starting at ``name`` (optionally spanning
+        ``rows`` rows across the following contiguous variables, e.g. the fused QKV)."""
+        s = self.layout.segments[name]
+        buf = self.shadow if self.shadow is not None else self.w
+        if rows is None:
+            return buf[s.offset:s.offset + s.size].view(s.shape)
+        cols = s.shape[-1]
+        return buf[s.offset:s.offset + rows * cols].view(rows, cols)
+
+    def span(self, buf: torch.Tensor, name: str, count: int, cols: Optional[int] = None):
+        s = self.layout.segments[name]
+        t = buf[s.offset:s.offset + count]
+        return t.view(-1, cols) if cols else t
+
+    def tables(self, buf=None) -> torch.Tensor:
+        buf = self.w if buf is None else buf
+        L = self.layout
+        return buf[L.table_start:L.table_start + L.table_rows * L.D].view(L.table_rows, L.D)
+
+    def refresh_shadow(self):
+        if self.shadow is not None:
+            from mfp.hip import ops
+            ops.cast_bf16(self.w, self.shadow)
+
+    # ------------------------------------------------------------------ init / (de)serialise
+    def init_keras(self, seed: int = 0):
+        """[TF-EXT] Keras defaults: Dense glorot_uniform + zero bias; Embedding U(-0.05, 0.05);
+        LayerNormalization gamma 1 / beta 0."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.layout.numel, dtype=np.float32)
+        for s in self.layout.segments.values():
+            if "/_pad/" in s.name:
+                continue
+            if s.name.endswith("/embeddings"):
+                v = rng.uniform(-0.05, 0.05, size=s.shape)
+            elif s.name.endswith("/kernel"):
+                limit = np.sqrt(6.0 / (s.shape[0] + s.shape[1]))
+                v = rng.uniform(-limit, limit, size=s.shape)
+            elif s.name.endswith("/gamma"):
+                v = np.ones(s.shape)
+            else:
+                v = np.zeros(s.shape)
+            host[s.offset:s.offset + s.size] = v.reshape(-1)
+        self.w.copy_(torch.from_numpy(host))
+        if self.w.is_cuda:
+            self.refresh_shadow()
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        """Keras-named, Keras-shaped (kernels ``[in][out]``) CPU tensors."""
+        out = OrderedDict()
+        w = self.w.detach().cpu()
+        for s in self.layout.segments.values():
+            if "/_pad/" in s.name:
+                continue
+            t = w[s.offset:s.offset + s.size].view(s.shape)
+            out[s.name] = t.t().contiguous() if s.transposed else t.clone()
+        return out
+
+    def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = True):
+        host = self.w.detach().cpu().clone()
+        missing = []
+        for s in self.layout.segments.values():
+            if "/_pad/" in s.name:
+                continue
+            if s.name not in state:
+                missing.append(s.name)
+                continue
+            t = torch.as_tensor(np.asarray(state[s.name]), dtype=torch.float32)
+            if s.transposed:
+                t = t.t()
+            if tuple(t.shape) != s.shape:
+                raise ValueError("shape mismatch for %s: %s vs %s" % (s.name, tuple(t.shape), s.shape))
+            host[s.offset:s.offset + s.size] = t.reshape(-1)
+        if strict and missing:
+            raise KeyError("missing variables: %s" % missing)
+        self.w.copy_(host)
+        if self.w.is_cuda:
+            self.refresh_shadow()
+
+    def grads_state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        out = OrderedDict()
+        g = self.g.detach().cpu()
+        for s in self.layout.segments.values():
+            if "/_pad/" in s.name:
+                continue
+            t = g[s.offset:s.offset + s.size].view(s.shape)
+            out[s.name] = t.t().contiguous() if s.transposed else t.clone()
+        return out

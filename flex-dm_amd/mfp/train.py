@@ -1,0 +1,73 @@
+"""``train(args)`` -- the reference's trainer glue (src/mfp/mfp/train.py:16-97) on this engine:
+seeds, ``job_dir/args.json``, DataSpec datasets, MFP model, optional warm start, Adam(lr,
+clipnorm=1.0), fit / evaluate (prints ``metric value`` lines), ``checkpoints/{best,final}.ckpt``.
+Data-parallel when launched under torchrun (one process per GPU, RCCL)."""
+import json
+import logging
+import os
+import random
+
+import numpy as np
+import torch
+
+from mfp import dp
+from mfp.data import DataSpec
+from mfp.helpers.callbacks import get_callbacks
+from mfp.models.mfp import MFP
+
+logger = logging.getLogger(__name__)
+
+
+def train(args):
+    logger.info(f"torch version {torch.__version__}")
+    world = dp.init_from_env()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = args.device
+    if device == "cuda":
+        torch.cuda.set_device(local_rank)
+        device = "cuda:%d" % local_rank
+    seed = args.seed
+    torch.manual_seed(seed + dp.rank())
+    np.random.seed(seed)
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+
+    os.makedirs(args.job_dir, exist_ok=True)
+    if dp.rank() == 0:
+        with open(os.path.join(args.job_dir, "args.json"), "w") as file_obj:
+            json.dump(vars(args), file_obj, indent=2)
+    checkpoint_dir = os.path.join(args.job_dir, "checkpoints")
+    checkpoint_path = os.path.join(checkpoint_dir, "best.ckpt")
+
+    dataspec = DataSpec(args.dataset_name, args.data_dir, batch_size=args.batch_size,
+                        seq_len=args.seq_len, device=device)
+    train_dataset = dataspec.make_dataset("train", shuffle=True, repeat=True, cache=True)
+    val_dataset = dataspec.make_dataset("val", cache=True)
+    test_dataset = dataspec.make_dataset("test", cache=True)
+
+    input_columns = dataspec.make_input_columns()
+    model = MFP(input_columns, num_blocks=args.num_blocks, block_type=args.block_type,
+                masking_method=args.masking_method, seq_type=args.seq_type, arch_type=args.arch_type,
+                context=args.context, latent_dim=args.latent_dim, dropout=args.dropout, l2=args.l2,
+                input_dtype=args.input_dtype, dtype=args.dtype, device=device, seed=seed)
+    if args.weights:
+        logger.info("Loading %s" % args.weights)
+        model.load_weights(args.weights)
+    dp.broadcast_parameters(model.model.store.w)
+    model.model.store.refresh_shadow()
+
+    model.compile(learning_rate=args.learning_rate, clipnorm=1.0, run_eagerly=True)
+    model.fit(train_dataset, steps_per_epoch=dataspec.steps_per_epoch("train"), epochs=args.num_epochs,
+              validation_data=val_dataset, validation_steps=dataspec.steps_per_epoch("val"),
+              validation_freq=min(args.validation_freq, args.num_epochs),
+              callbacks=get_callbacks(args, dataspec, checkpoint_path), verbose=args.verbose,
+              use_graph=args.use_graph)
+
+    results = model.evaluate(test_dataset, batch_size=args.batch_size)
+    if dp.rank() == 0:
+        for k, v in zip(model.metrics_names, results):
+            print(k, v)
+    model_path = os.path.join(args.job_dir, "checkpoints", "final.ckpt")
+    logger.info("Saving %s" % model_path)
+    model.save_weights(model_path)
+    return model

@@ -26,6 +26,7 @@ extern "C" {
 typedef void* mfp_stream_t; /* hipStream_t */
 
 enum { MFP_F32 = 0, MFP_BF16 = 1 };
+#define MFP_RNG_STEP_STRIDE 4096ull
 
 enum {
   MFP_OK = 0,
@@ -45,6 +46,11 @@ int mfp_version(void);
  * Forward Dense (transformer.py:85-98,163-169; encoder.py:88-92; decoder.py:39-43):
  *   a_kmajor=1,b_kmajor=0 with B = Keras kernel (in,out).  dgrad: a_kmajor=1,b_kmajor=1.
  *   wgrad: a_kmajor=0,b_kmajor=0 (contraction over tokens), split-K via `splitk`.
+ * The product stores every Dense kernel TRANSPOSED, W^T = [out][in] (so that the fused QKV and
+ * the concatenated decoder heads stay one contiguous row block per Keras variable, which the
+ * per-variable clipnorm needs).  With that storage: forward y = x W uses (a_kmajor=1,
+ * b_kmajor=1, B = W^T); dgrad dx = dy W^T uses (1, 0, B = W^T); wgrad dW^T = dy^T x uses
+ * (0, 0, A = dy, B = x).
  * Constraints: N%8==0, K%8==0 (kmajor operands), lda/ldb/ldc %8==0; M free.
  */
 enum {
@@ -55,8 +61,8 @@ enum {
   MFP_GEMM_ACCUM = 16,      /* C += result (C f32) */
   MFP_GEMM_ROWSKIP = 32,    /* rows with rowcode[m]!=0 contribute 0 (encoder.py:174-175) */
   MFP_GEMM_RELU_BWD = 64,   /* result *= (aux[m][n] > 0), aux in cdt, ld = ldc */
-  MFP_GEMM_COLSUM_B = 128,  /* wgrad only: also colsum[n] = sum_k B[k][n] (bias grad) */
-  MFP_GEMM_ROWSKIP_B = 256  /* wgrad only: rows k of B with rowcode[k]!=0 count as zero */
+  MFP_GEMM_COLSUM_A = 128,  /* wgrad only: also colsum[m] = sum_k A[k][m] (bias grad of dY) */
+  MFP_GEMM_ROWSKIP_A = 256  /* wgrad only: rows k of A with rowcode[k]!=0 count as zero */
 };
 
 typedef struct mfp_gemm_args {
@@ -67,8 +73,8 @@ typedef struct mfp_gemm_args {
   const float* residual;
   const void* aux;
   const uint8_t* rowcode;
-  float* colsum;        /* [N] f32, MFP_GEMM_COLSUM_B */
-  void* workspace;      /* wgrad split-K partials: splitk*M*N (+ splitk*N) floats */
+  float* colsum;        /* [M] f32, MFP_GEMM_COLSUM_A */
+  void* workspace;      /* wgrad split-K partials: splitk*M*N (+ splitk*M) floats */
   size_t workspace_bytes;
   int32_t M, N, K;
   int32_t lda, ldb, ldc;
@@ -80,6 +86,7 @@ typedef struct mfp_gemm_args {
   float dropout_p;
   uint64_t seed;
   uint64_t offset;
+  const int32_t* step_ptr; /* device; Philox offset += *step_ptr * MFP_RNG_STEP_STRIDE (graph replay) */
 } mfp_gemm_args;
 
 int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);
@@ -183,8 +190,8 @@ int mfp_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, mfp_stream_t s
  * workspace: mfp_colsum_workspace_bytes(M, N). */
 size_t mfp_colsum_workspace_bytes(int32_t M, int32_t N);
 int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* workspace, size_t workspace_bytes,
-                    int32_t M, int32_t N, float p, uint64_t seed, uint64_t offset, int32_t out_dtype,
-                    mfp_stream_t stream);
+                    int32_t M, int32_t N, float p, uint64_t seed, uint64_t offset,
+                    const int32_t* step_ptr, int32_t out_dtype, mfp_stream_t stream);
 /* colsum[n] = sum_m X[m][n] for a cdt matrix (bias gradients). */
 int mfp_colsum(const void* X, float* colsum, void* workspace, size_t workspace_bytes, int32_t M,
                int32_t N, int32_t ld, int32_t dtype, mfp_stream_t stream);

@@ -129,17 +129,17 @@ def test_gemm_epilogues(dtype):
 def test_gemm_wgrad_colsum_rowskip(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(11)
-    T, M, N = 1500, 128, 264
+    T, M, N = 1500, 264, 128
     X, dY = torch.randn(T, M, generator=g), torch.randn(T, N, generator=g)
     if dtype == torch.bfloat16:
         X, dY = bf16_round(X), bf16_round(dY)
     code = (torch.rand(T, generator=g) < 0.25).to(torch.uint8)
     keep = (code == 0).double()[:, None]
-    colsum = torch.empty(N, device=DEV)
+    colsum = torch.empty(M, device=DEV)
     got = ops.gemm(X.to(DEV, dtype), dY.to(DEV, dtype), M, N, T, a_kmajor=False, b_kmajor=False,
-                   out_dtype=torch.float32, colsum=colsum, rowskip_b=code.to(DEV), splitk=5)
-    assert_close(got, X.double().t() @ (dY.double() * keep), 2e-3, 1e-5, "wgrad")
-    assert_close(colsum, (dY.double() * keep).sum(0), 2e-3, 1e-5, "colsum")
+                   out_dtype=torch.float32, colsum=colsum, rowskip_a=code.to(DEV), splitk=5)
+    assert_close(got, (X.double() * keep).t() @ dY.double(), 2e-3, 1e-5, "wgrad")
+    assert_close(colsum, (X.double() * keep).sum(0), 2e-3, 1e-5, "colsum")
 
 
 def test_gemm_dropout_matches_dropout_bwd():

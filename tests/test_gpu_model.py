@@ -1,0 +1,211 @@
+"""GPU parity of the whole hot path (Encoder -> DeepSVG blocks -> Decoder -> LossLayer -> grads ->
+Keras Adam) through the reference-shaped ``mfp`` API, against the CPU oracle.
+
+f32 path: logits <= 1e-4 abs, per-key losses <= 1e-4 rel (north_star asks 1e-3), gradients
+<= 1e-4 of each variable's max |g|.  bf16 path: reported as deviation from the f32 oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(dataset="crello", B=3, S=10, D=128, L=2, seed=1, mask_p=0.5):
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models import masking
+    from mfp.models.architecture.mask import get_seq_mask
+    from mfp.models.metrics import loss_key_names
+    ic = make_input_columns(dataset)
+    nd = {k: v for k, v in ic.items() if not v.get("demo_only")}
+    params = np_ref.init_params(ic, D, L, seed=-(seed + 1))
+    batch = synthetic_batch(ic, B, S, seed=seed, ragged=True)
+    gen = torch.Generator().manual_seed(seed)
+    seq_mask = get_seq_mask(batch["length"], maxlen=S)
+    filtered = masking.filter_padding(batch, nd, seq_mask)
+    # every token type present: <MASK>, <UNUSED> (from filter_padding), random replacement
+    modified, masks = {}, {}
+    for k, c in nd.items():
+        if not c["is_sequence"]:
+            modified[k] = filtered[k]
+            continue
+        m = seq_mask & (torch.rand(B, S, generator=gen) < mask_p)
+        r = torch.rand(B, S, generator=gen)
+        x = masking.apply_token(filtered[k], c, m & (r < 0.7), "masked")
+        x = masking.apply_token(x, c, m & (r >= 0.7) & (r < 0.85), "random", gen)
+        modified[k], masks[k] = x, m
+    modified["length"] = batch["length"]
+    return ic, params, batch, modified, masks, np_ref, torch_ref, loss_key_names(ic)
+
+
+def _oracle(ic, params, batch, modified, masks, torch_ref, L, S, l2=None, dtype=torch.float64):
+    state = torch_ref.TrainState(params, l2=l2, clipnorm=1.0, lr=1e-2, dtype=dtype)
+    cast = lambda d: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in d.items()}
+    info, grads = torch_ref.loss_and_grads(state, ic, cast(batch), cast(modified), masks, L, maxlen=S)
+    return state, info, grads
+
+
+def _model(ic, params, D, L, dtype, dropout=0.0, l2=None):
+    from mfp.models.model import Model
+    model = Model(ic, num_blocks=L, latent_dim=D, dropout=dropout, l2=l2, dtype=dtype, device=DEV)
+    model.store.load_state_dict(params)
+    return model
+
+
+def _run(model, ic, batch, modified, masks):
+    from mfp.models.metrics import build_loss_keys
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    keys = build_loss_keys(ic, model.layout.head_cols, dev(batch), dev(masks))
+    loss, sums, outputs = model.forward_loss(dev(modified), keys, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss, sums, outputs
+
+
+@pytest.mark.parametrize("dataset,B,S,D,L", [("crello", 3, 10, 128, 2), ("rico", 8, 32, 128, 2),
+                                            ("crello", 2, 50, 256, 1), ("crello", 1, 1, 128, 1)])
+def test_forward_backward_parity_fp32(dataset, B, S, D, L):
+    ic, params, batch, modified, masks, np_ref, torch_ref, keys = _setup(dataset, B, S, D, L)
+    state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S)
+    model = _model(ic, params, D, L, "fp32")
+    loss, sums, outputs = _run(model, ic, batch, modified, masks)
+    for k in keys:
+        err = (outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item()
+        assert err < 1e-4, ("logits", k, err)
+    sums = sums.cpu().double()
+    for i, k in enumerate(keys):
+        want = float(info["losses"][k])
+        assert abs(sums[i, 0].item() - want) <= 1e-4 * max(1.0, abs(want)), (k, sums[i, 0].item(), want)
+        assert abs(sums[i, 1].item() - float(info["scores"][k + "_score_num"])) < 1e-3, k
+        assert abs(sums[i, 2].item() - float(info["scores"][k + "_score_den"])) < 1e-6, k
+    assert abs(float(loss) - float(info["data_loss"])) <= 1e-4 * max(1.0, float(info["data_loss"]))
+    gd = model.store.grads_state_dict()
+    for name, want in grads.items():
+        got = gd[name].double()
+        scale = max(want.abs().max().item(), 1e-6)
+        err = (got - want).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
+
+
+def test_train_step_adam_parity_fp32():
+    """fwd + loss + L2 + per-variable clipnorm + Keras Adam: parameter delta vs the oracle."""
+    B, S, D, L = 4, 12, 128, 2
+    ic, params, batch, modified, masks, np_ref, torch_ref, keys = _setup("crello", B, S, D, L, seed=3)
+    state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S, l2=1e-2)
+    before = {k: v.detach().clone() for k, v in state.p.items()}
+    torch_ref.apply_gradients(state, grads)
+    from mfp.optim import AdamKeras
+    model = _model(ic, params, D, L, "fp32", l2=1e-2)
+    opt = AdamKeras(model.store, learning_rate=1e-2, clipnorm=1.0)
+    _run(model, ic, batch, modified, masks)
+    opt.step()
+    torch.cuda.synchronize()
+    reg = float(opt.reg_loss())
+    assert abs(reg - float(info["reg_loss"])) <= 1e-4 * float(info["reg_loss"])
+    after = model.store.state_dict()
+    for name in before:
+        d_want = (state.p[name].detach() - before[name]).double().reshape(-1)
+        d_got = (after[name].double() - before[name].double()).reshape(-1)
+        cos = torch.dot(d_want, d_got) / (d_want.norm() * d_got.norm() + 1e-30)
+        assert cos > 0.9999, (name, float(cos))
+        assert (d_got - d_want).abs().max() <= 2e-3 * d_want.abs().max() + 1e-7, name
+
+
+def test_bf16_deviation_from_oracle():
+    B, S, D, L = 8, 32, 256, 2
+    ic, params, batch, modified, masks, np_ref, torch_ref, keys = _setup("crello", B, S, D, L, seed=5)
+    state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S)
+    model = _model(ic, params, D, L, "bf16")
+    loss, sums, outputs = _run(model, ic, batch, modified, masks)
+    want = float(info["data_loss"])
+    rel = abs(float(loss) - want) / want
+    print("bf16 loss %.5f vs f64 oracle %.5f (rel %.2e)" % (float(loss), want, rel))
+    assert rel < 5e-3
+    for k in keys:
+        err = (outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item()
+        assert err < 0.1, (k, err)
+    gd = model.store.grads_state_dict()
+    worst = 1.0
+    for name, w in grads.items():
+        got = gd[name].double().reshape(-1)
+        w = w.reshape(-1)
+        if w.norm() < 1e-8:
+            continue
+        cos = float(torch.dot(got, w) / (got.norm() * w.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > 0.98, (name, cos)
+    print("bf16 worst gradient cosine %.5f" % worst)
+
+
+def test_dropout_training_runs_and_is_seeded():
+    B, S, D, L = 4, 16, 128, 2
+    ic, params, batch, modified, masks, *_ = _setup("crello", B, S, D, L, seed=7)
+    outs = []
+    for _ in range(2):
+        model = _model(ic, params, D, L, "fp32", dropout=0.1)
+        loss, sums, _o = _run(model, ic, batch, modified, masks)
+        outs.append((float(loss), model.store.g.clone()))
+    assert np.isfinite(outs[0][0])
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])  # same seed/offset
+    model = _model(ic, params, D, L, "fp32", dropout=0.0)
+    loss0, *_ = _run(model, ic, batch, modified, masks)
+    assert abs(float(loss0) - outs[0][0]) > 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_mfp_train_step_eager_and_graph(dtype):
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    B, S = 8, 32
+    batch = synthetic_batch(ic, B, S, seed=0, ragged=True, device=DEV)
+    model = MFP(ic, num_blocks=2, latent_dim=128, dropout=0.1, l2=1e-2, masking_method="random",
+                dtype=dtype, device=DEV)
+    model.compile(learning_rate=1e-3)
+    w0 = model.model.store.w.clone()
+    losses = []
+    for _ in range(3):
+        sums = model.train_step(batch)
+        losses.append(float(sums[:, 0].sum()))
+    assert all(np.isfinite(losses))
+    assert not torch.equal(w0, model.model.store.w)
+    assert int(model.optimizer.step_t.item()) == 3
+    model.capture_train_step(batch, warmup=1)
+    t0 = int(model.optimizer.step_t.item())
+    for _ in range(20):
+        sums = model.train_step(batch)
+    torch.cuda.synchronize()
+    assert int(model.optimizer.step_t.item()) == t0 + 20
+    m = model.metrics_dict(sums)
+    assert np.isfinite(m["loss"]) and m["loss"] < losses[0] + 1e-3, (m["loss"], losses)
+    assert 0.0 <= m["total_score"] <= 1.0
+    assert set(model.metrics_names) <= set(m.keys())
+
+
+def test_mfp_call_demo_args_and_merge():
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.architecture.mask import get_seq_mask
+    from mfp.models.masking import get_initial_masks
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    B, S = 4, 12
+    batch = synthetic_batch(ic, B, S, seed=2, ragged=True, device=DEV)
+    model = MFP(ic, num_blocks=1, latent_dim=128, dropout=0.1, l2=1e-2, dtype="fp32", device=DEV)
+    seq_mask = get_seq_mask(batch["length"], maxlen=S)
+    masks = get_initial_masks(model.input_columns, seq_mask)
+    for k in ("left", "top", "width", "height"):
+        masks[k] = seq_mask
+    out = model(batch, training=False, demo_args={"masks": masks, "num_iter": 1})
+    assert out["left"].shape == (B, S, 1, 64) and out["image_embedding"].shape == (B, S, 512)
+    # unmasked attributes are overwritten by the ground truth (mfp.py:46-69)
+    assert torch.equal(out["type"].argmax(-1), batch["type"].long())
+    assert torch.equal(out["image_embedding"], batch["image_embedding"])
+    assert out["tasks"].shape == (B,)
+    out3 = model(batch, training=False, demo_args={"masks": masks, "num_iter": 3})
+    assert out3["left"].shape == (B, S, 1, 64)
+    out_t = model(batch, training=False)  # non-demo: runs the LossLayer
+    assert "total_score" in model.loss_layer.metrics
+    scores = model.loss_layer((batch, {k: v for k, v in out.items()}, masks))[0]
+    assert "left_score_num" in scores
