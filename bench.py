@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Benchmark of the MFP train-step hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): elements/sec of the train step (masking -> forward -> masked losses ->
+backward -> [RCCL all-reduce] -> clipnorm + L2 + Keras Adam) on Crello-shaped synthetic batches,
+seq_len=128, d_model=256, 4 blocks, B=256 documents per GPU (weak scaling), bf16 MFMA operands
+with f32 accumulation.  One "element" = one sequence slot of a document.  Inputs are resident in
+HBM before the timed region.  For N>1 the driver launches this file under
+``python -m torch.distributed.run`` (one rank per GPU, RCCL); run directly with --gpus N>1 it
+re-launches itself that way.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line (prompt section 4):
+  roofline     - dominant kernel (by summed duration over a step) measured with HIP events on
+                 the launch stream in instrumented eager steps of the same workload: algorithmic
+                 FLOPs (2*M*N*K per GEMM launch) / summed duration vs the 2.5 PFLOP/s dense bf16
+                 MFMA peak.  `step` gives the whole-step figure from SURVEY.md section 8d
+                 (17 320 960 algorithmic FLOP per element).
+  cpu_baseline - the oracle's eager torch-CPU restatement of the same train step (kind "port";
+                 the TensorFlow reference cannot run here) on a bounded sample, host cores.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "flex-dm_amd"))
+
+B_PER_GPU, SEQ_LEN, D_MODEL, NUM_BLOCKS = 256, 128, 256, 4
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0
+
+
+def train_flops_per_element(D, L, S, U, n_num):
+    """3*L*(16 D^2 + 4 S D) + 2*(2*n_num*512*D) + 3*(2*D*U)."""
+    return 3 * L * (16 * D * D + 4 * S * D) + 2 * (2 * n_num * 512 * D) + 3 * (2 * D * U)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--masking_method", default="random")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="documents per GPU")
+    return ap.parse_args()
+
+
+def cpu_baseline(ic, budget_s=12.0):
+    """Oracle (checker only) timed as the CPU baseline: same train step, eager torch-CPU f32."""
+    import torch
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import synthetic_batch
+    B = 16
+    params = np_ref.init_params(ic, D_MODEL, NUM_BLOCKS, seed=0)
+    state = torch_ref.TrainState(params, lr=1e-4, l2=1e-2)
+    batch = synthetic_batch(ic, B, SEQ_LEN, seed=0)
+    gen = torch.Generator().manual_seed(0)
+    torch_ref.train_step(state, ic, batch, NUM_BLOCKS, rate=0.1, gen=gen, maxlen=SEQ_LEN)  # warm-up
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < budget_s and n < 200):
+        torch_ref.train_step(state, ic, batch, NUM_BLOCKS, rate=0.1, gen=gen, maxlen=SEQ_LEN)
+        n += 1
+    dt = time.time() - t0
+    return {"value": B * SEQ_LEN * n / dt, "unit": "elements/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": 1e3 * dt / n,
+            "sample": "%d train steps of the eager torch-CPU f32 restatement (oracle/torch_ref.py), Crello "
+                      "D=%d L=%d S=%d, B=%d documents/step (B reduced from 256 to bound the sample), "
+                      "dropout 0.1, masking_method=random" % (n, D_MODEL, NUM_BLOCKS, SEQ_LEN, B)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # convenience: relaunch under torchrun exactly as the driver does
+        port = os.environ.get("MASTER_PORT", "29511")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    import torch.distributed as dist
+    from mfp import dp
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.hip import ops
+    from mfp.models.mfp import MFP
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    world = dp.init_from_env()
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    torch.manual_seed(1234 + rank)
+
+    ic = make_input_columns("crello")
+    B, S = args.batch, SEQ_LEN
+    batch = synthetic_batch(ic, B, S, seed=rank, ragged=False, device=device)
+    model = MFP(ic, num_blocks=NUM_BLOCKS, latent_dim=D_MODEL, dropout=0.1, l2=1e-2,
+                masking_method=args.masking_method, dtype=args.dtype, device=device, seed=0)
+    model.compile(learning_rate=1e-4, clipnorm=1.0)
+    dp.broadcast_parameters(model.model.store.w)
+    model.model.store.refresh_shadow()
+    if not args.no_graph:
+        model.capture_train_step(batch, warmup=2)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        model.train_step(batch)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sums = model.train_step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    metrics = model.metrics_dict(sums)
+    assert metrics["loss"] == metrics["loss"] and abs(metrics["loss"]) < 1e9, "loss is not finite"
+
+    value = world * B * S * args.steps / elapsed
+    L = model.model.layout
+    fpe = train_flops_per_element(D_MODEL, NUM_BLOCKS, S, L.U, len(L.num_keys))
+    step_tflops = value / world * fpe / 1e12   # per GPU
+    out = {
+        "metric": "elements_per_sec_train_step", "value": value, "unit": "elements/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "Crello Ours-IMP train step (masking_method=%s): d_model=%d, %d DeepSVG blocks, "
+                               "seq_len=%d, %d documents/GPU, dropout 0.1, l2 1e-2, Adam lr 1e-4 clipnorm 1.0"
+                               % (args.masking_method, D_MODEL, NUM_BLOCKS, S, B),
+                   "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
+                   "launch": "eager" if args.no_graph else "hipGraph replay",
+                   "params": L.numel, "train_flop_per_element": fpe},
+        "final_loss": metrics["loss"],
+    }
+
+    # ---------------- roofline of the dominant kernel: HIP events on the launch stream, eager steps
+    if not args.no_roofline and rank == 0:
+        model._graph = None
+        model.train_step(batch)
+        torch.cuda.synchronize()
+        ops.start_profile()
+        nprof = 3
+        for _ in range(nprof):
+            model.train_step(batch)
+        recs = ops.stop_profile()
+        agg = {}
+        for name, flops, nbytes, ms in recs:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += flops; a[2] += nbytes; a[3] += ms
+        total_ms = sum(a[3] for a in agg.values())
+        table = sorted(agg.items(), key=lambda kv: -kv[1][3])
+        name, (cnt, flops, nbytes, ms) = table[0]
+        if flops > 0:
+            achieved = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None}
+        else:
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+        roof.update({"launches_per_step": cnt // nprof, "avg_launch_us": 1e3 * ms / cnt,
+                     "share_of_instrumented_kernel_time": ms / total_ms,
+                     "step": {"achieved": step_tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": step_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS},
+                     "kernels_us_per_step": {k: round(1e3 * v[3] / nprof, 1) for k, v in table}})
+        out["roofline"] = roof
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(ic)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,45 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+# ------------------------------------------------------------------------------- profiling
+# bench.py's roofline leg: HIP events recorded on the launch stream around each library call
+# (torch.cuda.Event records on torch's current stream, which is the stream passed to the kernels).
+_prof = None
+
+
+def start_profile():
+    global _prof
+    _prof = []
+
+
+def stop_profile():
+    """-> [(kernel name, algorithmic flops, algorithmic bytes, milliseconds)]"""
+    global _prof
+    recs, _prof = _prof or [], None
+    torch.cuda.synchronize()
+    return [(n, f, b, e0.elapsed_time(e1)) for n, f, b, e0, e1 in recs]
+
+
+class _timed:
+    def __init__(self, name, flops=0, nbytes=0):
+        self.args = (name, flops, nbytes)
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _prof.append(self.args + (self.e0, e1))
+
+
+def _esz(t):
+    return t.element_size()
+
+
 # ------------------------------------------------------------------------------- workspace
 _workspaces: Dict[torch.device, List[torch.Tensor]] = {}
 
@@ -107,7 +146,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
     if nbytes:
         ws = workspace(nbytes, A.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    check(lib.mfp_gemm(ctypes.byref(a), _stream()), "mfp_gemm")
+    name = "gemm_kernel<%s,%s,%s>" % ("bf16" if A.dtype == torch.bfloat16 else "f32",
+                                      "Ak" if a_kmajor else "Am", "Bk" if b_kmajor else "Bn")
+    with _timed(name, 2 * M * N * K, (M * K + N * K) * _esz(A) + M * N * _esz(out)):
+        check(lib.mfp_gemm(ctypes.byref(a), _stream()), "mfp_gemm")
     return out
 
 
@@ -130,8 +172,9 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
     y = torch.empty((T, D), dtype=out_dtype, device=x.device)
     mean = torch.empty((T,), dtype=torch.float32, device=x.device)
     rstd = torch.empty((T,), dtype=torch.float32, device=x.device)
-    check(lib.mfp_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), T, D,
-                                LN_EPS, dt_code(out_dtype), _stream()), "mfp_layernorm_fwd")
+    with _timed("ln_fwd_kernel", 0, T * D * (4 + _esz(y))):
+        check(lib.mfp_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), T, D,
+                                    LN_EPS, dt_code(out_dtype), _stream()), "mfp_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -143,9 +186,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma
         dx = torch.empty((T, D), dtype=torch.float32, device=x.device)
     nbytes = lib.mfp_layernorm_bwd_workspace_bytes(T, D)
     ws = workspace(nbytes, x.device)
-    check(lib.mfp_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
-                                _ptr(dx), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), ws.numel(), T, D,
-                                dt_code(dy.dtype), _stream()), "mfp_layernorm_bwd")
+    with _timed("ln_bwd_kernel", 0, T * D * (_esz(dy) + 4 + (4 if dres is not None else 0) + 4)):
+        check(lib.mfp_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
+                                    _ptr(dx), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), ws.numel(), T, D,
+                                    dt_code(dy.dtype), _stream()), "mfp_layernorm_bwd")
     return dx
 
 
@@ -155,8 +199,9 @@ def attention_fwd(qkv: torch.Tensor, nvalid: torch.Tensor, B: int, S: int, H: in
     D = qkv.shape[1] // 3
     out = torch.empty((B * S, D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
-    check(lib.mfp_attention_fwd(_ptr(qkv), _ptr(nvalid), _ptr(out), _ptr(lse), B, S, H, D // H,
-                                dt_code(qkv.dtype), _stream()), "mfp_attention_fwd")
+    with _timed("attn_fwd", 4 * B * S * S * D, B * S * 4 * D * _esz(qkv)):
+        check(lib.mfp_attention_fwd(_ptr(qkv), _ptr(nvalid), _ptr(out), _ptr(lse), B, S, H, D // H,
+                                    dt_code(qkv.dtype), _stream()), "mfp_attention_fwd")
     return out, lse
 
 
@@ -164,8 +209,9 @@ def attention_bwd(qkv, nvalid, out, dout, lse, B: int, S: int, H: int) -> torch.
     lib = load()
     D = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
-    check(lib.mfp_attention_bwd(_ptr(qkv), _ptr(nvalid), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv),
-                                B, S, H, D // H, dt_code(qkv.dtype), _stream()), "mfp_attention_bwd")
+    with _timed("attn_bwd", 8 * B * S * S * D, B * S * 8 * D * _esz(qkv)):
+        check(lib.mfp_attention_bwd(_ptr(qkv), _ptr(nvalid), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv),
+                                    B, S, H, D // H, dt_code(qkv.dtype), _stream()), "mfp_attention_bwd")
     return dqkv
 
 
@@ -175,8 +221,9 @@ def embed_pool_fwd(idx: torch.Tensor, rowoff: torch.Tensor, tables: torch.Tensor
     T, NCOL = idx.shape
     ROWS, D = tables.shape
     out = torch.empty((T, D), dtype=torch.float32, device=idx.device)
-    check(lib.mfp_embed_pool_fwd(_ptr(idx), _ptr(rowoff), _ptr(tables), _ptr(out), T, NCOL, ROWS, D,
-                                 _stream()), "mfp_embed_pool_fwd")
+    with _timed("embed_fwd_kernel", 0, T * (NCOL * 4 + D * 4)):
+        check(lib.mfp_embed_pool_fwd(_ptr(idx), _ptr(rowoff), _ptr(tables), _ptr(out), T, NCOL, ROWS, D,
+                                     _stream()), "mfp_embed_pool_fwd")
     return out
 
 
@@ -186,8 +233,9 @@ def embed_pool_bwd(idx, rowoff, dout: torch.Tensor, dtables: torch.Tensor) -> to
     ROWS, D = dtables.shape
     nbytes = lib.mfp_embed_pool_bwd_workspace_bytes(T, NCOL, ROWS, D)
     ws = workspace(nbytes, idx.device)
-    check(lib.mfp_embed_pool_bwd(_ptr(idx), _ptr(rowoff), _ptr(dout), _ptr(dtables), ws.data_ptr(),
-                                 ws.numel(), T, NCOL, ROWS, D, _stream()), "mfp_embed_pool_bwd")
+    with _timed("embed_bwd_kernel", 0, T * (NCOL * 4 + D * 4)):
+        check(lib.mfp_embed_pool_bwd(_ptr(idx), _ptr(rowoff), _ptr(dout), _ptr(dtables), ws.data_ptr(),
+                                     ws.numel(), T, NCOL, ROWS, D, _stream()), "mfp_embed_pool_bwd")
     return dtables
 
 
@@ -196,8 +244,9 @@ def row_flags(x: torch.Tensor, rowcode: torch.Tensor, special_idx: Optional[torc
     """x f32 [T,K] -> rowcode u8 [T]; optionally special_idx[t*stride] = rowcode-1."""
     lib = load()
     T, K = x.shape
-    check(lib.mfp_row_flags(_ptr(x), _ptr(rowcode), _ptr(special_idx), idx_stride, T, K, _stream()),
-          "mfp_row_flags")
+    with _timed("row_flags_kernel", 0, T * K * 4):
+        check(lib.mfp_row_flags(_ptr(x), _ptr(rowcode), _ptr(special_idx), idx_stride, T, K, _stream()),
+              "mfp_row_flags")
     return rowcode
 
 
@@ -222,8 +271,10 @@ def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tenso
     if dl_dtype is not None and dlogits is None:
         dlogits = torch.zeros(logits.shape, dtype=dl_dtype, device=logits.device)
     code = dt_code(dlogits.dtype) if dlogits is not None else MFP_F32
-    check(lib.mfp_loss_fwd_bwd(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid), _ptr(sums),
-                               B, S, code, _stream()), "mfp_loss_fwd_bwd")
+    nb = logits.numel() * (4 + (_esz(dlogits) if dlogits is not None else 0))
+    with _timed("loss_kernels(ce+mse)", 0, nb):
+        check(lib.mfp_loss_fwd_bwd(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid), _ptr(sums),
+                                   B, S, code, _stream()), "mfp_loss_fwd_bwd")
     return sums, dlogits
 
 
@@ -248,7 +299,8 @@ def adam_keras(w, g, m, v, shadow: Optional[torch.Tensor], chunks: AdamChunks, s
                stats: torch.Tensor, step_t: torch.Tensor, lr: float, beta1: float = 0.9,
                beta2: float = 0.999, eps: float = 1e-7, clipnorm: float = 1.0, grad_scale: float = 1.0):
     lib = load()
-    check(lib.mfp_adam_keras(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(chunks.chunk_seg),
+    with _timed("adam_kernels", 0, w.numel() * (8 + 16 + 12 + (2 if shadow is not None else 0))):
+      check(lib.mfp_adam_keras(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(chunks.chunk_seg),
                              _ptr(chunks.chunk_beg), _ptr(chunks.chunk_len), chunks.nchunks,
                              _ptr(seg_l2), _ptr(stats), chunks.nseg, _ptr(step_t), lr, beta1, beta2, eps,
                              clipnorm if clipnorm is not None else 0.0, grad_scale, _stream()),
@@ -257,7 +309,8 @@ def adam_keras(w, g, m, v, shadow: Optional[torch.Tensor], chunks: AdamChunks, s
 
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
     lib = load()
-    check(lib.mfp_cast_f32_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), "mfp_cast_f32_bf16")
+    with _timed("cast_kernel", 0, src.numel() * 6):
+        check(lib.mfp_cast_f32_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), "mfp_cast_f32_bf16")
     return dst
 
 
@@ -267,8 +320,10 @@ def dropout_bwd(dx: torch.Tensor, out_dtype: torch.dtype, colsum: torch.Tensor, 
     M, N = dx.shape
     dy = torch.empty((M, N), dtype=out_dtype, device=dx.device)
     ws = workspace(lib.mfp_colsum_workspace_bytes(M, N), dx.device)
-    check(lib.mfp_dropout_bwd(_ptr(dx), _ptr(dy), _ptr(colsum), ws.data_ptr(), ws.numel(), M, N, float(p),
-                              int(seed), int(offset), _ptr(step_ptr), dt_code(out_dtype), _stream()), "mfp_dropout_bwd")
+    with _timed("dropout_bwd_kernel", 0, M * N * (4 + _esz(dy))):
+        check(lib.mfp_dropout_bwd(_ptr(dx), _ptr(dy), _ptr(colsum), ws.data_ptr(), ws.numel(), M, N, float(p),
+                                  int(seed), int(offset), _ptr(step_ptr), dt_code(out_dtype), _stream()),
+              "mfp_dropout_bwd")
     return dy
 
 
