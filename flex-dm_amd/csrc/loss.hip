@@ -176,6 +176,13 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
   }
 }
 
+// hipMemsetAsync is avoided on purpose: captured into a hipGraph as a memset node it left
+// stray words in the 120-byte `sums` buffer on ROCm 7.2 (replays only); a kernel node is exact.
+__global__ void zero_sums_kernel(float* __restrict__ sums, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sums[i] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
@@ -197,8 +204,8 @@ extern "C" int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, 
       cat.k[cat.n] = keys[i]; cat.key_slot[cat.n] = i; cat.n++;
     }
   }
-  hipError_t e = hipMemsetAsync(sums, 0, (size_t)nkeys * 3 * sizeof(float), st);
-  if (e != hipSuccess) { mfp_set_error("mfp_loss_fwd_bwd: memset: %s", hipGetErrorString(e)); return MFP_ELAUNCH; }
+  hipLaunchKernelGGL(zero_sums_kernel, dim3(1), dim3(64), 0, st, sums, nkeys * 3);
+  MFP_CHECK_LAUNCH();
   const float inv_B = 1.0f / (float)B;
   if (cat.n > 0) {
     int bx = (T + 15) / 16;
