@@ -3,6 +3,7 @@
 // sums the addressed rows of all (tiny, L2-resident) tables into the element's D-vector.
 // HBM-bound: algorithmic bytes/element = NCOL*4 read + D*4 write (fwd).
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -28,30 +29,42 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ 
   }
 }
 
-// Backward: dtables[rowoff[c] + idx[t][c]] += dout[t].  Workgroup = (token chunk, 64-wide d
-// slice); the slice of ALL tables lives in LDS (ROWS*64*4 B) and is accumulated with LDS float
-// atomics (lanes hit distinct addresses; waves may collide), then written as a partial
-// [chunk][ROWS][D]; a second kernel sums the chunks.  No global atomics.
-constexpr int EB_DSLICE = 64;
+// Backward: dtables[rowoff[c] + idx[t][c]] += dout[t].  Workgroup = (token chunk, 32-wide d
+// slice); the slice of ALL tables lives in LDS (ROWS*32*4 B, ~44 KB for Crello -> 3 WG/CU) and is
+// accumulated with native ds_add_f32 (a half-wave owns a token: lanes hit distinct addresses,
+// half-waves may collide).  The NCOL indices of a token are fetched with ONE vector load and
+// broadcast by shuffle.  Partials [chunk][ROWS][D] are summed by reduce_rows_kernel: no global
+// atomics.
+constexpr int EB_DSLICE = 32;
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ idx,
                                                         const int* __restrict__ rowoff,
                                                         const float* __restrict__ dout,
                                                         float* __restrict__ part, int T, int NCOL,
                                                         int ROWS, int D, int tok_per_chunk) {
-  extern __shared__ __attribute__((aligned(16))) float tab[];  // [ROWS][64]
+  extern __shared__ __attribute__((aligned(16))) float tab[];  // [ROWS][32]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
   const int chunk = blockIdx.x, d0 = blockIdx.y * EB_DSLICE;
   for (int i = threadIdx.x; i < ROWS * EB_DSLICE; i += 256) tab[i] = 0.f;
   __syncthreads();
+  const int myoff = l32 < NCOL ? rowoff[l32] : 0;
   const int t0 = chunk * tok_per_chunk, t1 = min(T, t0 + tok_per_chunk);
-  for (int t = t0 + wave; t < t1; t += 4) {
-    const float g = dout[(long long)t * D + d0 + lane];
-    const int* it = idx + (long long)t * NCOL;
+  for (int tb = t0 + wave * 2; tb < t1; tb += 8) {
+    const int t = tb + half;
+    const bool ok = t < t1;
+    float g = 0.f;
+    int myrow = -1;
+    if (ok) {
+      g = dout[(long long)t * D + d0 + l32];
+      if (l32 < NCOL) {
+        const int r = idx[(long long)t * NCOL + l32];
+        myrow = r < 0 ? -1 : myoff + r;
+      }
+    }
     for (int j = 0; j < NCOL; ++j) {
-      const int r = it[j];
-      if (r < 0) continue;
-      atomicAdd(&tab[(rowoff[j] + r) * EB_DSLICE + lane], g);
+      const int row = __shfl(myrow, half * 32 + j, 64);
+      if (row >= 0) atomicAdd(&tab[row * EB_DSLICE + l32], g);
     }
   }
   __syncthreads();
@@ -60,15 +73,6 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
     int r = i / EB_DSLICE, c = i % EB_DSLICE;
     pout[(long long)r * D + d0 + c] = tab[i];
   }
-}
-
-__global__ void embed_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dtables,
-                                        long long n, int nchunks) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += part[(long long)c * n + i];
-  dtables[i] = s;
 }
 
 // rowcode: 1 = all == 10.0 (<MASK>), 2 = all == 0.0 (<UNUSED>); one wave per row of K floats.
@@ -126,7 +130,7 @@ extern "C" int mfp_embed_pool_bwd(const int32_t* idx, const int32_t* rowoff, con
                                   float* dtables, void* workspace, size_t workspace_bytes, int32_t T,
                                   int32_t NCOL, int32_t ROWS, int32_t D, mfp_stream_t stream) {
   MFP_CHECK_ARG(idx && rowoff && dout && dtables);
-  MFP_CHECK_ARG(T > 0 && NCOL > 0 && ROWS > 0 && D > 0 && D % EB_DSLICE == 0);
+  MFP_CHECK_ARG(T > 0 && NCOL > 0 && NCOL <= 32 && ROWS > 0 && D > 0 && D % EB_DSLICE == 0);
   const size_t lds = (size_t)ROWS * EB_DSLICE * sizeof(float);
   MFP_CHECK_ARG(lds <= 160 * 1024);
   if (!workspace || workspace_bytes < mfp_embed_pool_bwd_workspace_bytes(T, NCOL, ROWS, D)) {
@@ -149,8 +153,7 @@ extern "C" int mfp_embed_pool_bwd(const int32_t* idx, const int32_t* rowoff, con
                      dout, part, T, NCOL, ROWS, D, tpc);
   MFP_CHECK_LAUNCH();
   long long n = (long long)ROWS * D;
-  hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, st, part,
-                     dtables, n, chunks);
+  launch_reduce_rows(part, dtables, dtables, n, chunks, n, n, st);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

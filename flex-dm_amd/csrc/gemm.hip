@@ -276,18 +276,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     }
 }
 
-// out[m][n] (+)= sum_z ws[z][m][n];  colsum[m] = sum_z ws_col[z][m]
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_col,
-                                     float* __restrict__ C, float* __restrict__ colsum, int M, int N,
-                                     int ldc, int splitk, int accum) {
-  long long total = (long long)M * N;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < splitk; ++z) s += ws[(long long)z * total + idx];
-    long long m = idx / N, n = idx % N;
-    float* c = C + m * ldc + n;
-    *c = accum ? *c + s : s;
+// out[m][n] (+)= sum_z ws[z][m][n];  colsum[m] = sum_z ws_col[z][m].  N % 4 == 0.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws,
+                                                            const float* __restrict__ ws_col,
+                                                            float* __restrict__ C, float* __restrict__ colsum,
+                                                            int M, int N, int ldc, int splitk, int accum) {
+  const long long total4 = (long long)M * N / 4;
+  const long long total = (long long)M * N;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4;
+       i4 += (long long)gridDim.x * blockDim.x) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int z = 0; z < splitk; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (long long)z * total + i4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const long long idx = i4 * 4, m = idx / N, n = idx % N;
+    float4* c = reinterpret_cast<float4*>(C + m * ldc + n);
+    if (accum) { const float4 o = *c; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *c = s;
   }
   if (colsum != nullptr) {
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
@@ -349,7 +356,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   if (a->flags & MFP_GEMM_DROPOUT) MFP_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f);
   const bool ws_path = uses_workspace(a);
   if (ws_path) {
-    MFP_CHECK_ARG(a->out_dtype == MFP_F32);
+    MFP_CHECK_ARG(a->out_dtype == MFP_F32 && a->N % 4 == 0 && a->ldc % 4 == 0);
     MFP_CHECK_ARG((a->flags & ~(MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A | MFP_GEMM_ACCUM)) == 0);
     if (a->workspace == nullptr || a->workspace_bytes < mfp_gemm_workspace_bytes(a)) {
       mfp_set_error("mfp_gemm: workspace too small (%zu < %zu)", a->workspace_bytes,
@@ -377,7 +384,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   if (rc != MFP_OK) return rc;
   MFP_CHECK_LAUNCH();
   if (ws_path) {
-    long long total = (long long)a->M * a->N;
+    long long total = (long long)a->M * a->N / 4;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ws_col,

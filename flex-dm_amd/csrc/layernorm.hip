@@ -3,6 +3,7 @@
 // loads, wavefront-wide shuffle reductions; mean/rstd saved (8 B/row) for the backward.
 //   fwd bytes/row: D*4 read + D*e write (+8);  bwd: D*(4 + e + 4[dres]) read + D*4 write.
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -143,16 +144,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   }
 }
 
-// out[c] = sum_p part[p][c], c < ncols
-__global__ void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                       float* __restrict__ out1, int nparts, int D) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * D) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(long long)p * 2 * D + c];
-  if (c < D) out0[c] = s; else out1[c - D] = s;
-}
-
 }  // namespace
 
 extern "C" int mfp_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y,
@@ -203,8 +194,7 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
   }
 #undef LN_BWD
   MFP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, part, dgamma,
-                     dbeta, nblk, D);
+  launch_reduce_rows(part, dgamma, dbeta, D, nblk, 2 * D, 2 * D, st);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -1,0 +1,158 @@
+// Fused MFP input masking for the train step: filter_padding + random_masking + elem_masking +
+// feat_masking + the per-document task select of preprocess_for_train (reference
+// models/masking.py:24-53,68-155,227-269; models/mfp.py:95-138) in ONE launch.
+//
+// The reference computes all 7 task variants of every attribute with ~20 small eager ops each and
+// tf.where-selects by task id; here one wave owns one element (token): its lanes decide every
+// categorical (column, feature) at once and then stream the 512-wide numerical rows.  Outputs go
+// straight into the buffers the encoder kernels read:
+//   idx_all [T][NCOL] int32 : modified categorical indices (<MASK> = C, <UNUSED> = C+1) and, in
+//                             the special columns, 0 / 1 / -1 for numerical <MASK>/<UNUSED>/none
+//   rowcode [T] u8, x_out [T][W] cdt : numerical attributes (encoder.py:165-175 semantics)
+//   mask_out [T] u8 : the MFP mask of each attribute (what LossLayer weighs by)
+// HBM-bound: ~W*(4 + e) bytes per numerical attribute per element + O(100) bytes of indices.
+//
+// Randomness is counter-based Philox keyed by (seed, element, column, step): same distribution as
+// the reference (MASK_PROB .15, 90 % changed of which 1/9 random token), not the same stream.
+#include "common.h"
+
+namespace {
+
+struct MaskCols {
+  mfp_mask_col c[MFP_MAX_MASK_COLS];
+  int n;
+};
+
+__device__ __forceinline__ float u01(unsigned int r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+constexpr float MASK_PROB = 0.15f;          // masking.py:11
+constexpr float CHANGE_PROB = 0.9f;         // masking.py:13-14
+constexpr float THRESH = 0.1f / 0.9f;       // masking.py:15
+
+// decision for (element t, column k): 0 keep, 1 <MASK>, 2 <UNUSED>, 3 random token; *mfp = mask bit
+__device__ __forceinline__ int decide(const mfp_mask_col& col, int k, int t, int s, int nv, int task, int sel,
+                                      unsigned long long seed, unsigned long long off, bool* mfp,
+                                      unsigned int* rnd_extra) {
+  const bool valid = s < nv;
+  bool unused = !valid;
+  if (col.cond_idx != nullptr && valid) {
+    const int v = col.cond_idx[(long long)t * col.cond_stride];
+    unused = !(v >= 0 && v < 32 && ((col.cond_bits >> v) & 1u));
+  }
+  int code = unused ? 2 : 0;
+  bool m = false;
+  if (task == 0) {
+    unsigned int r[4];
+    philox4x32(seed, (unsigned int)t, (unsigned int)k, off, r);
+    m = valid && u01(r[0]) < MASK_PROB;
+    const bool chg = m && u01(r[1]) < CHANGE_PROB;
+    if (chg) code = u01(r[2]) >= THRESH ? 1 : 3;
+    *rnd_extra = r[3];
+  } else if (task == 1) {
+    m = valid && s == sel;
+    if (m) code = 1;
+  } else {
+    m = valid && col.group == task - 2;
+    if (m) code = 1;
+  }
+  *mfp = m;
+  return code;
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void mask_kernel(MaskCols cols, int* __restrict__ idx_all, int NCOL,
+                                                   const int* __restrict__ nvalid, const int* __restrict__ tasks,
+                                                   int T, int S, unsigned long long seed,
+                                                   unsigned long long offset0, const int* __restrict__ step_ptr) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const unsigned long long off = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  const int b = t / S, s = t % S;
+  const int nv = nvalid[b], task = tasks[b];
+  int sel = -1;
+  if (task == 1) {  // select_single_element (masking.py:98-113): floor(U * length)
+    unsigned int r[4];
+    philox4x32(seed, (unsigned int)b, 0xE1E0E1E0u, off, r);
+    sel = min((int)(u01(r[0]) * (float)nv), nv - 1);
+  }
+  for (int k = 0; k < cols.n; ++k) {
+    const mfp_mask_col& col = cols.c[k];
+    bool mfp;
+    unsigned int extra;
+    const int code = decide(col, k, t, s, nv, task, sel, seed, off, &mfp, &extra);  // wave-uniform
+    if (lane == 0) col.mask_out[t] = mfp ? 1 : 0;
+    if (!col.is_numerical) {
+      if (lane < col.n_feat) {
+        int v = reinterpret_cast<const int*>(col.src)[(long long)t * col.n_feat + lane];
+        if (code == 2) v = col.input_dim + 1;
+        else if (code == 1) v = col.input_dim;
+        else if (code == 3) {
+          unsigned int r[4];
+          philox4x32(seed, (unsigned int)t, (unsigned int)(k + 64 * (lane + 1)), off, r);
+          v = (int)(((unsigned long long)r[0] * (unsigned long long)col.input_dim) >> 32);
+        }
+        idx_all[(long long)t * NCOL + col.idx_col + lane] = v;
+      }
+    } else {
+      const int W = col.n_feat;
+      if (lane == 0) {
+        col.rowcode[t] = (unsigned char)((code == 1 || code == 2) ? code : 0);
+        idx_all[(long long)t * NCOL + col.idx_col] = code == 1 ? 0 : (code == 2 ? 1 : -1);
+      }
+      const float* src = reinterpret_cast<const float*>(col.src) + (long long)t * W;
+      TX* dst = reinterpret_cast<TX*>(col.x_out) + (long long)t * W;
+      for (int c = lane * 4; c < W; c += 256) {
+        float4 v;
+        if (code == 0) {
+          v = *reinterpret_cast<const float4*>(src + c);
+        } else if (code == 1) {
+          v = make_float4(10.f, 10.f, 10.f, 10.f);     // MASK_VALUE (masking.py:8)
+        } else if (code == 2) {
+          v = make_float4(0.f, 0.f, 0.f, 0.f);         // NULL_VALUE (masking.py:9)
+        } else {  // tf.random.normal(stddev=0.1): Box-Muller on 4 Philox uniforms
+          unsigned int r[4];
+          philox4x32(seed, (unsigned int)t, (unsigned int)(k + 64 * (1 + c / 4)), off ^ 0x5bd1e995ull, r);
+          const float u0 = fmaxf(u01(r[0]), 1e-7f), u1 = u01(r[1]), u2 = fmaxf(u01(r[2]), 1e-7f), u3 = u01(r[3]);
+          const float ra = 0.1f * sqrtf(-2.f * logf(u0)), rb = 0.1f * sqrtf(-2.f * logf(u2));
+          v = make_float4(ra * cosf(6.2831853f * u1), ra * sinf(6.2831853f * u1),
+                          rb * cosf(6.2831853f * u3), rb * sinf(6.2831853f * u3));
+        }
+        if constexpr (sizeof(TX) == 4) {
+          *reinterpret_cast<float4*>(dst + c) = v;
+        } else {
+          u32x2 pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+          *reinterpret_cast<u32x2*>(dst + c) = pk;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mfp_mask_tokens(const mfp_mask_col* cols, int32_t ncols, int32_t* idx_all, int32_t NCOL,
+                               const int32_t* nvalid, const int32_t* tasks, int32_t B, int32_t S, uint64_t seed,
+                               uint64_t offset, const int32_t* step_ptr, int32_t x_dtype, mfp_stream_t stream) {
+  MFP_CHECK_ARG(cols && idx_all && nvalid && tasks);
+  MFP_CHECK_ARG(ncols > 0 && ncols <= MFP_MAX_MASK_COLS && B > 0 && S > 0 && NCOL > 0);
+  MFP_CHECK_ARG(x_dtype == MFP_F32 || x_dtype == MFP_BF16);
+  MaskCols mc;
+  mc.n = ncols;
+  for (int i = 0; i < ncols; ++i) {
+    MFP_CHECK_ARG(cols[i].src && cols[i].mask_out);
+    if (cols[i].is_numerical) MFP_CHECK_ARG(cols[i].x_out && cols[i].rowcode && cols[i].n_feat % 4 == 0);
+    else MFP_CHECK_ARG(cols[i].n_feat >= 1 && cols[i].n_feat <= 64 && cols[i].input_dim > 0);
+    mc.c[i] = cols[i];
+  }
+  const int T = B * S;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (x_dtype == MFP_F32)
+    hipLaunchKernelGGL(mask_kernel<float>, dim3((T + 3) / 4), dim3(256), 0, st, mc, idx_all, NCOL, nvalid, tasks, T, S,
+                       seed, offset, step_ptr);
+  else
+    hipLaunchKernelGGL(mask_kernel<unsigned short>, dim3((T + 3) / 4), dim3(256), 0, st, mc, idx_all, NCOL, nvalid,
+                       tasks, T, S, seed, offset, step_ptr);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

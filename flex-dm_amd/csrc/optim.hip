@@ -7,6 +7,7 @@
 //  * mfp_dropout_bwd: regenerates the Philox keep mask of MFP_GEMM_DROPOUT and emits the
 //    (cdt) gradient of the Dense output together with its column sums (= bias gradient).
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -130,14 +131,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
   part[(long long)blockIdx.y * N + c] = cs;
 }
 
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int nparts) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(long long)p * N + c];
-  out[c] = s;
-}
-
 }  // namespace
 
 // The chunk table (segment id, start, length per <=4096-element chunk) is static per model: it
@@ -202,8 +195,8 @@ extern "C" int mfp_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, mfp
 }
 
 static int rows_per_block_for(int M) {
-  int rpb = ((M + 255) / 256 + 3) & ~3;  // <= 256 row blocks, multiple of 4 (Philox row groups)
-  if (rpb < 4) rpb = 4;
+  int rpb = ((M + 1023) / 1024 + 3) & ~3;  // <= 1024 row blocks, multiple of 4 (Philox row groups)
+  if (rpb < 16) rpb = 16;
   return rpb;
 }
 
@@ -231,7 +224,7 @@ extern "C" int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* w
   else
     hipLaunchKernelGGL(dropout_bwd_kernel<unsigned short>, grid, dim3(256), 0, st, dx, (unsigned short*)dy, part, M, N, p, seed, offset, step_ptr, rpb);
   MFP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, colsum, N, nrb);
+  launch_reduce_rows(part, colsum, colsum, N, nrb, N, N, st);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
@@ -253,7 +246,7 @@ extern "C" int mfp_colsum(const void* X, float* colsum, void* workspace, size_t 
   else
     hipLaunchKernelGGL(colsum_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short*)X, part, M, N, ld, rpb);
   MFP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, colsum, N, nrb);
+  launch_reduce_rows(part, colsum, colsum, N, nrb, N, N, st);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -50,6 +50,15 @@ class LossKey(Structure):
     ]
 
 
+class MaskCol(Structure):
+    _fields_ = [
+        ("is_numerical", c_int32), ("n_feat", c_int32), ("input_dim", c_int32), ("group", c_int32),
+        ("src", c_void_p), ("cond_idx", c_void_p), ("cond_stride", c_int32), ("cond_bits", c_uint32),
+        ("idx_col", c_int32), ("_pad", c_int32), ("x_out", c_void_p), ("rowcode", c_void_p),
+        ("mask_out", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/mfp_hip.h declares
 # (tests/test_abi.py cross-checks this table against the header and the .so).
 SIGNATURES = {
@@ -78,6 +87,8 @@ SIGNATURES = {
     "mfp_dropout_bwd": (c_int32, [c_void_p] * 4 + [c_size_t, c_int32, c_int32, c_float, c_uint64,
                                                    c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_colsum": (c_int32, [c_void_p] * 3 + [c_size_t] + [c_int32] * 4 + [c_void_p]),
+    "mfp_mask_tokens": (c_int32, [POINTER(MaskCol), c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
+                                  c_int32, c_uint64, c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_debug_tr_probe": (c_int32, [c_void_p, c_void_p, c_void_p]),
 }
 

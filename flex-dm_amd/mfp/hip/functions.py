@@ -43,11 +43,37 @@ class StepCtx:
 
 
 # ------------------------------------------------------------------------------------ encoder
+def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
+    st, L = ctx.store, ctx.store.layout
+    T, D = ctx.T, L.D
+    h = ops.embed_pool_fwd(idx_all, st.rowoff, st.tables())
+    for j, k in enumerate(L.num_keys):
+        width = xs[j].shape[1]
+        ops.gemm(xs[j], st.cw("encoder/input_%s/kernel" % k), T, D, width, a_kmajor=True, b_kmajor=True,
+                 out=h, accum=True, rowskip=codes[j], bias=st.weight("encoder/input_%s/bias" % k))
+    return h
+
+
+def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
+    st, L = ctx.store, ctx.store.layout
+    T, D = ctx.T, L.D
+    ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
+    if L.num_keys:
+        dh_c = ctx.to_cdt(dh)
+        for j, k in enumerate(L.num_keys):
+            width = xs[j].shape[1]
+            ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
+                     out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
+                     colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
+
+
 class EncoderFn(torch.autograd.Function):
+    """Encoder on a dict of (already masked) attribute tensors, as the reference's call takes."""
+
     @staticmethod
     def forward(fctx, anchor, ctx: StepCtx, cat_inputs: List[torch.Tensor], num_inputs: List[torch.Tensor]):
-        st, L = ctx.store, ctx.store.layout
-        T, D = ctx.T, L.D
+        L = ctx.store.layout
+        T = ctx.T
         dev = anchor.device
         n_num = len(L.num_keys)
         cols = [t.reshape(T, -1).to(torch.int32) for t in cat_inputs]
@@ -62,32 +88,32 @@ class EncoderFn(torch.autograd.Function):
             ops.row_flags(x, code, idx_all[:, L.special_col[k]:], idx_all.shape[1])
             codes.append(code)
             xs.append(ctx.to_cdt(x))
-        h = ops.embed_pool_fwd(idx_all, st.rowoff, st.tables())
-        for j, k in enumerate(L.num_keys):
-            width = xs[j].shape[1]
-            ops.gemm(xs[j], st.cw("encoder/input_%s/kernel" % k), T, D, width, a_kmajor=True, b_kmajor=True,
-                     out=h, accum=True, rowskip=codes[j], bias=st.weight("encoder/input_%s/bias" % k))
         fctx.ctx = ctx
         fctx.saved = (idx_all, codes, xs)
-        return h
+        return _encoder_fwd(ctx, idx_all, codes, xs)
 
     @staticmethod
     def backward(fctx, dh):
-        ctx = fctx.ctx
-        st, L = ctx.store, ctx.store.layout
-        idx_all, codes, xs = fctx.saved
-        dh = dh.contiguous()
-        T, D = ctx.T, L.D
-        ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
-        if L.num_keys:
-            dh_c = ctx.to_cdt(dh)
-            for j, k in enumerate(L.num_keys):
-                width = xs[j].shape[1]
-                ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
-                         out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
-                         colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
+        _encoder_bwd(fctx.ctx, *fctx.saved, dh.contiguous())
         fctx.saved = None
         return None, None, None, None
+
+
+class EncoderPreFn(torch.autograd.Function):
+    """Encoder on the outputs of the fused masking kernel (train-step fast path): the index
+    matrix, row codes and compute-dtype numerical rows already exist."""
+
+    @staticmethod
+    def forward(fctx, anchor, ctx: StepCtx, idx_all, codes, xs):
+        fctx.ctx = ctx
+        fctx.saved = (idx_all, codes, xs)
+        return _encoder_fwd(ctx, idx_all, codes, xs)
+
+    @staticmethod
+    def backward(fctx, dh):
+        _encoder_bwd(fctx.ctx, *fctx.saved, dh.contiguous())
+        fctx.saved = None
+        return None, None, None, None, None
 
 
 # -------------------------------------------------------------------------------------- block

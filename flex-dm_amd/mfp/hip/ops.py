@@ -13,7 +13,7 @@ import torch
 
 from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_A, GEMM_DROPOUT, GEMM_RELU, GEMM_RELU_BWD,
                GEMM_RESIDUAL, GEMM_ROWSKIP, GEMM_ROWSKIP_A, MFP_BF16, MFP_F32, GemmArgs, LossKey,
-               check, load)
+               MaskCol, check, load)
 
 _DT = {torch.float32: MFP_F32, torch.bfloat16: MFP_BF16}
 
@@ -156,7 +156,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
 def wgrad_splitk(T: int, M: int, N: int) -> int:
     """Split the token contraction so that ~2 workgroups per CU are in flight."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    sk = max(1, min(64, 512 // max(tiles, 1)))
+    sk = max(1, min(32, 288 // max(tiles, 1)))
     while sk > 1 and T // sk < 256:
         sk //= 2
     return sk
@@ -333,6 +333,28 @@ def colsum(X: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int]
     check(lib.mfp_colsum(_ptr(X), _ptr(out), ws.data_ptr(), ws.numel(), M, N, ld or N, dt_code(X.dtype),
                          _stream()), "mfp_colsum")
     return out
+
+
+def mask_tokens(cols: Sequence[dict], idx_all: torch.Tensor, nvalid: torch.Tensor, tasks: torch.Tensor,
+                B: int, S: int, seed: int, offset: int, step_ptr: Optional[torch.Tensor], x_dtype: torch.dtype):
+    """Fused preprocess_for_train (see mfp_mask_tokens).  cols: dicts with is_numerical, n_feat,
+    input_dim, group, src, cond_idx, cond_stride, cond_bits, idx_col, x_out, rowcode, mask_out."""
+    lib = load()
+    arr = (MaskCol * len(cols))()
+    nbytes = 0
+    for i, c in enumerate(cols):
+        a = arr[i]
+        a.is_numerical, a.n_feat, a.input_dim, a.group = int(c["is_numerical"]), c["n_feat"], c.get("input_dim", 0), c["group"]
+        a.src, a.cond_idx = _ptr(c["src"]), _ptr(c.get("cond_idx"))
+        a.cond_stride, a.cond_bits = c.get("cond_stride", 1), c.get("cond_bits", 0xFFFFFFFF)
+        a.idx_col = c["idx_col"]
+        a.x_out, a.rowcode, a.mask_out = _ptr(c.get("x_out")), _ptr(c.get("rowcode")), _ptr(c["mask_out"])
+        if c["is_numerical"]:
+            nbytes += B * S * c["n_feat"] * (4 + c["x_out"].element_size())
+    with _timed("mask_kernel", 0, nbytes + idx_all.numel() * 8):
+        check(lib.mfp_mask_tokens(arr, len(cols), _ptr(idx_all), idx_all.shape[1], _ptr(nvalid), _ptr(tasks), B, S,
+                                  int(seed), int(offset), _ptr(step_ptr), dt_code(x_dtype), _stream()),
+              "mfp_mask_tokens")
 
 
 def tr_probe(byte_addr: torch.Tensor) -> torch.Tensor:

@@ -20,6 +20,7 @@ from mfp.models.architecture.mask import get_seq_mask
 from mfp.models.masking import (apply_token, elem_masking, feat_masking, filter_padding,
                                 get_task_names, random_masking)
 from mfp.models.metrics import LossLayer, build_loss_keys, loss_key_names, metrics_from_sums
+from mfp.models.fast_masking import FusedMasker
 from mfp.models.model import Model
 from mfp.models.tensor_utils import shuffle_inputs, sort_inputs
 from mfp.optim import AdamKeras
@@ -191,6 +192,8 @@ class MFP:
         self._active_tasks = [i for i, p in enumerate(self.task_probs) if p > 0.0]
         self._task_probs_dev = torch.tensor(self.task_probs, dtype=torch.float32, device=self.model.store.device)
         self.sort_pos = get_dataset_name(input_columns.keys()) == "rico"
+        self.fast_masking = True   # fused HIP masking in train_step (same semantics, Philox stream)
+        self._masker = FusedMasker(self.input_columns, self.model.layout, self.model.store, kwargs.get("seed", 0))
         self.optimizer: Optional[AdamKeras] = None
         self.stop_training = False
         self._graph = None
@@ -250,11 +253,17 @@ class MFP:
         tasks = self.sample_tasks(B)
         if self.sort_pos and self.task_names.index("pos") in self._active_tasks:
             raise NotImplementedError("RICO position-sorted training loss is a 'next' row (SURVEY.md §8f-4)")
-        targets, modified_inputs, masks = preprocess_for_train(
-            batch, self.input_columns, tasks, is_autoreg=self.is_autoreg, input_dtype=self.input_dtype,
-            active_tasks=self._active_tasks)
-        keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, targets, masks)
-        loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True)
+        if self.fast_masking and self.input_dtype == "set":
+            ctx = self.model.make_ctx(batch, True)
+            idx_all, codes, xs, masks = self._masker(batch, tasks, ctx.nvalid, ctx.B, ctx.S, self.model.step_ptr)
+            keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, batch, masks)
+            loss, sums, _ = self.model.forward_loss(None, keys, training=True, premasked=(idx_all, codes, xs), ctx=ctx)
+        else:
+            targets, modified_inputs, masks = preprocess_for_train(
+                batch, self.input_columns, tasks, is_autoreg=self.is_autoreg, input_dtype=self.input_dtype,
+                active_tasks=self._active_tasks)
+            keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, targets, masks)
+            loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True)
         loss.backward()
         return sums
 

@@ -9,7 +9,7 @@ from typing import Dict, Optional, Union
 
 import torch
 
-from mfp.hip.functions import DecoderLossFn, StepCtx
+from mfp.hip.functions import DecoderLossFn, EncoderPreFn, StepCtx
 from mfp.models.architecture.decoder import Decoder, split_logits
 from mfp.models.architecture.encoder import Encoder
 from mfp.models.architecture.transformer import Blocks
@@ -62,9 +62,14 @@ class Model:
         h, ctx = self.hidden(inputs, training)
         return self.decoder(h, ctx)
 
-    def forward_loss(self, inputs: Dict, loss_keys, training: bool = True):
-        """Train-step path: heads + LossLayer fused.  Returns (loss_total, sums, outputs)."""
-        h, ctx = self.hidden(inputs, training)
+    def forward_loss(self, inputs: Dict, loss_keys, training: bool = True, premasked=None, ctx=None):
+        """Train-step path: heads + LossLayer fused.  Returns (loss_total, sums, outputs).
+        ``premasked`` = (idx_all, codes, xs) from the fused masking kernel replaces ``inputs``."""
+        if premasked is not None:
+            h = EncoderPreFn.apply(self.store.anchor, ctx, *premasked).view(ctx.B, ctx.S, self.layout.D)
+            h = self.blocks(h, None, ctx)
+        else:
+            h, ctx = self.hidden(inputs, training)
         B, S, D = h.shape
         loss, sums, logits = DecoderLossFn.apply(h.reshape(B * S, D), ctx, loss_keys)
         outputs = split_logits(logits, self.layout, self.input_columns, B, S)

@@ -196,6 +196,36 @@ int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* workspace, s
 int mfp_colsum(const void* X, float* colsum, void* workspace, size_t workspace_bytes, int32_t M,
                int32_t N, int32_t ld, int32_t dtype, mfp_stream_t stream);
 
+/* ------------------------------------------------------------------------ input masking
+ * preprocess_for_train fused (mfp.py:95-138; masking.py:24-53,68-155,227-269): per element and
+ * attribute decide keep / <MASK> / <UNUSED> / random token from the document's task id
+ * (0 random, 1 elem, 2+g attribute group g) and write the encoder's inputs directly:
+ *   categorical: idx_all[t][idx_col + f] = modified index (C = <MASK>, C+1 = <UNUSED>)
+ *   numerical  : x_out[t][0..W) (cdt) = row / 10.0 / 0.0 / N(0,0.1); rowcode[t] in {0,1,2};
+ *                idx_all[t][idx_col] = 0 (<MASK>) / 1 (<UNUSED>) / -1
+ *   mask_out[t] = MFP mask bit of the attribute (LossLayer weight).
+ * Philox offset = offset + *step_ptr * MFP_RNG_STEP_STRIDE (step_ptr may be NULL).
+ */
+typedef struct mfp_mask_col {
+  int32_t is_numerical;
+  int32_t n_feat;          /* categorical: N; numerical: width W (W % 4 == 0) */
+  int32_t input_dim;       /* categorical C */
+  int32_t group;           /* attribute-group id (task = group + 2) */
+  const void* src;         /* int32 [T][N] or f32 [T][W] (unmasked batch column) */
+  const int32_t* cond_idx; /* loss_condition key values [T*cond_stride] or NULL */
+  int32_t cond_stride;
+  uint32_t cond_bits;
+  int32_t idx_col;         /* first column of this attribute in idx_all */
+  int32_t _pad;
+  void* x_out;             /* numerical only */
+  uint8_t* rowcode;        /* numerical only */
+  uint8_t* mask_out;       /* [T] */
+} mfp_mask_col;
+#define MFP_MAX_MASK_COLS 16
+int mfp_mask_tokens(const mfp_mask_col* cols /*host*/, int32_t ncols, int32_t* idx_all, int32_t NCOL,
+                    const int32_t* nvalid, const int32_t* tasks, int32_t B, int32_t S, uint64_t seed,
+                    uint64_t offset, const int32_t* step_ptr, int32_t x_dtype, mfp_stream_t stream);
+
 /* Hardware probe (tests only): lane mapping of ds_read_b64_tr_b16.  byte_addr int32 [64]
  * (8-byte aligned offsets into a 4 KiB LDS image whose b16 element e holds e); out u16 [64][4]. */
 int mfp_debug_tr_probe(const int32_t* byte_addr, uint16_t* out, mfp_stream_t stream);
