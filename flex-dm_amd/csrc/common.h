@@ -71,9 +71,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ----------------------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG for dropout: the keep mask of element (row, col) of an [M,N] activation is
-// philox(key = seed, ctr = (col, row>>2, offset_lo, offset_hi))[row & 3] so that the MFMA
-// C-fragment (4 consecutive rows of one column per lane) needs one call, and the backward
-// kernel regenerates the identical mask from (seed, offset).
+// philox(key = seed, ctr = (row, col>>2, offset_lo, offset_hi))[col & 3] so that the GEMM epilogue
+// (4 consecutive columns of one row per lane and quad) needs one call per 16-byte store, and the
+// backward kernel regenerates the identical mask from (seed, offset).
 __device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
   const unsigned int M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
   unsigned int hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];

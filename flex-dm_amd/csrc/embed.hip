@@ -29,49 +29,52 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ 
   }
 }
 
-// Backward: dtables[rowoff[c] + idx[t][c]] += dout[t].  Workgroup = (token chunk, 32-wide d
-// slice); the slice of ALL tables lives in LDS (ROWS*32*4 B, ~44 KB for Crello -> 3 WG/CU) and is
-// accumulated with native ds_add_f32 (a half-wave owns a token: lanes hit distinct addresses,
-// half-waves may collide).  The NCOL indices of a token are fetched with ONE vector load and
-// broadcast by shuffle.  Partials [chunk][ROWS][D] are summed by reduce_rows_kernel: no global
-// atomics.
-constexpr int EB_DSLICE = 32;
+// Backward: dtables[rowoff[c] + idx[t][c]] += dout[t].  Workgroup = (token chunk, 16-wide d
+// slice); the slice of ALL tables lives in LDS and is accumulated with 64-bit FIXED-POINT integer
+// atomics: on gfx950 ds_add_f32 costs ~195 cycles per wave-op against ~19 for ds_add_u64
+// (tools/ubench/lds_atomics.hip), and integer adds make the sum order-independent (deterministic).
+// Scale 2^34: resolution 5.8e-11, range +-5.4e8 per (chunk, row, d) -- a chunk is <= 512 tokens.
+// A 16-lane group owns a token (4 tokens per wave instruction); the NCOL <= 16 indices of a token
+// come from ONE vector load and are broadcast by shuffle.  Partials [chunk][ROWS][D] (float) are
+// summed by reduce_rows_kernel: no global atomics.
+constexpr int EB_DSLICE = 16;
+constexpr float EB_SCALE = 17179869184.0f;          // 2^34
+constexpr float EB_INV_SCALE = 1.0f / 17179869184.0f;
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ idx,
                                                         const int* __restrict__ rowoff,
                                                         const float* __restrict__ dout,
                                                         float* __restrict__ part, int T, int NCOL,
                                                         int ROWS, int D, int tok_per_chunk) {
-  extern __shared__ __attribute__((aligned(16))) float tab[];  // [ROWS][32]
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];  // [ROWS][16]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l32 = lane & 31, half = lane >> 5;
+  const int l16 = lane & 15, grp = lane >> 4;
   const int chunk = blockIdx.x, d0 = blockIdx.y * EB_DSLICE;
-  for (int i = threadIdx.x; i < ROWS * EB_DSLICE; i += 256) tab[i] = 0.f;
+  for (int i = threadIdx.x; i < ROWS * EB_DSLICE; i += 256) tab[i] = 0ull;
   __syncthreads();
-  const int myoff = l32 < NCOL ? rowoff[l32] : 0;
+  const int myoff = l16 < NCOL ? rowoff[l16] : 0;
   const int t0 = chunk * tok_per_chunk, t1 = min(T, t0 + tok_per_chunk);
-  for (int tb = t0 + wave * 2; tb < t1; tb += 8) {
-    const int t = tb + half;
-    const bool ok = t < t1;
-    float g = 0.f;
+  for (int tb = t0 + wave * 4; tb < t1; tb += 16) {
+    const int t = tb + grp;
+    long long q = 0;
     int myrow = -1;
-    if (ok) {
-      g = dout[(long long)t * D + d0 + l32];
-      if (l32 < NCOL) {
-        const int r = idx[(long long)t * NCOL + l32];
+    if (t < t1) {
+      q = (long long)(dout[(long long)t * D + d0 + l16] * EB_SCALE);
+      if (l16 < NCOL) {
+        const int r = idx[(long long)t * NCOL + l16];
         myrow = r < 0 ? -1 : myoff + r;
       }
     }
     for (int j = 0; j < NCOL; ++j) {
-      const int row = __shfl(myrow, half * 32 + j, 64);
-      if (row >= 0) atomicAdd(&tab[row * EB_DSLICE + l32], g);
+      const int row = __shfl(myrow, grp * 16 + j, 64);
+      if (row >= 0) atomicAdd(&tab[row * EB_DSLICE + l16], (unsigned long long)q);
     }
   }
   __syncthreads();
   float* pout = part + (long long)chunk * ROWS * D;
   for (int i = threadIdx.x; i < ROWS * EB_DSLICE; i += 256) {
     int r = i / EB_DSLICE, c = i % EB_DSLICE;
-    pout[(long long)r * D + d0 + c] = tab[i];
+    pout[(long long)r * D + d0 + c] = (float)(long long)tab[i] * EB_INV_SCALE;
   }
 }
 
@@ -130,8 +133,8 @@ extern "C" int mfp_embed_pool_bwd(const int32_t* idx, const int32_t* rowoff, con
                                   float* dtables, void* workspace, size_t workspace_bytes, int32_t T,
                                   int32_t NCOL, int32_t ROWS, int32_t D, mfp_stream_t stream) {
   MFP_CHECK_ARG(idx && rowoff && dout && dtables);
-  MFP_CHECK_ARG(T > 0 && NCOL > 0 && NCOL <= 32 && ROWS > 0 && D > 0 && D % EB_DSLICE == 0);
-  const size_t lds = (size_t)ROWS * EB_DSLICE * sizeof(float);
+  MFP_CHECK_ARG(T > 0 && NCOL > 0 && NCOL <= 16 && ROWS > 0 && D > 0 && D % EB_DSLICE == 0);
+  const size_t lds = (size_t)ROWS * EB_DSLICE * sizeof(unsigned long long);
   MFP_CHECK_ARG(lds <= 160 * 1024);
   if (!workspace || workspace_bytes < mfp_embed_pool_bwd_workspace_bytes(T, NCOL, ROWS, D)) {
     mfp_set_error("mfp_embed_pool_bwd: workspace too small");

@@ -1,17 +1,23 @@
 // MFMA tile GEMM for the MFP hot path (gfx950).  One kernel template, three operand layouts:
-//   forward Dense   C = A[M][K] * W[K][N]        (A k-major, B n-major)
-//   dgrad           C = dY[M][K] * W[N][K]^T     (A k-major, B k-major)
-//   wgrad           C = X[K][M]^T * dY[K][N]     (A m-major, B n-major, split-K over tokens)
+//   forward Dense   C = X[M][K] * Wt[N][K]^T     (A k-major, B k-major; Wt = kernel stored [out][in])
+//   dgrad           C = dY[M][K] * Wt[K][N]      (A k-major, B n-major)
+//   wgrad           C = dY[K][M]^T * X[K][N]     (A m-major, B n-major, split-K over tokens)
 // bf16 operands use v_mfma_f32_16x16x32_bf16; f32 operands use the exact-f32
-// v_mfma_f32_16x16x4_f32 (parity path).  Operands that are not k-contiguous in memory are
-// staged untransposed and read with ds_read_b64_tr_b16 (bf16) / a strided scalar read (f32),
-// so no transposed weight copies exist anywhere.
+// v_mfma_f32_16x16x4_f32 (parity path).  Operands that are not k-contiguous in memory are staged
+// untransposed and read with ds_read_b64_tr_b16 (bf16) / a strided scalar read (f32).
 //
-// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles).
-// Fragment conventions (lane l: i = l&15, g = l>>4):
-//   A frag: row i of the 16-row tile, k = 8g..8g+7 (bf16) / k = g (f32)
-//   B frag: col i of the 16-col tile, same k
-//   C frag: col i, rows 4g..4g+3
+// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles),
+// BK = 64 (bf16) / 16 (f32), LDS double-buffered, ONE barrier per k-tile; the next tile's global
+// loads are in flight in registers while the current tile is multiplied.
+//
+// The MFMA is issued TRANSPOSED (D^T = B^T A^T: the weight side is the MFMA "A" operand) and the
+// weight rows are assigned to MFMA rows by the permutation n(b, 4q+e) = 16q + 4b + e.  Result:
+// lane (i = l&15, g = l>>4) owns, for each of its 4 m-tiles a, the row m = 16a + i and the 16
+// CONTIGUOUS columns n = 16g .. 16g+15 (tile b supplies columns 16g+4b .. 16g+4b+3).  The whole
+// epilogue (bias, ReLU, ReLU-mask, dropout, residual, accumulate, store) is therefore 16-byte
+// vector traffic.  For the k-major weight tile the permutation is applied when the tile is
+// written to LDS (row n -> LDS row 16b + 4q + e), so fragment reads stay conflict-free rows; for
+// the n-major tile the four lanes of a tr-read row supply the four column bases 16q + 4b.
 #include "common.h"
 
 namespace {
@@ -39,7 +45,6 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
-// 16-byte global load of a chunk or zeros
 template <typename T>
 __device__ __forceinline__ u32x4 load_chunk(const T* base, long long off, bool ok) {
   u32x4 z = {0u, 0u, 0u, 0u};
@@ -47,19 +52,36 @@ __device__ __forceinline__ u32x4 load_chunk(const T* base, long long off, bool o
   return *reinterpret_cast<const u32x4*>(base + off);
 }
 
+// weight-row permutation inside a 64-row wave block: local n = 16q + 4b + e  ->  LDS row 16b + 4q + e
+__device__ __forceinline__ int perm_row(int n_local) {
+  const int blk = n_local & ~63, r = n_local & 63;
+  return blk + ((r >> 2) & 3) * 16 + (r >> 4) * 4 + (r & 3);
+}
+
+template <typename T, bool A_KMAJOR, bool B_KMAJOR>
+struct GemmLds {
+  using Cfg = GemmCfg<T>;
+  static constexpr int BK = Cfg::BK, PAD = Cfg::PAD;
+  static constexpr int A_ROWS = A_KMAJOR ? BM : BK, A_COLS = A_KMAJOR ? BK : BM, LDA_S = A_COLS + PAD;
+  static constexpr int B_ROWS = B_KMAJOR ? BN : BK, B_COLS = B_KMAJOR ? BK : BN, LDB_S = B_COLS + PAD;
+  static constexpr int A_ELEMS = A_ROWS * LDA_S, B_ELEMS = B_ROWS * LDB_S;
+  static constexpr size_t BYTES = (size_t)2 * (A_ELEMS + B_ELEMS) * sizeof(T) + BM * sizeof(float);
+};
+
 template <typename T, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   using Cfg = GemmCfg<T>;
-  constexpr int BK = Cfg::BK, EPC = Cfg::EPC, PAD = Cfg::PAD;
+  using L = GemmLds<T, A_KMAJOR, B_KMAJOR>;
+  constexpr int BK = Cfg::BK, EPC = Cfg::EPC;
   constexpr bool IS_BF16 = sizeof(T) == 2;
-  // LDS tiles keep the operand's memory orientation.
-  constexpr int A_ROWS = A_KMAJOR ? BM : BK, A_COLS = A_KMAJOR ? BK : BM, LDA_S = A_COLS + PAD;
-  constexpr int B_ROWS = B_KMAJOR ? BN : BK, B_COLS = B_KMAJOR ? BK : BN, LDB_S = B_COLS + PAD;
+  constexpr int A_ROWS = L::A_ROWS, A_COLS = L::A_COLS, LDA_S = L::LDA_S;
+  constexpr int B_ROWS = L::B_ROWS, B_COLS = L::B_COLS, LDB_S = L::LDB_S;
   constexpr int A_CPR = A_COLS / EPC, B_CPR = B_COLS / EPC;  // chunks per row
   constexpr int A_CH = A_ROWS * A_CPR / NT, B_CH = B_ROWS * B_CPR / NT;
-  __shared__ __attribute__((aligned(16))) T As[A_ROWS * LDA_S];
-  __shared__ __attribute__((aligned(16))) T Bs[B_ROWS * LDB_S];
-  __shared__ float colsum_s[BM];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* As0 = reinterpret_cast<T*>(smem_raw);
+  T* Bs0 = As0 + 2 * L::A_ELEMS;
+  float* colsum_s = reinterpret_cast<float*>(Bs0 + 2 * L::B_ELEMS);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -81,7 +103,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
   const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B);
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][4];  // [m-tile a][n-quad b]
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -121,7 +143,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
       }
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    T* As = As0 + buf * L::A_ELEMS;
+    T* Bs = Bs0 + buf * L::B_ELEMS;
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
       int ch = tid + c * NT, row = ch / A_CPR, col = (ch % A_CPR) * EPC;
@@ -144,67 +168,74 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
       int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
+      if (B_KMAJOR) row = perm_row(row);
       *reinterpret_cast<u32x4*>(&Bs[row * LDB_S + col]) = rb[c];
+    }
+  };
+  auto compute = [&](int buf) {
+    const T* As = As0 + buf * L::A_ELEMS;
+    const T* Bs = Bs0 + buf * L::B_ELEMS;
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 xf[4], wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (A_KMAJOR) {
+            xf[t] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + t * 16 + li) * LDA_S + ks * 32 + lg * 8]);
+          } else {
+            const T* ptr = &As[(ks * 32 + lg * 8 + (li >> 2)) * LDA_S + wm * 64 + t * 16 + (li & 3) * 4];
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDA_S));
+            xf[t] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+          if (B_KMAJOR) {  // rows already permuted at staging: MFMA row li of quad t = LDS row 16t + li
+            wf[t] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 64 + t * 16 + li) * LDB_S + ks * 32 + lg * 8]);
+          } else {         // tr-read: the 4 lanes of a k-row supply column bases 16q + 4t
+            const T* ptr = &Bs[(ks * 32 + lg * 8 + (li >> 2)) * LDB_S + wn * 64 + (li & 3) * 16 + t * 4];
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDB_S));
+            wf[t] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float xf[4], wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          xf[t] = A_KMAJOR ? As[(wm * 64 + t * 16 + li) * LDA_S + ks * 4 + lg]
+                           : As[(ks * 4 + lg) * LDA_S + wm * 64 + t * 16 + li];
+          wf[t] = B_KMAJOR ? Bs[(wn * 64 + t * 16 + li) * LDB_S + ks * 4 + lg]
+                           : Bs[(ks * 4 + lg) * LDB_S + wn * 64 + (li >> 2) * 16 + t * 4 + (li & 3)];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b], xf[a], acc[a][b], 0, 0, 0);
+      }
     }
   };
 
   if (kbeg < kend) {
     gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      __syncthreads();  // previous tile fully consumed
-      lstore();
+      const bool more = k0 + BK < kend;
+      if (more) gload(k0 + BK);   // next tile: global -> registers, in flight during the MFMAs
+      compute(buf);
+      if (more) lstore(buf ^ 1);  // the other buffer was last read one barrier ago
       __syncthreads();
-      if (k0 + BK < kend) gload(k0 + BK);  // prefetch next tile into registers
-
-      if constexpr (IS_BF16) {
-#pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-          bf16x8 af[4], bfr[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if (A_KMAJOR) {
-              af[t] = *reinterpret_cast<const bf16x8*>(
-                  &As[(wm * 64 + t * 16 + li) * LDA_S + ks * 32 + lg * 8]);
-            } else {
-              const T* ptr = &As[(ks * 32 + lg * 8 + (li >> 2)) * LDA_S + wm * 64 + t * 16 + (li & 3) * 4];
-              bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
-              bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDA_S));
-              af[t] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-            if (B_KMAJOR) {
-              bfr[t] = *reinterpret_cast<const bf16x8*>(
-                  &Bs[(wn * 64 + t * 16 + li) * LDB_S + ks * 32 + lg * 8]);
-            } else {
-              const T* ptr = &Bs[(ks * 32 + lg * 8 + (li >> 2)) * LDB_S + wn * 64 + t * 16 + (li & 3) * 4];
-              bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
-              bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDB_S));
-              bfr[t] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-          }
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-          float af[4], bfr[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            af[t] = A_KMAJOR ? As[(wm * 64 + t * 16 + li) * LDA_S + ks * 4 + lg]
-                             : As[(ks * 4 + lg) * LDA_S + wm * 64 + t * 16 + li];
-            bfr[t] = B_KMAJOR ? Bs[(wn * 64 + t * 16 + li) * LDB_S + ks * 4 + lg]
-                              : Bs[(ks * 4 + lg) * LDB_S + wn * 64 + t * 16 + li];
-          }
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
-        }
-      }
+      buf ^= 1;
     }
   }
 
@@ -212,7 +243,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   if (!A_KMAJOR && do_colsum) {
     if (tid < BM) colsum_s[tid] = 0.f;
     __syncthreads();
-    // every thread owns EPC columns starting at (tid % A_CPR) * EPC (same for all its chunks)
     int col = (tid % A_CPR) * EPC;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) atomicAdd(&colsum_s[col + e], csum[e]);
@@ -220,60 +250,94 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     if (tid < BM && m0 + tid < p.M) p.ws_col[(long long)kz * p.M + m0 + tid] = colsum_s[tid];
   }
 
-  // ---- epilogue
+  // ---- epilogue: lane owns rows m = .. + 16a + li and columns nb .. nb+15 (quad b = 4 columns)
   const int flags = p.flags;
+  const int nb = n0 + wn * 64 + lg * 16;
   if (p.ws != nullptr) {  // split-K / wgrad path: raw partials, reduced by splitk_reduce_kernel
     float* ws = p.ws + (long long)kz * p.M * p.N;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      const int row = m0 + wm * 64 + a * 16 + li;
+      if (row >= p.M) continue;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        int col = n0 + wn * 64 + b * 16 + li;
-        int row = m0 + wm * 64 + a * 16 + lg * 4;
-        if (col < p.N) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row + r < p.M) ws[(long long)(row + r) * p.N + col] = acc[a][b][r];
-        }
+        const int col = nb + b * 4;
+        if (col < p.N) *reinterpret_cast<f32x4*>(ws + (long long)row * p.N + col) = acc[a][b];
       }
+    }
     return;
   }
 
   const float inv_keep = (flags & MFP_GEMM_DROPOUT) ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
   const unsigned long long rng_off = p.offset + (p.step_ptr ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  f32x4 bias4[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int b = 0; b < 4; ++b) {
+    const int col = nb + b * 4;
+    bias4[b] = ((flags & MFP_GEMM_BIAS) && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col)
+                                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = m0 + wm * 64 + a * 16 + li;
+    if (row >= p.M) continue;
+    const bool skip = (flags & MFP_GEMM_ROWSKIP) && p.rowcode[row] != 0;
+    f32x4 v[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      int col = n0 + wn * 64 + b * 16 + li;
-      int row = m0 + wm * 64 + a * 16 + lg * 4;
-      if (col >= p.N || row >= p.M) continue;
-      float bias = (flags & MFP_GEMM_BIAS) ? p.bias[col] : 0.f;
-      unsigned int rnd[4] = {0u, 0u, 0u, 0u};
-      if (flags & MFP_GEMM_DROPOUT) philox4x32(p.seed, (unsigned int)col, (unsigned int)(row >> 2), rng_off, rnd);
+      const int col = nb + b * 4;
+      if (col >= p.N) { v[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
+      const long long o = (long long)row * p.ldc + col;
+      f32x4 x = acc[a][b] + bias4[b];
+      if (flags & MFP_GEMM_RELU) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (row + r >= p.M) break;
-        long long o = (long long)(row + r) * p.ldc + col;
-        float v = acc[a][b][r] + bias;
-        if (flags & MFP_GEMM_RELU) v = fmaxf(v, 0.f);
-        if (flags & MFP_GEMM_RELU_BWD) {
-          float h = p.out_bf16 ? bf16_to_f32(reinterpret_cast<const unsigned short*>(p.aux)[o])
-                               : reinterpret_cast<const float*>(p.aux)[o];
-          v = h > 0.f ? v : 0.f;
-        }
-        if ((flags & MFP_GEMM_ROWSKIP) && p.rowcode[row + r] != 0) v = 0.f;
-        if (flags & MFP_GEMM_DROPOUT) v = philox_keep(rnd[r], p.dropout_p) ? v * inv_keep : 0.f;
-        if (flags & MFP_GEMM_RESIDUAL) v += p.residual[o];
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+      }
+      if (flags & MFP_GEMM_RELU_BWD) {
         if (p.out_bf16) {
-          reinterpret_cast<unsigned short*>(p.C)[o] = f32_to_bf16(v);
+          const u32x2 h = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.aux) + o);
+          x[0] = bf16_to_f32((unsigned short)(h[0] & 0xffff)) > 0.f ? x[0] : 0.f;
+          x[1] = bf16_to_f32((unsigned short)(h[0] >> 16)) > 0.f ? x[1] : 0.f;
+          x[2] = bf16_to_f32((unsigned short)(h[1] & 0xffff)) > 0.f ? x[2] : 0.f;
+          x[3] = bf16_to_f32((unsigned short)(h[1] >> 16)) > 0.f ? x[3] : 0.f;
         } else {
-          float* c = reinterpret_cast<float*>(p.C) + o;
-          if (flags & MFP_GEMM_ACCUM) v += *c;
-          *c = v;
+          const f32x4 h = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux) + o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = h[r] > 0.f ? x[r] : 0.f;
         }
       }
+      if (skip) x = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (flags & MFP_GEMM_DROPOUT) {
+        unsigned int rnd[4];
+        philox4x32(p.seed, (unsigned int)row, (unsigned int)(col >> 2), rng_off, rnd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = philox_keep(rnd[r], p.dropout_p) ? x[r] * inv_keep : 0.f;
+      }
+      if (flags & MFP_GEMM_RESIDUAL) x += *reinterpret_cast<const f32x4*>(p.residual + o);
+      if (!p.out_bf16 && (flags & MFP_GEMM_ACCUM)) x += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + o);
+      v[b] = x;
     }
+    if (p.out_bf16) {
+      unsigned short* c = reinterpret_cast<unsigned short*>(p.C) + (long long)row * p.ldc + nb;
+#pragma unroll
+      for (int b = 0; b < 4; b += 2) {
+        if (nb + b * 4 >= p.N) continue;
+        if (nb + b * 4 + 4 < p.N) {
+          u32x4 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
+                      pack_bf16x2(v[b + 1][0], v[b + 1][1]), pack_bf16x2(v[b + 1][2], v[b + 1][3])};
+          *reinterpret_cast<u32x4*>(c + b * 4) = pk;
+        } else {
+          u32x2 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
+          *reinterpret_cast<u32x2*>(c + b * 4) = pk;
+        }
+      }
+    } else {
+      float* c = reinterpret_cast<float*>(p.C) + (long long)row * p.ldc + nb;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (nb + b * 4 < p.N) *reinterpret_cast<f32x4*>(c + b * 4) = v[b];
+    }
+  }
 }
 
 // out[m][n] (+)= sum_z ws[z][m][n];  colsum[m] = sum_z ws_col[z][m].  N % 4 == 0.
@@ -305,14 +369,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+template <typename T, bool AK, bool BK_>
+int launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = GemmLds<T, AK, BK_>::BYTES;
+  static bool attr_set = false;  // benign cache: the attribute is a per-function constant
+  if (lds > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AK, BK_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_gemm: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<T, AK, BK_>), grid, dim3(NT), lds, st, p);
+  return MFP_OK;
+}
+
 template <typename T>
 int launch_gemm(const mfp_gemm_args* a, const GemmParams& p, dim3 grid, hipStream_t st) {
   if (a->a_kmajor && !a->b_kmajor) {
-    hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(NT), 0, st, p);
+    return launch_one<T, true, false>(p, grid, st);
   } else if (a->a_kmajor && a->b_kmajor) {
-    hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(NT), 0, st, p);
+    return launch_one<T, true, true>(p, grid, st);
   } else if (!a->a_kmajor && !a->b_kmajor) {
-    hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(NT), 0, st, p);
+    return launch_one<T, false, false>(p, grid, st);
   } else {
     mfp_set_error("mfp_gemm: layout a_kmajor=0,b_kmajor=1 is not on the MFP path");
     return MFP_EINVAL;
@@ -338,7 +419,8 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   MFP_CHECK_ARG(a->in_dtype == MFP_F32 || a->in_dtype == MFP_BF16);
   MFP_CHECK_ARG(a->out_dtype == MFP_F32 || a->out_dtype == MFP_BF16);
   const int epc = a->in_dtype == MFP_BF16 ? 8 : 4;
-  MFP_CHECK_ARG(a->lda % epc == 0 && a->ldb % epc == 0);
+  MFP_CHECK_ARG(a->lda % epc == 0 && a->ldb % epc == 0 && a->ldc % 4 == 0 && a->N % 4 == 0);
+  MFP_CHECK_ARG(((uintptr_t)a->C % 16) == 0);
   MFP_CHECK_ARG(a->N % epc == 0 || a->b_kmajor);
   if (a->a_kmajor) MFP_CHECK_ARG(a->K % epc == 0); else MFP_CHECK_ARG(a->M % epc == 0);
   if (a->b_kmajor) MFP_CHECK_ARG(a->K % epc == 0);

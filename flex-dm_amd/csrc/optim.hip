@@ -90,34 +90,58 @@ __global__ void cast_kernel(const float* __restrict__ src, unsigned short* __res
     for (long long j = n & ~3ll; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
 }
 
-// thread = (column c, 4-row group): matches the MFMA C-fragment keyed Philox stream.
+// thread = (row, 4 consecutive columns): matches the Philox keying of the GEMM epilogue
+// (ctr = (row, col >> 2)).  Block = 256 threads = (N/4 column quads) x (1024/N rows per pass).
 template <typename TOUT>
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dx, TOUT* __restrict__ dy,
                                                           float* __restrict__ colsum_part, int M, int N,
                                                           float p, unsigned long long seed,
                                                           unsigned long long offset0, const int* step_ptr,
                                                           int rows_per_block) {
+  __shared__ float red[4][256];
   const unsigned long long offset = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
-  // block handles columns [blockIdx.x*256, +256) and rows [blockIdx.y*rows_per_block, ...)
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  if (c >= N) return;
+  const int nq = N >> 2;                      // column quads per row
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  float cs = 0.f;
-  for (int r = r0; r < r1; r += 4) {
-    unsigned int rnd[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    if (p > 0.f) philox4x32(seed, (unsigned int)c, (unsigned int)(r >> 2), offset, rnd);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (r + e >= r1) break;
-      const long long o = (long long)(r + e) * N + c;
-      float v = dx[o];
-      if (p > 0.f) v = philox_keep(rnd[e], p) ? v * inv_keep : 0.f;
-      cdt_traits<TOUT>::store(dy + o, v);
-      cs += v;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int qb = blockIdx.x * 256; qb < nq; qb += gridDim.x * 256) {   // usually one pass
+    // threads cover quads [qb, qb+256) of a row when nq >= 256, else several rows at once
+    const int qpr = min(nq - qb, 256);           // quads of this row slice handled per row
+    const int rows_at_once = 256 / qpr;
+    const int q = qb + threadIdx.x % qpr, rsub = threadIdx.x / qpr;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rsub < rows_at_once) {
+      for (int r = r0 + rsub; r < r1; r += rows_at_once) {
+        const long long o = (long long)r * N + q * 4;
+        float4 v = *reinterpret_cast<const float4*>(dx + o);
+        if (p > 0.f) {
+          unsigned int rnd[4];
+          philox4x32(seed, (unsigned int)r, (unsigned int)q, offset, rnd);
+          v.x = philox_keep(rnd[0], p) ? v.x * inv_keep : 0.f;
+          v.y = philox_keep(rnd[1], p) ? v.y * inv_keep : 0.f;
+          v.z = philox_keep(rnd[2], p) ? v.z * inv_keep : 0.f;
+          v.w = philox_keep(rnd[3], p) ? v.w * inv_keep : 0.f;
+        }
+        if constexpr (sizeof(TOUT) == 4) {
+          *reinterpret_cast<float4*>(dy + o) = v;
+        } else {
+          u32x2 pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+          *reinterpret_cast<u32x2*>(dy + o) = pk;
+        }
+        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+      }
     }
+    red[0][threadIdx.x] = cs.x; red[1][threadIdx.x] = cs.y; red[2][threadIdx.x] = cs.z; red[3][threadIdx.x] = cs.w;
+    __syncthreads();
+    if (threadIdx.x < qpr) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int rs = 0; rs < rows_at_once; ++rs)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += red[e][rs * qpr + threadIdx.x];
+      float* out = colsum_part + (long long)blockIdx.y * N + (qb + threadIdx.x) * 4;
+      out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; out[3] = s[3];
+    }
+    __syncthreads();
   }
-  colsum_part[(long long)blockIdx.y * N + c] = cs;
 }
 
 template <typename T>
@@ -195,8 +219,8 @@ extern "C" int mfp_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, mfp
 }
 
 static int rows_per_block_for(int M) {
-  int rpb = ((M + 1023) / 1024 + 3) & ~3;  // <= 1024 row blocks, multiple of 4 (Philox row groups)
-  if (rpb < 16) rpb = 16;
+  int rpb = (M + 1023) / 1024;  // <= 1024 row blocks
+  if (rpb < 32) rpb = 32;
   return rpb;
 }
 
@@ -209,7 +233,7 @@ extern "C" int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* w
                                size_t workspace_bytes, int32_t M, int32_t N, float p, uint64_t seed,
                                uint64_t offset, const int32_t* step_ptr, int32_t out_dtype,
                                mfp_stream_t stream) {
-  MFP_CHECK_ARG(dx && dy && colsum && M > 0 && N > 0 && p >= 0.f && p < 1.f);
+  MFP_CHECK_ARG(dx && dy && colsum && M > 0 && N > 0 && N % 4 == 0 && p >= 0.f && p < 1.f);
   MFP_CHECK_ARG(out_dtype == MFP_F32 || out_dtype == MFP_BF16);
   if (!workspace || workspace_bytes < mfp_colsum_workspace_bytes(M, N)) {
     mfp_set_error("mfp_dropout_bwd: workspace too small");
@@ -217,7 +241,7 @@ extern "C" int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* w
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int rpb = rows_per_block_for(M), nrb = (M + rpb - 1) / rpb;
-  dim3 grid((N + 255) / 256, nrb);
+  dim3 grid(1, nrb);
   float* part = reinterpret_cast<float*>(workspace);
   if (out_dtype == MFP_F32)
     hipLaunchKernelGGL(dropout_bwd_kernel<float>, grid, dim3(256), 0, st, dx, (float*)dy, part, M, N, p, seed, offset, step_ptr, rpb);
