@@ -216,9 +216,8 @@ __device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long 
   }
 }
 
-constexpr int MAX_KT = 16;  // S <= 256
-
-template <int HD>
+// MAX_KT = key tiles held in registers: 8 (S <= 128) or 16 (S <= 256)
+template <int HD, int MAX_KT>
 __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
                                                      bf16_t* __restrict__ out, float* __restrict__ lse, int S,
                                                      int H, float scale) {
@@ -527,8 +526,13 @@ int fwd_hd(const void* qkv, const int* nvalid, void* out, float* lse, int B, int
     constexpr int LDH = (HD < 32 ? 32 : HD) + 8;
     const int SP = (S + 31) & ~31;
     size_t lds = (size_t)3 * SP * LDH * sizeof(bf16_t);
-    if (int rc = set_lds(attn_fwd_bf16<HD>, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_bf16<HD>, grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);
+    if (SP <= 128) {
+      if (int rc = set_lds(attn_fwd_bf16<HD, 8>, lds)) return rc;
+      hipLaunchKernelGGL((attn_fwd_bf16<HD, 8>), grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);
+    } else {
+      if (int rc = set_lds(attn_fwd_bf16<HD, 16>, lds)) return rc;
+      hipLaunchKernelGGL((attn_fwd_bf16<HD, 16>), grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);
+    }
   }
   MFP_CHECK_LAUNCH();
   return MFP_OK;

@@ -18,6 +18,8 @@
 // vector traffic.  For the k-major weight tile the permutation is applied when the tile is
 // written to LDS (row n -> LDS row 16b + 4q + e), so fragment reads stay conflict-free rows; for
 // the n-major tile the four lanes of a tr-read row supply the four column bases 16q + 4b.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -56,6 +58,83 @@ __device__ __forceinline__ u32x4 load_chunk(const T* base, long long off, bool o
 __device__ __forceinline__ int perm_row(int n_local) {
   const int blk = n_local & ~63, r = n_local & 63;
   return blk + ((r >> 2) & 3) * 16 + (r >> 4) * 4 + (r & 3);
+}
+
+// Dense epilogue for MT m-tiles: lane (li, lg) owns rows mrow0 + 16a + li and the 16 contiguous
+// columns nb .. nb+15 (quad b = columns nb+4b .. nb+4b+3).
+template <int MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MT][4], int mrow0, int nb, int li) {
+  const int flags = p.flags;
+  const float inv_keep = (flags & MFP_GEMM_DROPOUT) ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const unsigned long long rng_off = p.offset + (p.step_ptr ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  f32x4 bias4[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int col = nb + b * 4;
+    bias4[b] = ((flags & MFP_GEMM_BIAS) && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col)
+                                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int row = mrow0 + a * 16 + li;
+    if (row >= p.M) continue;
+    const bool skip = (flags & MFP_GEMM_ROWSKIP) && p.rowcode[row] != 0;
+    f32x4 v[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = nb + b * 4;
+      if (col >= p.N) { v[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
+      const long long o = (long long)row * p.ldc + col;
+      f32x4 x = acc[a][b] + bias4[b];
+      if (flags & MFP_GEMM_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+      }
+      if (flags & MFP_GEMM_RELU_BWD) {
+        if (p.out_bf16) {
+          const u32x2 h = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.aux) + o);
+          x[0] = bf16_to_f32((unsigned short)(h[0] & 0xffff)) > 0.f ? x[0] : 0.f;
+          x[1] = bf16_to_f32((unsigned short)(h[0] >> 16)) > 0.f ? x[1] : 0.f;
+          x[2] = bf16_to_f32((unsigned short)(h[1] & 0xffff)) > 0.f ? x[2] : 0.f;
+          x[3] = bf16_to_f32((unsigned short)(h[1] >> 16)) > 0.f ? x[3] : 0.f;
+        } else {
+          const f32x4 h = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux) + o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = h[r] > 0.f ? x[r] : 0.f;
+        }
+      }
+      if (skip) x = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (flags & MFP_GEMM_DROPOUT) {
+        unsigned int rnd[4];
+        philox4x32(p.seed, (unsigned int)row, (unsigned int)(col >> 2), rng_off, rnd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = philox_keep(rnd[r], p.dropout_p) ? x[r] * inv_keep : 0.f;
+      }
+      if (flags & MFP_GEMM_RESIDUAL) x += *reinterpret_cast<const f32x4*>(p.residual + o);
+      if (!p.out_bf16 && (flags & MFP_GEMM_ACCUM)) x += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + o);
+      v[b] = x;
+    }
+    if (p.out_bf16) {
+      unsigned short* c = reinterpret_cast<unsigned short*>(p.C) + (long long)row * p.ldc + nb;
+#pragma unroll
+      for (int b = 0; b < 4; b += 2) {
+        if (nb + b * 4 >= p.N) continue;
+        if (nb + b * 4 + 4 < p.N) {
+          u32x4 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
+                      pack_bf16x2(v[b + 1][0], v[b + 1][1]), pack_bf16x2(v[b + 1][2], v[b + 1][3])};
+          *reinterpret_cast<u32x4*>(c + b * 4) = pk;
+        } else {
+          u32x2 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
+          *reinterpret_cast<u32x2*>(c + b * 4) = pk;
+        }
+      }
+    } else {
+      float* c = reinterpret_cast<float*>(p.C) + (long long)row * p.ldc + nb;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (nb + b * 4 < p.N) *reinterpret_cast<f32x4*>(c + b * 4) = v[b];
+    }
+  }
 }
 
 template <typename T, bool A_KMAJOR, bool B_KMAJOR>
@@ -251,7 +330,6 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   }
 
   // ---- epilogue: lane owns rows m = .. + 16a + li and columns nb .. nb+15 (quad b = 4 columns)
-  const int flags = p.flags;
   const int nb = n0 + wn * 64 + lg * 16;
   if (p.ws != nullptr) {  // split-K / wgrad path: raw partials, reduced by splitk_reduce_kernel
     float* ws = p.ws + (long long)kz * p.M * p.N;
@@ -268,75 +346,167 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     return;
   }
 
-  const float inv_keep = (flags & MFP_GEMM_DROPOUT) ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const unsigned long long rng_off = p.offset + (p.step_ptr ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
-  f32x4 bias4[4];
+  gemm_epilogue<4>(p, acc, m0 + wm * 64, nb, li);
+}
+
+// ------------------------------------------------------------------------------------------
+// A-panel-resident GEMM for the skinny forward / dgrad products of the MFP step: M = #elements
+// (32768), N <= 1384, K <= 512.  One workgroup per CU owns BM rows of A: the [BM][K] panel is
+// loaded ONCE with every 16-byte request in flight at the same time (at 1 WG/CU a wave may use
+// the whole 512-register budget), then the workgroup sweeps all N tiles; the weight tiles
+// ([128][64], L2-resident) are requested two steps ahead.  HBM sees A once and C once -- the
+// algorithmic bytes -- instead of A once per N tile through L2 with one tile of latency exposed
+// per k-step.  Same fragment / epilogue conventions as gemm_kernel.
+template <typename T, bool B_KMAJOR, int MT /* m-tiles per wave: BM = 32*MT */>
+__global__ __launch_bounds__(NT, 1) void gemm_apanel_kernel(GemmParams p, int kpad /*K rounded up to BK*/) {
+  using Cfg = GemmCfg<T>;
+  constexpr int BK = Cfg::BK, EPC = Cfg::EPC, PAD = Cfg::PAD;
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int BMP = 32 * MT;
+  constexpr int B_ROWS = B_KMAJOR ? BN : BK, B_COLS = B_KMAJOR ? BK : BN, LDB_S = B_COLS + PAD;
+  constexpr int B_CPR = B_COLS / EPC, B_CH = B_ROWS * B_CPR / NT, B_ELEMS = B_ROWS * LDB_S;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lda_s = kpad + PAD;
+  T* Ap = reinterpret_cast<T*>(smem_raw);
+  T* Bs0 = Ap + BMP * lda_s;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BMP;
+  const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B);
+  const int nkt = kpad / BK, nnt = (p.N + BN - 1) / BN, nsteps = nkt * nnt;
+
+  u32x4 rb0[B_CH], rb1[B_CH];
+  auto gload_b = [&](int step, u32x4 (&rb)[B_CH]) {
+    const int n0 = (step / nkt) * BN, k0 = (step % nkt) * BK;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int col = nb + b * 4;
-    bias4[b] = ((flags & MFP_GEMM_BIAS) && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col)
-                                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int row = m0 + wm * 64 + a * 16 + li;
-    if (row >= p.M) continue;
-    const bool skip = (flags & MFP_GEMM_ROWSKIP) && p.rowcode[row] != 0;
-    f32x4 v[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = nb + b * 4;
-      if (col >= p.N) { v[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
-      const long long o = (long long)row * p.ldc + col;
-      f32x4 x = acc[a][b] + bias4[b];
-      if (flags & MFP_GEMM_RELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+    for (int c = 0; c < B_CH; ++c) {
+      int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
+      if (B_KMAJOR) {
+        int n = n0 + row, k = k0 + col;
+        rb[c] = load_chunk(Bg, (long long)n * p.ldb + k, n < p.N && k < p.K);
+      } else {
+        int k = k0 + row, n = n0 + col;
+        rb[c] = load_chunk(Bg, (long long)k * p.ldb + n, k < p.K && n < p.N);
       }
-      if (flags & MFP_GEMM_RELU_BWD) {
-        if (p.out_bf16) {
-          const u32x2 h = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.aux) + o);
-          x[0] = bf16_to_f32((unsigned short)(h[0] & 0xffff)) > 0.f ? x[0] : 0.f;
-          x[1] = bf16_to_f32((unsigned short)(h[0] >> 16)) > 0.f ? x[1] : 0.f;
-          x[2] = bf16_to_f32((unsigned short)(h[1] & 0xffff)) > 0.f ? x[2] : 0.f;
-          x[3] = bf16_to_f32((unsigned short)(h[1] >> 16)) > 0.f ? x[3] : 0.f;
-        } else {
-          const f32x4 h = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.aux) + o);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = h[r] > 0.f ? x[r] : 0.f;
-        }
-      }
-      if (skip) x = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (flags & MFP_GEMM_DROPOUT) {
-        unsigned int rnd[4];
-        philox4x32(p.seed, (unsigned int)row, (unsigned int)(col >> 2), rng_off, rnd);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = philox_keep(rnd[r], p.dropout_p) ? x[r] * inv_keep : 0.f;
-      }
-      if (flags & MFP_GEMM_RESIDUAL) x += *reinterpret_cast<const f32x4*>(p.residual + o);
-      if (!p.out_bf16 && (flags & MFP_GEMM_ACCUM)) x += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + o);
-      v[b] = x;
     }
-    if (p.out_bf16) {
-      unsigned short* c = reinterpret_cast<unsigned short*>(p.C) + (long long)row * p.ldc + nb;
+  };
+  auto lstore_b = [&](int buf, u32x4 (&rb)[B_CH]) {
+    T* Bs = Bs0 + buf * B_ELEMS;
 #pragma unroll
-      for (int b = 0; b < 4; b += 2) {
-        if (nb + b * 4 >= p.N) continue;
-        if (nb + b * 4 + 4 < p.N) {
-          u32x4 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
-                      pack_bf16x2(v[b + 1][0], v[b + 1][1]), pack_bf16x2(v[b + 1][2], v[b + 1][3])};
-          *reinterpret_cast<u32x4*>(c + b * 4) = pk;
-        } else {
-          u32x2 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3])};
-          *reinterpret_cast<u32x2*>(c + b * 4) = pk;
+    for (int c = 0; c < B_CH; ++c) {
+      int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
+      if (B_KMAJOR) row = perm_row(row);
+      *reinterpret_cast<u32x4*>(&Bs[row * LDB_S + col]) = rb[c];
+    }
+  };
+
+  // ---- weight tiles 0 and 1 first (short L2 latency), then the whole A panel in one burst
+  gload_b(0, rb0);
+  if (nsteps > 1) gload_b(1, rb1);
+  {
+    const int cpr = kpad / EPC;                 // chunks per panel row
+    const int total = BMP * cpr;
+    constexpr int BURST = 16;                   // 16 x 16 B per thread in flight per burst
+    for (int base = 0; base < total; base += NT * BURST) {
+      u32x4 r[BURST];
+#pragma unroll
+      for (int j = 0; j < BURST; ++j) {
+        const int ch = base + j * NT + tid;
+        const int row = ch / cpr, col = (ch % cpr) * EPC;
+        const int m = m0 + row;
+        r[j] = load_chunk(Ag, (long long)m * p.lda + col, ch < total && m < p.M && col < p.K);
+      }
+#pragma unroll
+      for (int j = 0; j < BURST; ++j) {
+        const int ch = base + j * NT + tid;
+        if (ch < total) {
+          const int row = ch / cpr, col = (ch % cpr) * EPC;
+          *reinterpret_cast<u32x4*>(&Ap[row * lda_s + col]) = r[j];
         }
+      }
+    }
+  }
+  lstore_b(0, rb0);
+  __syncthreads();
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf, int kt) {
+    const T* Bs = Bs0 + buf * B_ELEMS;
+    const T* As = Ap + kt * BK;   // column offset inside the panel
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 xf[MT], wf[4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          xf[t] = *reinterpret_cast<const bf16x8*>(&As[(wm * 16 * MT + t * 16 + li) * lda_s + ks * 32 + lg * 8]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (B_KMAJOR) {
+            wf[t] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 64 + t * 16 + li) * LDB_S + ks * 32 + lg * 8]);
+          } else {
+            const T* ptr = &Bs[(ks * 32 + lg * 8 + (li >> 2)) * LDB_S + wn * 64 + (li & 3) * 16 + t * 4];
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDB_S));
+            wf[t] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
       }
     } else {
-      float* c = reinterpret_cast<float*>(p.C) + (long long)row * p.ldc + nb;
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if (nb + b * 4 < p.N) *reinterpret_cast<f32x4*>(c + b * 4) = v[b];
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        float xf[MT], wf[4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) xf[t] = As[(wm * 16 * MT + t * 16 + li) * lda_s + ks * 4 + lg];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          wf[t] = B_KMAJOR ? Bs[(wn * 64 + t * 16 + li) * LDB_S + ks * 4 + lg]
+                           : Bs[(ks * 4 + lg) * LDB_S + wn * 64 + (li >> 2) * 16 + t * 4 + (li & 3)];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b], xf[a], acc[a][b], 0, 0, 0);
+      }
     }
+  };
+  auto finish_tile = [&](int step) {   // after the last k-tile of an N tile: epilogue + reset
+    if ((step + 1) % nkt != 0) return;
+    const int n0 = (step / nkt) * BN;
+    gemm_epilogue<MT>(p, acc, m0 + wm * 16 * MT, n0 + wn * 64 + lg * 16, li);
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // step s: LDS buffer s&1 holds weight tile s; tile s+1 is in the other register set;
+  // tile s+2 is requested now into the set tile s came from.
+  for (int s0 = 0; s0 < nsteps; s0 += 2) {
+    if (s0 + 2 < nsteps) gload_b(s0 + 2, rb0);
+    compute(0, s0 % nkt);
+    finish_tile(s0);
+    if (s0 + 1 < nsteps) lstore_b(1, rb1);
+    __syncthreads();
+    if (s0 + 1 >= nsteps) break;
+    if (s0 + 3 < nsteps) gload_b(s0 + 3, rb1);
+    compute(1, (s0 + 1) % nkt);
+    finish_tile(s0 + 1);
+    if (s0 + 2 < nsteps) lstore_b(0, rb0);
+    __syncthreads();
   }
 }
 
@@ -386,6 +556,43 @@ int launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
   return MFP_OK;
 }
 
+bool uses_workspace_fwd(const mfp_gemm_args* a);
+
+template <typename T, bool BKM, int MT>
+int launch_apanel(const GemmParams& p, int kpad, hipStream_t st) {
+  using Cfg = GemmCfg<T>;
+  constexpr int B_ROWS = BKM ? BN : Cfg::BK, B_COLS = BKM ? Cfg::BK : BN;
+  const size_t lds = ((size_t)32 * MT * (kpad + Cfg::PAD) + (size_t)2 * B_ROWS * (B_COLS + Cfg::PAD)) * sizeof(T);
+  static size_t attr_bytes = 0;  // benign cache (largest size requested so far)
+  if (lds > 64 * 1024 && lds > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_apanel_kernel<T, BKM, MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_gemm: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_bytes = lds;
+  }
+  dim3 grid((p.M + 32 * MT - 1) / (32 * MT));
+  hipLaunchKernelGGL((gemm_apanel_kernel<T, BKM, MT>), grid, dim3(NT), lds, st, p, kpad);
+  return MFP_OK;
+}
+
+// -> MT (m-tiles per wave) of the panel kernel that fits LDS, or 0 to use the tiled kernel
+template <typename T>
+int apanel_choice(const mfp_gemm_args* a, int* kpad_out) {
+  using Cfg = GemmCfg<T>;
+  if (!a->a_kmajor || uses_workspace_fwd(a) || a->M < 2048) return 0;
+  const int kpad = ((a->K + Cfg::BK - 1) / Cfg::BK) * Cfg::BK;
+  *kpad_out = kpad;
+  const size_t b_bytes = (size_t)2 * 128 * (Cfg::BK + Cfg::PAD) * sizeof(T) + 4096;
+  for (int mt = 4; mt >= 2; mt -= 2) {
+    const size_t a_bytes = (size_t)32 * mt * (kpad + Cfg::PAD) * sizeof(T);
+    if (a_bytes + b_bytes <= 150 * 1024) return mt;
+  }
+  return 0;
+}
+
 template <typename T>
 int launch_gemm(const mfp_gemm_args* a, const GemmParams& p, dim3 grid, hipStream_t st) {
   if (a->a_kmajor && !a->b_kmajor) {
@@ -399,6 +606,10 @@ int launch_gemm(const mfp_gemm_args* a, const GemmParams& p, dim3 grid, hipStrea
     return MFP_EINVAL;
   }
   return MFP_OK;
+}
+
+bool uses_workspace_fwd(const mfp_gemm_args* a) {
+  return a->splitk > 1 || (a->flags & (MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A));
 }
 
 bool uses_workspace(const mfp_gemm_args* a) {
@@ -461,8 +672,21 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   p.kchunk = kchunk;
   dim3 grid(p.tiles_m * p.tiles_n, 1, splitk);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int rc = a->in_dtype == MFP_BF16 ? launch_gemm<unsigned short>(a, p, grid, st)
-                                    : launch_gemm<float>(a, p, grid, st);
+  int rc;
+  int kpad = 0;
+  const int mt = a->in_dtype == MFP_BF16 ? apanel_choice<unsigned short>(a, &kpad) : apanel_choice<float>(a, &kpad);
+  if (mt && getenv("MFP_NO_APANEL") == nullptr) {
+    if (a->in_dtype == MFP_BF16) {
+      if (a->b_kmajor) rc = mt == 4 ? launch_apanel<unsigned short, true, 4>(p, kpad, st) : launch_apanel<unsigned short, true, 2>(p, kpad, st);
+      else rc = mt == 4 ? launch_apanel<unsigned short, false, 4>(p, kpad, st) : launch_apanel<unsigned short, false, 2>(p, kpad, st);
+    } else {
+      if (a->b_kmajor) rc = mt == 4 ? launch_apanel<float, true, 4>(p, kpad, st) : launch_apanel<float, true, 2>(p, kpad, st);
+      else rc = mt == 4 ? launch_apanel<float, false, 4>(p, kpad, st) : launch_apanel<float, false, 2>(p, kpad, st);
+    }
+  } else {
+    rc = a->in_dtype == MFP_BF16 ? launch_gemm<unsigned short>(a, p, grid, st)
+                                  : launch_gemm<float>(a, p, grid, st);
+  }
   if (rc != MFP_OK) return rc;
   MFP_CHECK_LAUNCH();
   if (ws_path) {

@@ -126,6 +126,48 @@ def test_gemm_epilogues(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["fwd", "dgrad"])
+@pytest.mark.parametrize("M,N,K", [(2304, 264, 256), (4100, 768, 128), (2050, 136, 512), (3000, 1384, 256),
+                                   (2200, 256, 768), (2048, 128, 72)])
+def test_gemm_apanel_kernel(dtype, layout, M, N, K):
+    """M >= 2048 with A k-major and small K dispatches to the A-panel-resident kernel."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(K, N, generator=g) * 0.1
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    if dtype == torch.bfloat16:
+        A, W = bf16_round(A), bf16_round(W)
+    Bdev = (W.t().contiguous() if layout == "fwd" else W).to(DEV, dtype)
+    bk = layout == "fwd"
+    want = A.double() @ W.double()
+    tol = 2e-4 * math.sqrt(K)
+    got = ops.gemm(A.to(DEV, dtype), Bdev, M, N, K, a_kmajor=True, b_kmajor=bk, out_dtype=torch.float32)
+    assert_close(got, want, tol, 1e-5, "apanel plain")
+    code = (torch.rand(M, generator=g) < 0.2).to(torch.uint8)
+    C0 = torch.randn(M, N, generator=g)
+    out = C0.clone().to(DEV)
+    ops.gemm(A.to(DEV, dtype), Bdev, M, N, K, a_kmajor=True, b_kmajor=bk, out=out, bias=bias.to(DEV), accum=True,
+             rowskip=code.to(DEV))
+    assert_close(out, C0.double() + (want + bias.double()) * (code == 0)[:, None], tol, 1e-5, "apanel accum+rowskip")
+    got = ops.gemm(A.to(DEV, dtype), Bdev, M, N, K, a_kmajor=True, b_kmajor=bk, bias=bias.to(DEV), relu=True,
+                   residual=None, out_dtype=dtype)
+    ref = (want + bias.double()).clamp(min=0)
+    if dtype == torch.bfloat16:
+        assert_close(got, ref, 2e-2, 1e-2, "apanel relu bf16")
+    else:
+        assert_close(got, ref, tol, 1e-5, "apanel relu")
+    p, seed, off = 0.1, 99, 5
+    plain = ops.gemm(A.to(DEV, dtype), Bdev, M, N, K, a_kmajor=True, b_kmajor=bk, bias=bias.to(DEV),
+                     out_dtype=torch.float32)
+    dropped = ops.gemm(A.to(DEV, dtype), Bdev, M, N, K, a_kmajor=True, b_kmajor=bk, bias=bias.to(DEV),
+                       residual=res.to(DEV), dropout=(p, seed, off), out_dtype=torch.float32)
+    colsum = torch.empty(N, device=DEV)
+    via_bwd = ops.dropout_bwd(plain, torch.float32, colsum, p, seed, off)
+    assert_close(dropped, via_bwd.double().cpu() + res.double(), 1e-5, 1e-5, "apanel dropout+residual")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_wgrad_colsum_rowskip(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(11)
