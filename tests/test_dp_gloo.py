@@ -1,0 +1,100 @@
+"""Data-parallel path on CPU: 2 ranks over gloo (the fake fabric; RCCL on the GPU box).
+
+The DP contract (mfp/dp.py): shard the batch on axis 0, each rank's loss is a
+mean over its shard, SUM-all-reduce the flat gradient, and fold 1/N + the L2 term + per-variable
+clipnorm into the optimizer AFTER the reduction.  Result must equal the 1-rank step on the global
+batch.  Gradients come from the oracle's torch restatement (the HIP kernels need a GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _grads(ic, params, batch, masks, L, S):
+    from oracle import torch_ref
+    state = torch_ref.TrainState(params, l2=None, clipnorm=None, dtype=torch.float64)
+    info, grads = torch_ref.loss_and_grads(state, ic, batch, batch, masks, L, maxlen=S)
+    return info, grads
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "flex-dm_amd")]
+    from oracle import np_ref
+    from mfp import dp
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    assert dp.init_from_env("gloo") == world and dp.rank() == rank and dp.world_size() == world
+    ic = make_input_columns("rico")
+    B, S, D, L = 4, 6, 16, 1
+    params = np_ref.init_params(ic, D, L, seed=-7)
+    batch = synthetic_batch(ic, B, S, seed=9, ragged=True)
+    g = torch.Generator().manual_seed(3)
+    keys = [k for k, c in ic.items() if c.get("is_sequence")]
+    masks = {k: torch.rand(B, S, generator=g) < 0.6 for k in keys}
+    shard = dp.shard_batch(batch)
+    mshard = dp.shard_batch(masks)
+    assert shard["left"].shape[0] == B // world
+    info, grads = _grads(ic, params, shard, mshard, L, S)
+    names = sorted(grads)
+    flat = torch.cat([grads[n].reshape(-1) for n in names])
+    dp.allreduce_gradients(flat)                      # SUM; the optimizer applies grad_scale = 1/N
+    flat = flat / world
+    sums = torch.tensor([[float(info["losses"][k]), float(info["scores"][k + "_score_num"]),
+                          float(info["scores"][k + "_score_den"])] for k in keys], dtype=torch.float64)
+    red = dp.allreduce_sums(sums)
+    w = torch.full((5,), float(rank))
+    dp.broadcast_parameters(w, src=0)
+    if rank == 0:
+        q.put((names, flat.numpy(), red.numpy(), w.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_global_batch_step():
+    from oracle import np_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    names, flat, red, w = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ic = make_input_columns("rico")
+    B, S, D, L = 4, 6, 16, 1
+    params = np_ref.init_params(ic, D, L, seed=-7)
+    batch = synthetic_batch(ic, B, S, seed=9, ragged=True)
+    g = torch.Generator().manual_seed(3)
+    keys = [k for k, c in ic.items() if c.get("is_sequence")]
+    masks = {k: torch.rand(B, S, generator=g) < 0.6 for k in keys}
+    info, grads = _grads(ic, params, batch, masks, L, S)
+    want = np.concatenate([grads[n].reshape(-1).numpy() for n in names])
+    np.testing.assert_allclose(flat, want, rtol=1e-9, atol=1e-12)      # tolerance 1e-5 asked; f64 gives 1e-9
+    for i, k in enumerate(keys):
+        assert abs(red[i, 0] - float(info["losses"][k])) < 1e-9
+        assert abs(red[i, 1] - float(info["scores"][k + "_score_num"])) < 1e-9
+        assert abs(red[i, 2] - float(info["scores"][k + "_score_den"])) < 1e-9
+    assert (w == 0).all()
+
+
+def test_single_process_helpers_are_noops():
+    from mfp import dp
+    t = torch.ones(3)
+    assert dp.world_size() == 1 and dp.rank() == 0
+    assert dp.allreduce_gradients(t) is None and torch.equal(dp.allreduce_sums(t.view(1, 3)), t.view(1, 3))
+    assert dp.shard_batch({"a": t})["a"] is t

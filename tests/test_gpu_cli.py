@@ -1,0 +1,44 @@
+"""End-to-end plumbing on the GPU through the reference's entry points: ``python -m mfp`` (config
+c1 of BASELINE.json: RICO, masking_method=random, 2 blocks, d_model=128, seq_len=32, batch=8) and
+``eval.py`` on the job directory it wrote."""
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_cli_rico_then_eval(tmp_path, capsys):
+    from mfp.main import main
+    job = str(tmp_path / "job")
+    main(["--dataset_name", "rico", "--data_dir", "synthetic:32:32", "--job-dir", job, "--latent_dim", "128",
+          "--num_blocks", "2", "--batch_size", "8", "--num_epochs", "2", "--validation_freq", "1",
+          "--masking_method", "random", "--dtype", "fp32", "--verbose", "0"])
+    out = capsys.readouterr().out
+    assert "total_score" in out and "loss" in out                      # train.py:90-92 prints metric lines
+    args = json.load(open(os.path.join(job, "args.json")))             # train.py:30-33
+    assert args["dataset_name"] == "rico" and args["latent_dim"] == 128 and args["job_dir"] == job
+    ck = os.path.join(job, "checkpoints")
+    assert os.path.exists(os.path.join(ck, "final.ckpt.safetensors"))  # train.py:95-97
+    assert os.path.exists(os.path.join(ck, "best.ckpt.safetensors"))   # callbacks.py:49-56
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_cli", os.path.join(root, "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    res = ev.main(["--job-dir", job, "--task_mode", "attr", "--batch_size", "8"])
+    assert set(res) == {"icon", "clickable", "text_button"} and all(0.0 <= v <= 1.0 for v in res.values())
+    res = ev.main(["--job-dir", job, "--task_mode", "random", "--batch_size", "8", "--num_iter", "2"])
+    assert "left" in res
+    res = ev.main(["--job-dir", job, "--task_mode", "elem"])
+    assert "type" in res
+
+
+def test_train_cli_crello_bf16_graph(tmp_path):
+    from mfp.main import main
+    job = str(tmp_path / "job2")
+    main(["--dataset_name", "crello", "--data_dir", "synthetic:16:32", "--job-dir", job, "--latent_dim", "128",
+          "--num_blocks", "1", "--batch_size", "16", "--num_epochs", "2", "--validation_freq", "2",
+          "--masking_method", "elem_pos_attr_img_txt", "--dtype", "bf16", "--use_graph", "--verbose", "0"])
+    assert os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))

@@ -129,8 +129,8 @@ def test_gemm_epilogues(dtype):
 @pytest.mark.parametrize("layout", ["fwd", "dgrad"])
 @pytest.mark.parametrize("M,N,K", [(2304, 264, 256), (4100, 768, 128), (2050, 136, 512), (3000, 1384, 256),
                                    (2200, 256, 768), (2048, 128, 72)])
-def test_gemm_apanel_kernel(dtype, layout, M, N, K):
-    """M >= 2048 with A k-major and small K dispatches to the A-panel-resident kernel."""
+def test_gemm_large_m_epilogues(dtype, layout, M, N, K):
+    """Train-step-like skinny shapes (large M, small N/K) through every epilogue flag."""
     ops = _ops()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
