@@ -38,13 +38,17 @@ void mfp_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {  // round-to-nearest-even
-  unsigned int u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+// f32 -> bf16, round-to-nearest-even, through the native __bf16 type: on gfx950 this is ONE
+// v_cvt_pk_bf16_f32 per pair (a software round costs ~5 VALU per value; the GEMM epilogues were
+// VALU-bound on it).
+typedef __attribute__((ext_vector_type(2))) __bf16 mfp_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float mfp_f32x2_t;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  const mfp_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, mfp_bf16x2_t));
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 
 template <typename T> struct cdt_traits;

@@ -49,14 +49,10 @@ struct GemmParams {
   unsigned long long seed, offset;
   const int* step_ptr;
   int tiles_m, tiles_n;
+#ifdef MFP_GEMM_TRACE
+  unsigned long long* trace;  // [workgroup][16] s_memtime stamps of wave 0
+#endif
 };
-
-template <typename T>
-__device__ __forceinline__ u32x4 load_chunk(const T* base, long long off, bool ok) {
-  u32x4 z = {0u, 0u, 0u, 0u};
-  if (!ok) return z;
-  return *reinterpret_cast<const u32x4*>(base + off);
-}
 
 // weight-row permutation inside a (16 NQ)-row wave block: local n = 4NQ q + 4b + e -> LDS row 16b + 4q + e
 template <int NQ>
@@ -174,6 +170,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef MFP_GEMM_TRACE
+  int trace_i = 0;
+#define TRACE_STAMP() do { if (tid == 0 && trace_i < 16) p.trace[(long long)(blockIdx.x + gridDim.x * blockIdx.z) * 16 + trace_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TRACE_STAMP() do {} while (0)
+#endif
+  TRACE_STAMP();  // 0: start
 
   // XCD-aware bijective remap: consecutive logical tiles stay on one XCD (shared A panel in L2)
   int nwg = p.tiles_m * p.tiles_n;
@@ -203,32 +206,57 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 #pragma unroll
   for (int e = 0; e < EPC; ++e) csum[e] = 0.f;
 
+  // Per-chunk state computed ONCE: global pointer (advanced by a constant per k-tile), row
+  // predicate, k column (for the K tail) and LDS offset (weight-row permutation folded in).  The
+  // k-loop then issues loads with one 64-bit add per chunk instead of re-deriving addresses.
   u32x4 ra[A_CH], rb[B_CH];
+  const T* pa[A_CH];
+  const T* pb[B_CH];
+  bool oka[A_CH], okb[B_CH];
+  int kca[A_CH], kcb[B_CH];     // k offset of the chunk inside a tile (row for k-strided tiles)
+  int lsa[A_CH], lsb[B_CH];     // LDS element offsets
+#pragma unroll
+  for (int c = 0; c < A_CH; ++c) {
+    const int ch = tid + c * NT, row = ch / A_CPR, col = (ch % A_CPR) * EPC;
+    lsa[c] = row * LDA_S + col;
+    if (A_KMAJOR) {
+      oka[c] = m0 + row < p.M; kca[c] = col;
+      pa[c] = Ag + (long long)(m0 + row) * p.lda + kbeg + col;
+    } else {
+      oka[c] = m0 + col < p.M; kca[c] = row;
+      pa[c] = Ag + (long long)(kbeg + row) * p.lda + m0 + col;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < B_CH; ++c) {
+    const int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
+    if (B_KMAJOR) {
+      okb[c] = n0 + row < p.N; kcb[c] = col;
+      pb[c] = Bg + (long long)(n0 + row) * p.ldb + kbeg + col;
+      lsb[c] = perm_row<NQ>(row) * LDB_S + col;
+    } else {
+      okb[c] = n0 + col < p.N; kcb[c] = row;
+      pb[c] = Bg + (long long)(kbeg + row) * p.ldb + n0 + col;
+      lsb[c] = row * LDB_S + col;
+    }
+  }
+  const long long stepa = A_KMAJOR ? (long long)BK : (long long)BK * p.lda;
+  const long long stepb = B_KMAJOR ? (long long)BK : (long long)BK * p.ldb;
 
   auto gload = [&](int k0) {
+    const bool full = k0 + BK <= kend;   // uniform: only the last tile of a ragged K checks columns
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
-      int ch = tid + c * NT, row = ch / A_CPR, col = (ch % A_CPR) * EPC;
-      if (A_KMAJOR) {
-        int m = m0 + row, k = k0 + col;
-        ra[c] = load_chunk(Ag, (long long)m * p.lda + k, m < p.M && k < kend);
-      } else {
-        int k = k0 + row, m = m0 + col;
-        bool ok = k < kend && m < p.M;
-        if (rowskip_a && ok) ok = p.rowcode[k] == 0;
-        ra[c] = load_chunk(Ag, (long long)k * p.lda + m, ok);
-      }
+      bool ok = oka[c] && (full || k0 + kca[c] < kend);
+      if (!A_KMAJOR && rowskip_a && ok) ok = p.rowcode[k0 + kca[c]] == 0;
+      ra[c] = ok ? *reinterpret_cast<const u32x4*>(pa[c]) : (u32x4){0u, 0u, 0u, 0u};
+      pa[c] += stepa;
     }
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
-      int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
-      if (B_KMAJOR) {
-        int n = n0 + row, k = k0 + col;
-        rb[c] = load_chunk(Bg, (long long)n * p.ldb + k, n < p.N && k < kend);
-      } else {
-        int k = k0 + row, n = n0 + col;
-        rb[c] = load_chunk(Bg, (long long)k * p.ldb + n, k < kend && n < p.N);
-      }
+      const bool ok = okb[c] && (full || k0 + kcb[c] < kend);
+      rb[c] = ok ? *reinterpret_cast<const u32x4*>(pb[c]) : (u32x4){0u, 0u, 0u, 0u};
+      pb[c] += stepb;
     }
   };
   auto lstore = [&](int buf) {
@@ -236,8 +264,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     T* Bs = Bs0 + buf * L::B_ELEMS;
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
-      int ch = tid + c * NT, row = ch / A_CPR, col = (ch % A_CPR) * EPC;
-      *reinterpret_cast<u32x4*>(&As[row * LDA_S + col]) = ra[c];
+      *reinterpret_cast<u32x4*>(&As[lsa[c]]) = ra[c];
       if (!A_KMAJOR && do_colsum) {
         // A_CPR chunks per row and NT % A_CPR == 0: a thread always owns the same columns.
         if (IS_BF16) {
@@ -254,11 +281,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
       }
     }
 #pragma unroll
-    for (int c = 0; c < B_CH; ++c) {
-      int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
-      if (B_KMAJOR) row = perm_row<NQ>(row);
-      *reinterpret_cast<u32x4*>(&Bs[row * LDB_S + col]) = rb[c];
-    }
+    for (int c = 0; c < B_CH; ++c) *reinterpret_cast<u32x4*>(&Bs[lsb[c]]) = rb[c];
   };
   auto compute = [&](int buf) {
     const T* As = As0 + buf * L::A_ELEMS;
@@ -318,16 +341,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 
   if (kbeg < kend) {
     gload(kbeg);
+    TRACE_STAMP();  // 1: first loads issued
     lstore(0);
+    TRACE_STAMP();  // 2: first tile landed + written to LDS
     __syncthreads();
+    TRACE_STAMP();  // 3: barrier
     if constexpr (NBUF == 2) {      // one barrier per k-tile, 2x LDS
       int buf = 0;
       for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) gload(k0 + BK);   // next tile: global -> registers, in flight during the MFMAs
         compute(buf);
+        TRACE_STAMP();              // 4,7,10,13: MFMAs of the tile issued
         if (more) lstore(buf ^ 1);  // the other buffer was last read one barrier ago
+        TRACE_STAMP();              // 5,8,11,14: next tile landed + written
         __syncthreads();
+        TRACE_STAMP();              // 6,9,12,15: barrier
         buf ^= 1;
       }
     } else {                        // two barriers per k-tile, half the LDS -> more resident workgroups
@@ -452,11 +481,19 @@ int launch_gemm(const mfp_gemm_args* a, const GemmParams& p, int splitk, hipStre
   return MFP_EINVAL;
 }
 
+#ifdef MFP_GEMM_TRACE
+unsigned long long* g_trace = nullptr;
+#endif
+
 bool uses_workspace(const mfp_gemm_args* a) {
   return a->splitk > 1 || (a->flags & (MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A));
 }
 
 }  // namespace
+
+#ifdef MFP_GEMM_TRACE
+extern "C" void mfp_trace_buffer(void* p) { g_trace = reinterpret_cast<unsigned long long*>(p); }
+#endif
 
 extern "C" size_t mfp_gemm_workspace_bytes(const mfp_gemm_args* a) {
   if (!uses_workspace(a)) return 0;
@@ -507,6 +544,9 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   p.out_bf16 = a->out_dtype == MFP_BF16; p.flags = a->flags;
   p.dropout_p = a->dropout_p; p.seed = a->seed; p.offset = a->offset; p.step_ptr = a->step_ptr;
   p.tiles_m = 0; p.tiles_n = 0;  // set per tile configuration in launch_one
+#ifdef MFP_GEMM_TRACE
+  p.trace = g_trace;
+#endif
   const int bk = a->in_dtype == MFP_BF16 ? GemmCfg<unsigned short>::BK : GemmCfg<float>::BK;
   int kchunk = (a->K + splitk - 1) / splitk;
   kchunk = ((kchunk + bk - 1) / bk) * bk;

@@ -1,0 +1,6 @@
+#!/bin/bash
+# builds the trace variant of the GEMM next to the tool (never shipped) and prints the timeline
+set -e
+cd "$(dirname "$0")/../flex-dm_amd/csrc"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMFP_GEMM_TRACE -shared gemm.hip error.cpp -o ../../tools/libmfp_trace.so
+cd ../.. && python tools/trace_gemm.py
