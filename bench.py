@@ -114,6 +114,7 @@ def main():
     model.model.store.refresh_shadow()
     if not args.no_graph:
         model.capture_train_step(batch, warmup=2)
+        batch = model.static_batch   # the graph's input buffers: inputs are already resident there
 
     def barrier():
         if world > 1:

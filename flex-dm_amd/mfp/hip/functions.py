@@ -25,14 +25,34 @@ class StepCtx:
     """Per-call constants shared by the Functions of one forward pass."""
 
     def __init__(self, store, B: int, S: int, nvalid: torch.Tensor, training: bool, dropout: float,
-                 seed: int, step_ptr: Optional[torch.Tensor]):
+                 seed: int, step_ptr: Optional[torch.Tensor], side_stream=None):
         self.store, self.B, self.S, self.T = store, B, S, B * S
+        self.side = side_stream
         self.nvalid = nvalid
         self.training = training
         self.p = float(dropout) if training else 0.0
         self.seed = int(seed)
         self.step_ptr = step_ptr
         self.cdt = store.compute_dtype
+
+    def on_side(self, fn, *tensors):
+        """Run ``fn`` (weight-gradient GEMMs: off the critical path, only Adam needs them) on the
+        side HIP stream, forked after everything enqueued so far on the current stream.  Every
+        kernel of the step leaves most of a CU idle (profiles/r01_gemm_qkv_timeline.txt), so the
+        wgrads overlap with the dgrad / attention / LayerNorm chain.  ``join_side`` must be called
+        before the gradients are consumed."""
+        if self.side is None:
+            return fn()
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in tensors:   # their memory must not be recycled by main-stream allocations too early
+            t.record_stream(self.side)
+
+    def join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def to_cdt(self, x: torch.Tensor) -> torch.Tensor:
         if self.cdt == torch.float32:
@@ -57,14 +77,18 @@ def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
 def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     st, L = ctx.store, ctx.store.layout
     T, D = ctx.T, L.D
-    ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
     if L.num_keys:
         dh_c = ctx.to_cdt(dh)
-        for j, k in enumerate(L.num_keys):
-            width = xs[j].shape[1]
-            ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
-                     out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
-                     colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
+
+        def wgrads():
+            for j, k in enumerate(L.num_keys):
+                width = xs[j].shape[1]
+                ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
+                         out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
+                         colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
+        ctx.on_side(wgrads, dh_c, *xs, *codes)
+    ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
+    ctx.join_side()   # last node of the backward pass: every weight gradient is complete after this
 
 
 class EncoderFn(torch.autograd.Function):
@@ -156,10 +180,13 @@ class BlockFn(torch.autograd.Function):
         d_o2 = ops.dropout_bwd(dx2, cdt, st.grad(p + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * i + 2, ctx.step_ptr)
         dh = ops.gemm(d_o2, st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True, b_kmajor=False,
                       out_dtype=cdt, relu_bwd_aux=h)
-        ops.gemm(d_o2, h, D, 2 * D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_1/kernel"),
-                 splitk=sk(T, D, 2 * D))
-        ops.gemm(dh, y2, 2 * D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_0/kernel"),
-                 colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
+
+        def wgrads_mlp():
+            ops.gemm(d_o2, h, D, 2 * D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_1/kernel"),
+                     splitk=sk(T, D, 2 * D))
+            ops.gemm(dh, y2, 2 * D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_0/kernel"),
+                     colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
+        ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
         dy2 = ops.gemm(dh, st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True, b_kmajor=False, out_dtype=cdt)
         dx1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
                                 st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"))
@@ -168,12 +195,15 @@ class BlockFn(torch.autograd.Function):
                                ctx.step_ptr)
         da = ops.gemm(d_o1, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=False,
                       out_dtype=cdt)
-        ops.gemm(d_o1, a, D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "attn/combine_heads/kernel"),
-                 splitk=sk(T, D, D))
         dqkv = ops.attention_bwd(qkv, ctx.nvalid, a, da, lse, B, S, NUM_HEADS)
-        ops.gemm(dqkv, y1, 3 * D, D, T, a_kmajor=False, b_kmajor=False,
-                 out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D),
-                 colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D), splitk=sk(T, 3 * D, D))
+
+        def wgrads_attn():
+            ops.gemm(d_o1, a, D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "attn/combine_heads/kernel"),
+                     splitk=sk(T, D, D))
+            ops.gemm(dqkv, y1, 3 * D, D, T, a_kmajor=False, b_kmajor=False,
+                     out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D),
+                     colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D), splitk=sk(T, 3 * D, D))
+        ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
         dy1 = ops.gemm(dqkv, st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D, 3 * D, a_kmajor=True,
                        b_kmajor=False, out_dtype=cdt)
         dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
@@ -195,11 +225,13 @@ def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Ten
     st, L = ctx.store, ctx.store.layout
     first = next(iter(L.columns))
     T, D, U = ctx.T, L.D, L.Upad
+    def wgrad_heads():
+        ops.gemm(dl_c, h_c, U, D, T, a_kmajor=False, b_kmajor=False,
+                 out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
+                 colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U), splitk=ops.wgrad_splitk(T, U, D))
+    ctx.on_side(wgrad_heads, dl_c, h_c)
     dh = ops.gemm(dl_c, st.cw("decoder/decoder_%s/kernel" % first, rows=U), T, D, U, a_kmajor=True,
                   b_kmajor=False, out_dtype=torch.float32)
-    ops.gemm(dl_c, h_c, U, D, T, a_kmajor=False, b_kmajor=False,
-             out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
-             colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U), splitk=ops.wgrad_splitk(T, U, D))
     return dh
 
 
@@ -228,7 +260,8 @@ class DecoderLossFn(torch.autograd.Function):
     def forward(fctx, h, ctx: StepCtx, keys: List[dict]):
         h_c = ctx.to_cdt(h.contiguous())
         logits = _heads_fwd(ctx, h_c)
-        sums, dl = ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt)
+        dl = ctx.store.scratch("dlogits", logits.shape, ctx.cdt)   # zeroed once: pad columns stay 0
+        sums, dl = ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt, dlogits=dl)
         fctx.ctx, fctx.saved = ctx, (h_c, dl)
         fctx.mark_non_differentiable(sums, logits)
         return sums[:, 0].sum(), sums, logits

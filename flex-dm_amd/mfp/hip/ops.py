@@ -78,14 +78,15 @@ def _esz(t):
 
 
 # ------------------------------------------------------------------------------- workspace
-_workspaces: Dict[torch.device, List[torch.Tensor]] = {}
+_workspaces: Dict[tuple, List[torch.Tensor]] = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (stream-ordered reuse; old buffers are kept alive so
-    pointers baked into a captured hipGraph stay valid)."""
+    """Grow-only scratch buffer per (device, stream): reuse is stream-ordered, so kernels running
+    concurrently on the side stream (weight gradients) never share partial buffers with the main
+    stream; old buffers are kept alive so pointers baked into a captured hipGraph stay valid."""
     device = torch.device(device)
-    lst = _workspaces.setdefault(device, [])
+    lst = _workspaces.setdefault((device, torch.cuda.current_stream().cuda_stream), [])
     if not lst or lst[-1].numel() < nbytes:
         lst.append(torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device))
     return lst[-1]

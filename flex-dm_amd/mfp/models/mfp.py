@@ -265,6 +265,8 @@ class MFP:
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, targets, masks)
             loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True)
         loss.backward()
+        if self.model.side_stream is not None:   # weight gradients run on the side stream
+            torch.cuda.current_stream().wait_stream(self.model.side_stream)
         return sums
 
     def _apply(self):
@@ -321,6 +323,7 @@ class MFP:
 
         self._graph = replay
         self._graph_objs = (g1, g2, static, static_sums)
+        self.static_batch = static   # a loader that writes the next batch here avoids the copy
         return replay
 
     def test_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:

@@ -147,7 +147,18 @@ class ParamStore:
         # autograd anchor: the custom Functions need one differentiable input even when the data
         # inputs are integer indices; parameter gradients bypass autograd and land in ``g``.
         self.anchor = torch.zeros((), dtype=torch.float32, device=device, requires_grad=True)
+        self._scratch = {}
         self.init_keras(seed)
+
+    def scratch(self, name: str, shape, dtype) -> torch.Tensor:
+        """Persistent zero-initialised device buffer (allocated once per shape), e.g. the dlogits
+        matrix whose padding columns must stay zero without a 90 MB fill every step."""
+        key = (name, tuple(shape), dtype)
+        buf = self._scratch.get(key)
+        if buf is None:
+            buf = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+            self._scratch[key] = buf
+        return buf
 
     # ------------------------------------------------------------------ views
     def _view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
