@@ -172,11 +172,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
 #ifdef MFP_GEMM_TRACE
   int trace_i = 0;
-#define TRACE_STAMP() do { if (tid == 0 && trace_i < 16) p.trace[(long long)(blockIdx.x + gridDim.x * blockIdx.z) * 16 + trace_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TRACE_STAMP() do { if (tid == 0 && trace_i < 20) p.trace[(long long)(blockIdx.x + gridDim.x * blockIdx.z) * 24 + trace_i++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TRACE_STAMP() do {} while (0)
 #endif
   TRACE_STAMP();  // 0: start
+#ifdef MFP_GEMM_TRACE
+  if (tid == 0) p.trace[(long long)(blockIdx.x + gridDim.x * blockIdx.z) * 24 + 20] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // XCD-aware bijective remap: consecutive logical tiles stay on one XCD (shared A panel in L2)
   int nwg = p.tiles_m * p.tiles_n;
@@ -206,57 +209,61 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 #pragma unroll
   for (int e = 0; e < EPC; ++e) csum[e] = 0.f;
 
-  // Per-chunk state computed ONCE: global pointer (advanced by a constant per k-tile), row
-  // predicate, k column (for the K tail) and LDS offset (weight-row permutation folded in).  The
-  // k-loop then issues loads with one 64-bit add per chunk instead of re-deriving addresses.
+  // Branch-free staging loads: raw buffer loads through a wave-uniform descriptor.  Each chunk
+  // has a FIXED 32-bit byte offset (voffset; 0xFFFFFFF0 = "out of range" -> the hardware returns
+  // zeros, no exec-mask branch), the k-tile advance rides in the scalar soffset.  No per-tile
+  // address VALU, and the whole k-loop body is one basic block so loads interleave with MFMAs.
   u32x4 ra[A_CH], rb[B_CH];
-  const T* pa[A_CH];
-  const T* pb[B_CH];
-  bool oka[A_CH], okb[B_CH];
+  unsigned int voa[A_CH], vob[B_CH];
   int kca[A_CH], kcb[B_CH];     // k offset of the chunk inside a tile (row for k-strided tiles)
-  int lsa[A_CH], lsb[B_CH];     // LDS element offsets
+  int lsa[A_CH], lsb[B_CH];     // LDS element offsets (weight-row permutation folded in)
+  constexpr unsigned int OOB = 0xFFFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Ag), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Bg), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
   for (int c = 0; c < A_CH; ++c) {
     const int ch = tid + c * NT, row = ch / A_CPR, col = (ch % A_CPR) * EPC;
     lsa[c] = row * LDA_S + col;
     if (A_KMAJOR) {
-      oka[c] = m0 + row < p.M; kca[c] = col;
-      pa[c] = Ag + (long long)(m0 + row) * p.lda + kbeg + col;
+      kca[c] = col;
+      voa[c] = m0 + row < p.M ? (unsigned int)(((long long)(m0 + row) * p.lda + kbeg + col) * sizeof(T)) : OOB;
     } else {
-      oka[c] = m0 + col < p.M; kca[c] = row;
-      pa[c] = Ag + (long long)(kbeg + row) * p.lda + m0 + col;
+      kca[c] = row;
+      voa[c] = m0 + col < p.M ? (unsigned int)(((long long)(kbeg + row) * p.lda + m0 + col) * sizeof(T)) : OOB;
     }
   }
 #pragma unroll
   for (int c = 0; c < B_CH; ++c) {
     const int ch = tid + c * NT, row = ch / B_CPR, col = (ch % B_CPR) * EPC;
     if (B_KMAJOR) {
-      okb[c] = n0 + row < p.N; kcb[c] = col;
-      pb[c] = Bg + (long long)(n0 + row) * p.ldb + kbeg + col;
+      kcb[c] = col;
+      vob[c] = n0 + row < p.N ? (unsigned int)(((long long)(n0 + row) * p.ldb + kbeg + col) * sizeof(T)) : OOB;
       lsb[c] = perm_row<NQ>(row) * LDB_S + col;
     } else {
-      okb[c] = n0 + col < p.N; kcb[c] = row;
-      pb[c] = Bg + (long long)(kbeg + row) * p.ldb + n0 + col;
+      kcb[c] = row;
+      vob[c] = n0 + col < p.N ? (unsigned int)(((long long)(kbeg + row) * p.ldb + n0 + col) * sizeof(T)) : OOB;
       lsb[c] = row * LDB_S + col;
     }
   }
-  const long long stepa = A_KMAJOR ? (long long)BK : (long long)BK * p.lda;
-  const long long stepb = B_KMAJOR ? (long long)BK : (long long)BK * p.ldb;
+  const int stepa = (A_KMAJOR ? BK : BK * p.lda) * (int)sizeof(T);   // bytes per k-tile
+  const int stepb = (B_KMAJOR ? BK : BK * p.ldb) * (int)sizeof(T);
 
   auto gload = [&](int k0) {
-    const bool full = k0 + BK <= kend;   // uniform: only the last tile of a ragged K checks columns
+    const bool full = k0 + BK <= kend;   // uniform: only a ragged / absent tile checks its k columns
+    const int t = (k0 - kbeg) / BK;
+    const int soa = t * stepa, sob = t * stepb;
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
-      bool ok = oka[c] && (full || k0 + kca[c] < kend);
-      if (!A_KMAJOR && rowskip_a && ok) ok = p.rowcode[k0 + kca[c]] == 0;
-      ra[c] = ok ? *reinterpret_cast<const u32x4*>(pa[c]) : (u32x4){0u, 0u, 0u, 0u};
-      pa[c] += stepa;
+      unsigned int vo = voa[c];
+      if (!full) vo = k0 + kca[c] < kend ? vo : OOB;
+      if (!A_KMAJOR && rowskip_a) vo = (k0 + kca[c] < kend && p.rowcode[k0 + kca[c]] != 0) ? OOB : vo;
+      ra[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, vo, soa, 0));
     }
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
-      const bool ok = okb[c] && (full || k0 + kcb[c] < kend);
-      rb[c] = ok ? *reinterpret_cast<const u32x4*>(pb[c]) : (u32x4){0u, 0u, 0u, 0u};
-      pb[c] += stepb;
+      unsigned int vo = vob[c];
+      if (!full) vo = k0 + kcb[c] < kend ? vo : OOB;
+      rb[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, sob, 0));
     }
   };
   auto lstore = [&](int buf) {
@@ -349,11 +356,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     if constexpr (NBUF == 2) {      // one barrier per k-tile, 2x LDS
       int buf = 0;
       for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
-        if (more) gload(k0 + BK);   // next tile: global -> registers, in flight during the MFMAs
+        // Unconditional: past the last tile every offset is out of range (zero-fill, no traffic),
+        // so the loop body is ONE basic block and the scheduler may interleave loads and MFMAs.
+        gload(k0 + BK);             // next tile: global -> registers, in flight during the MFMAs
         compute(buf);
+        if constexpr (IS_BF16 && (A_CH + B_CH) * 2 <= MT * NQ * (BK / 32)) {
+          // In-order issue: a wave's MFMAs would queue behind its 8 VMEM instructions, which the
+          // address path throttles (1 KB per wave-load = 16 clk; profiles/r01_gemm_qkv_timeline.txt).
+          // Trickle one load per two MFMAs so the load path and the matrix pipe run concurrently.
+          __builtin_amdgcn_sched_group_barrier(0x100, MT + NQ, 0);     // fragment ds_reads of k-step 0
+#pragma unroll
+          for (int i = 0; i < A_CH + B_CH; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // one global load
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);         // two MFMAs
+          }
+        }
         TRACE_STAMP();              // 4,7,10,13: MFMAs of the tile issued
-        if (more) lstore(buf ^ 1);  // the other buffer was last read one barrier ago
+        lstore(buf ^ 1);            // the other buffer was last read one barrier ago
         TRACE_STAMP();              // 5,8,11,14: next tile landed + written
         __syncthreads();
         TRACE_STAMP();              // 6,9,12,15: barrier
@@ -400,7 +419,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
     }
     return;
   }
+  TRACE_STAMP();  // epilogue start
   gemm_epilogue<MT, NQ>(p, acc, m0 + wm * WBM, nb, li);
+  TRACE_STAMP();  // stores issued
+#ifdef MFP_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  TRACE_STAMP();  // stores retired
+#ifdef MFP_GEMM_TRACE
+  if (tid == 0) p.trace[(long long)(blockIdx.x + gridDim.x * blockIdx.z) * 24 + 21] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // out[m][n] (+)= sum_z ws[z][m][n];  colsum[m] = sum_z ws_col[z][m].  N % 4 == 0.
@@ -513,6 +541,11 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   if (a->a_kmajor) MFP_CHECK_ARG(a->K % epc == 0); else MFP_CHECK_ARG(a->M % epc == 0);
   if (a->b_kmajor) MFP_CHECK_ARG(a->K % epc == 0);
   MFP_CHECK_ARG(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->B % 16) == 0);
+  {  // staging loads use 32-bit byte offsets (raw buffer loads)
+    const long long esz = a->in_dtype == MFP_BF16 ? 2 : 4;
+    const long long rows_a = a->a_kmajor ? a->M : a->K, rows_b = a->b_kmajor ? a->N : a->K;
+    MFP_CHECK_ARG(rows_a * a->lda * esz < 0x7FFFFFF0ll && rows_b * a->ldb * esz < 0x7FFFFFF0ll);
+  }
   const int splitk = a->splitk < 1 ? 1 : a->splitk;
   const bool wgrad = !a->a_kmajor && !a->b_kmajor;
   MFP_CHECK_ARG(splitk == 1 || wgrad);
