@@ -61,6 +61,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 constexpr int LN_BWD_ROWS = 64;  // rows per workgroup (4 waves x 16 rows)
 
+// Optional fused consumer: the LN-backward output dx is, in the DeepSVG block, immediately fed to
+// the backward of a Dropout + Dense pair (x1 = x + Dropout(Dense(.))): when `ddrop` is given the
+// kernel also emits ddrop = cdt(keep ? dx/(1-p) : 0) with the Philox keying of the GEMM epilogue
+// (a lane holds 4 consecutive columns = one Philox call) and the column sums of ddrop (the Dense
+// bias gradient) as a third partial vector -- saving a full re-read of dx and two launches.
 template <typename TDY, int NVEC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ x,
@@ -69,13 +74,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ part,
-                                                     int T, int D) {
-  // part: [gridDim.x][2][D]  (dgamma partial, dbeta partial)
-  __shared__ float red[4][2][NVEC * 256];
+                                                     int T, int D, TDY* __restrict__ ddrop, float drop_p,
+                                                     unsigned long long seed, unsigned long long offset0,
+                                                     const int* __restrict__ step_ptr) {
+  // part: [gridDim.x][3][D]  (dgamma, dbeta, colsum(ddrop) partials)
+  __shared__ float red[4][3][NVEC * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float dg[NVEC * 4], db[NVEC * 4];
+  const unsigned long long rng_off = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float dg[NVEC * 4], db[NVEC * 4], dc[NVEC * 4];
 #pragma unroll
-  for (int j = 0; j < NVEC * 4; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  for (int j = 0; j < NVEC * 4; ++j) { dg[j] = 0.f; db[j] = 0.f; dc[j] = 0.f; }
   const int row0 = blockIdx.x * LN_BWD_ROWS;
   for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
     const int row = row0 + rr;
@@ -126,19 +135,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
       *reinterpret_cast<float4*>(dxr + c) = o;
+      if (ddrop != nullptr) {
+        if (drop_p > 0.f) {
+          unsigned int rnd[4];
+          philox4x32(seed, (unsigned int)row, (unsigned int)(c >> 2), rng_off, rnd);
+          o.x = philox_keep(rnd[0], drop_p) ? o.x * inv_keep : 0.f;
+          o.y = philox_keep(rnd[1], drop_p) ? o.y * inv_keep : 0.f;
+          o.z = philox_keep(rnd[2], drop_p) ? o.z * inv_keep : 0.f;
+          o.w = philox_keep(rnd[3], drop_p) ? o.w * inv_keep : 0.f;
+        }
+        TDY* dr = ddrop + (long long)row * D + c;
+        if constexpr (sizeof(TDY) == 4) {
+          *reinterpret_cast<float4*>(dr) = o;
+        } else {
+          u32x2 pk = {pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
+          *reinterpret_cast<u32x2*>(dr) = pk;
+        }
+        dc[j] += o.x; dc[j + 1] += o.y; dc[j + 2] += o.z; dc[j + 3] += o.w;
+      }
     }
   }
-  // cross-wave reduction of the dgamma/dbeta partials
+  // cross-wave reduction of the dgamma/dbeta(/colsum) partials
 #pragma unroll
   for (int i = 0; i < NVEC; ++i) {
     const int c = lane * 4 + i * 256, j = 4 * i;
     if (c >= D) continue;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[wave][0][c + e] = dg[j + e]; red[wave][1][c + e] = db[j + e]; }
+    for (int e = 0; e < 4; ++e) { red[wave][0][c + e] = dg[j + e]; red[wave][1][c + e] = db[j + e]; red[wave][2][c + e] = dc[j + e]; }
   }
   __syncthreads();
-  float* pout = part + (long long)blockIdx.x * 2 * D;
-  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+  float* pout = part + (long long)blockIdx.x * 3 * D;
+  for (int c = threadIdx.x; c < 3 * D; c += 256) {
     int which = c / D, col = c % D;
     pout[c] = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
   }
@@ -168,15 +195,17 @@ extern "C" int mfp_layernorm_fwd(const float* x, const float* gamma, const float
 
 extern "C" size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D) {
   size_t nblk = (size_t)(T + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
-  return nblk * 2 * D * sizeof(float);
+  return nblk * 3 * D * sizeof(float);
 }
 
 extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
                                  const float* rstd, const float* dres, float* dx, float* dgamma,
                                  float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
-                                 int32_t D, int32_t dy_dtype, mfp_stream_t stream) {
+                                 int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
+                                 uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
   MFP_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta);
   MFP_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024);
+  MFP_CHECK_ARG((ddrop == nullptr) == (drop_colsum == nullptr) && drop_p >= 0.f && drop_p < 1.f);
   if (!workspace || workspace_bytes < mfp_layernorm_bwd_workspace_bytes(T, D)) {
     mfp_set_error("mfp_layernorm_bwd: workspace too small");
     return MFP_EWORKSPACE;
@@ -186,7 +215,7 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
   float* part = reinterpret_cast<float*>(workspace);
   MFP_CHECK_ARG(dy_dtype == MFP_F32 || dy_dtype == MFP_BF16);
   const int nvec = (D + 255) / 256;
-#define LN_BWD(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D)
+#define LN_BWD(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D, (TT*)ddrop, drop_p, seed, offset, step_ptr)
   if (dy_dtype == MFP_F32) {
     if (nvec == 1) LN_BWD(float, 1); else if (nvec == 2) LN_BWD(float, 2); else LN_BWD(float, 4);
   } else {
@@ -194,7 +223,9 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
   }
 #undef LN_BWD
   MFP_CHECK_LAUNCH();
-  launch_reduce_rows(part, dgamma, dbeta, D, nblk, 2 * D, 2 * D, st);
+  launch_reduce_rows(part, dgamma, dbeta, D, nblk, 2 * D, 3 * D, st);
+  MFP_CHECK_LAUNCH();
+  if (ddrop != nullptr) launch_reduce_rows(part + 2 * D, drop_colsum, drop_colsum, D, nblk, D, 3 * D, st);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -28,6 +28,7 @@ class StepCtx:
                  seed: int, step_ptr: Optional[torch.Tensor], side_stream=None):
         self.store, self.B, self.S, self.T = store, B, S, B * S
         self.side = side_stream
+        self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
         self.nvalid = nvalid
         self.training = training
         self.p = float(dropout) if training else 0.0
@@ -177,7 +178,9 @@ class BlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         sk = ops.wgrad_splitk
         # ---- MLP: x2 = x1 + drop(h W2 + b2)
-        d_o2 = ops.dropout_bwd(dx2, cdt, st.grad(p + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * i + 2, ctx.step_ptr)
+        d_o2 = ctx.handoff.pop(i, None)   # produced by the LN1 backward of block i+1 (fused)
+        if d_o2 is None:
+            d_o2 = ops.dropout_bwd(dx2, cdt, st.grad(p + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * i + 2, ctx.step_ptr)
         dh = ops.gemm(d_o2, st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True, b_kmajor=False,
                       out_dtype=cdt, relu_bwd_aux=h)
 
@@ -188,11 +191,12 @@ class BlockFn(torch.autograd.Function):
                      colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
         ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
         dy2 = ops.gemm(dh, st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True, b_kmajor=False, out_dtype=cdt)
-        dx1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
-                                st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"))
+        # LN2 backward also emits the masked/cast gradient of the attention Dropout + its bias grad
+        dx1, d_o1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
+                                      st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
+                                      drop=(st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
+                                            ctx.step_ptr))
         # ---- attention: x1 = x + drop(a Wo + bo)
-        d_o1 = ops.dropout_bwd(dx1, cdt, st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
-                               ctx.step_ptr)
         da = ops.gemm(d_o1, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=False,
                       out_dtype=cdt)
         dqkv = ops.attention_bwd(qkv, ctx.nvalid, a, da, lse, B, S, NUM_HEADS)
@@ -206,8 +210,16 @@ class BlockFn(torch.autograd.Function):
         ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
         dy1 = ops.gemm(dqkv, st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D, 3 * D, a_kmajor=True,
                        b_kmajor=False, out_dtype=cdt)
-        dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
-                               st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"))
+        if i > 0:   # dx is the dx2 of block i-1: hand its masked/cast copy over (skips a dropout_bwd)
+            pp = "blocks/seq2seq_%d/" % (i - 1)
+            dx, nxt = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
+                                        st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"),
+                                        drop=(st.grad(pp + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * (i - 1) + 2,
+                                              ctx.step_ptr))
+            ctx.handoff[i - 1] = nxt
+        else:
+            dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
+                                   st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"))
         fctx.saved = None
         return dx, None, None
 

@@ -180,18 +180,24 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,
-                  dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None):
+    """``drop`` = (colsum_out [D], p, seed, offset, step_ptr): also return the dropout-masked,
+    compute-dtype copy of dx for the consuming Dense backward (fused mfp_dropout_bwd)."""
     lib = load()
     T, D = x.shape
     if dx is None:
         dx = torch.empty((T, D), dtype=torch.float32, device=x.device)
+    ddrop = torch.empty((T, D), dtype=dy.dtype, device=x.device) if drop is not None else None
+    colsum, p_, seed_, off_, sp_ = drop if drop is not None else (None, 0.0, 0, 0, None)
     nbytes = lib.mfp_layernorm_bwd_workspace_bytes(T, D)
     ws = workspace(nbytes, x.device)
-    with _timed("ln_bwd_kernel", 0, T * D * (_esz(dy) + 4 + (4 if dres is not None else 0) + 4)):
+    nb = T * D * (_esz(dy) + 4 + (4 if dres is not None else 0) + 4 + (_esz(dy) if drop is not None else 0))
+    with _timed("ln_bwd_kernel", 0, nb):
         check(lib.mfp_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
                                     _ptr(dx), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), ws.numel(), T, D,
-                                    dt_code(dy.dtype), _stream()), "mfp_layernorm_bwd")
-    return dx
+                                    dt_code(dy.dtype), _ptr(ddrop), _ptr(colsum), float(p_), int(seed_), int(off_),
+                                    _ptr(sp_), _stream()), "mfp_layernorm_bwd")
+    return (dx, ddrop) if drop is not None else dx
 
 
 # ------------------------------------------------------------------------------- attention

@@ -100,11 +100,15 @@ int mfp_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
                       float* mean, float* rstd, int32_t T, int32_t D, float eps,
                       int32_t out_dtype, mfp_stream_t stream);
 /* dx[t] = (dres ? dres[t] : 0) + LN'(dy)[t]; dgamma/dbeta f32 [D].
- * workspace: mfp_layernorm_bwd_workspace_bytes(T,D). dx may alias dres. */
+ * workspace: mfp_layernorm_bwd_workspace_bytes(T,D). dx may alias dres.
+ * Optional fused consumer (ddrop != NULL): also writes ddrop = cdt(keep ? dx/(1-p) : 0) with the
+ * Philox stream of MFP_GEMM_DROPOUT / mfp_dropout_bwd and drop_colsum[D] = column sums of ddrop
+ * (the gradient of the Dense bias behind the Dropout, transformer.py:218-219,224-225). */
 int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx, float* dgamma,
                       float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
-                      int32_t D, int32_t dy_dtype, mfp_stream_t stream);
+                      int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
+                      uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D);
 
 /* --------------------------------------------------------------------------- attention

@@ -232,6 +232,16 @@ def test_layernorm(dtype, T, D):
     assert_close(dx, x.grad + dres, 2e-5, 1e-5, "ln dx")
     assert_close(dg, gamma.grad, 1e-3, 1e-5, "ln dgamma")
     assert_close(db, beta.grad, 1e-3, 1e-5, "ln dbeta")
+    # fused Dropout-backward consumer == mfp_dropout_bwd on the produced dx (same Philox stream)
+    p, seed, off = 0.1, 77, 3
+    cs = torch.empty(D, device=DEV)
+    dx2, dd = ops.layernorm_bwd(dy.to(DEV, dtype), x.detach().to(DEV), gamma.detach().to(DEV), md, rd,
+                                dres.to(DEV), dg, db, drop=(cs, p, seed, off, None))
+    assert torch.equal(dx2, dx)
+    cs_ref = torch.empty(D, device=DEV)
+    dd_ref = ops.dropout_bwd(dx, dtype, cs_ref, p, seed, off)
+    assert torch.equal(dd, dd_ref)
+    assert_close(cs, cs_ref, 1e-3, 1e-4, "fused colsum")
 
 
 # ------------------------------------------------------------------------------- attention
