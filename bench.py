@@ -98,8 +98,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    dev_index = local_rank % torch.cuda.device_count()   # (several ranks per GPU only under MFP_DIST_BACKEND=gloo)
+    torch.cuda.set_device(dev_index)
+    device = "cuda:%d" % dev_index
     world = dp.init_from_env()
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     torch.manual_seed(1234 + rank)
@@ -136,6 +137,13 @@ def main():
         elapsed = float(t.item())
     metrics = model.metrics_dict(sums)
     assert metrics["loss"] == metrics["loss"] and abs(metrics["loss"]) < 1e9, "loss is not finite"
+    in_sync = True
+    if world > 1:   # replicas must hold identical parameters after identical averaged updates
+        w = model.model.store.w
+        lo, hi = w.clone(), w.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi)) and bool(torch.isfinite(w).all())
 
     value = world * B * S * args.steps / elapsed
     L = model.model.layout
@@ -153,6 +161,7 @@ def main():
                    "launch": "eager" if args.no_graph else "hipGraph replay",
                    "params": L.numel, "train_flop_per_element": fpe},
         "final_loss": metrics["loss"],
+        "params_in_sync": in_sync,
     }
 
     # ---------------- roofline of the dominant kernel: HIP events on the launch stream, eager steps

@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ qk
   constexpr int LD = HD + 1;
   float* Ks = sm;
   float* Vs = sm + S * LD;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);   // heads of one document -> one XCD (shared 128-B lines)
+  const int b = bid / H, h = bid % H;
   const int D = H * HD, D3 = 3 * D;
   const int nv = nvalid[b];
   for (int i = threadIdx.x; i < S * HD; i += blockDim.x) {
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32(const float* __restrict__
   constexpr int LD = HD + 1;
   float* Ks = sm;
   float* Vs = sm + S * LD;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);   // heads of one document -> one XCD (shared 128-B lines)
+  const int b = bid / H, h = bid % H;
   const int D = H * HD, D3 = 3 * D;
   const int nv = nvalid[b];
   for (int i = threadIdx.x; i < S * HD; i += blockDim.x) {
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32(const float* __restrict_
   float* dOs = sm + S * LD;
   float* Ls = dOs + S * LD;
   float* Dl = Ls + S;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);   // heads of one document -> one XCD (shared 128-B lines)
+  const int b = bid / H, h = bid % H;
   const int D = H * HD, D3 = 3 * D;
   const int nv = nvalid[b];
   for (int i = threadIdx.x; i < S * HD; i += blockDim.x) {
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const bf16_t* __restrict__ 
   bf16_t* Qs = smb;
   bf16_t* Ks = Qs + SP * LDH;
   bf16_t* Vs = Ks + SP * LDH;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);   // heads of one document -> one XCD (shared 128-B lines)
+  const int b = bid / H, h = bid % H;
   const int D = H * HD, D3 = 3 * D;
   const int nv = nvalid[b];
   const bf16_t* base = qkv + (long long)b * S * D3 + h * HD;
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const bf16_t* __restrict__ 
   bf16_t* dOs = Vs + SP * LDH;
   float* Ls = reinterpret_cast<float*>(dOs + SP * LDH);
   float* Dl = Ls + SP;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);   // heads of one document -> one XCD (shared 128-B lines)
+  const int b = bid / H, h = bid % H;
   const int D = H * HD, D3 = 3 * D;
   const int nv = nvalid[b];
   const bf16_t* base = qkv + (long long)b * S * D3 + h * HD;

@@ -100,3 +100,12 @@ __device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned int
 __device__ __forceinline__ bool philox_keep(unsigned int r, float p) {
   return (float)(r >> 8) * (1.0f / 16777216.0f) >= p;
 }
+
+// ----------------------------------------------------------------------------- XCD-aware block order
+// Hardware places block b on XCD b % 8 (speed only, never correctness).  This bijective remap gives
+// every XCD a CONTIGUOUS range of logical ids, so neighbouring logical ids (tiles sharing an operand
+// panel, or the 8 heads of a document whose 64-byte slices share 128-byte lines) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}

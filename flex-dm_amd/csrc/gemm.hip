@@ -182,12 +182,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 #endif
 
   // XCD-aware bijective remap: consecutive logical tiles stay on one XCD (shared A panel in L2)
-  int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
+  const int bid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kz = blockIdx.z;

@@ -24,7 +24,9 @@ def init_from_env(backend: Optional[str] = None) -> int:
     if world <= 1:
         return 1
     if not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # MFP_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests of the multi-rank step logic);
+        # production is "nccl" (= RCCL on ROCm), one rank per GPU over xGMI.
+        backend = backend or os.environ.get("MFP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend)
     return dist.get_world_size()

@@ -24,6 +24,7 @@ def train(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = args.device
     if device == "cuda":
+        local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         device = "cuda:%d" % local_rank
     seed = args.seed

@@ -218,3 +218,25 @@ def test_mfp_call_demo_args_and_merge():
     assert "total_score" in model.loss_layer.metrics
     scores = model.loss_layer((batch, {k: v for k, v in out.items()}, masks))[0]
     assert "left_score_num" in scores
+
+
+def test_two_rank_step_on_one_gpu_over_gloo(tmp_path):
+    """The N>1 step (graph 1: masking+fwd+bwd, eager all-reduce, graph 2: Adam) run with 2 ranks
+    sharing this GPU over gloo.  Ranks see different batches; after the step their parameters must
+    be identical and finite, and bench.py must print its one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MFP_DIST_BACKEND="gloo", MASTER_PORT="29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5",
+           "--warmup", "2", "--batch", "32", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
+    assert d["params_in_sync"] is True
