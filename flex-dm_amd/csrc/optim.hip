@@ -13,14 +13,18 @@ namespace {
 
 constexpr int ADAM_CHUNK = 4096;  // elements per workgroup
 
-// stats[seg][0] += sum (g*gs + 2*l2*w)^2 ; stats[seg][1] += sum w^2
+// partial[chunk] = { sum (g*gs + 2*l2*w)^2 , sum w^2 } over the chunk.  No float atomics: the
+// per-variable totals are formed in a FIXED order by adam_update_kernel, so data-parallel replicas
+// (which hold bit-identical all-reduced gradients) compute bit-identical clip factors and stay in
+// lock-step -- atomics made the norm's last bit depend on arrival order and replicas drifted.
 __global__ __launch_bounds__(256) void adam_norm_kernel(const float* __restrict__ w,
                                                         const float* __restrict__ g,
                                                         const int* __restrict__ chunk_seg,
                                                         const long long* __restrict__ chunk_beg,
                                                         const int* __restrict__ chunk_len,
                                                         const float* __restrict__ seg_l2,
-                                                        float* __restrict__ stats, float grad_scale) {
+                                                        float* __restrict__ partial, float grad_scale,
+                                                        int* __restrict__ step_t) {
   __shared__ float red[2][4];
   const int seg = chunk_seg[blockIdx.x];
   const long long beg = chunk_beg[blockIdx.x];
@@ -36,10 +40,9 @@ __global__ __launch_bounds__(256) void adam_norm_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[0][wave] = sg; red[1][wave] = sw; }
   __syncthreads();
-  if (threadIdx.x < 2) {
-    float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-    atomicAdd(&stats[seg * 2 + threadIdx.x], s);
-  }
+  if (threadIdx.x < 2)
+    partial[blockIdx.x * 2 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *step_t += 1;   // the update kernel (next launch) reads it
 }
 
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ w, const float* __restrict__ g,
@@ -48,18 +51,33 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ w,
                                                           const int* __restrict__ chunk_seg,
                                                           const long long* __restrict__ chunk_beg,
                                                           const int* __restrict__ chunk_len,
+                                                          const int* __restrict__ seg_first,
                                                           const float* __restrict__ seg_l2,
-                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ partial,
+                                                          float* __restrict__ stats,
                                                           const int* __restrict__ step_t, float lr, float b1,
                                                           float b2, float eps, float clipnorm, float grad_scale) {
+  __shared__ float tot[2];
   const int seg = chunk_seg[blockIdx.x];
   const long long beg = chunk_beg[blockIdx.x];
   const int len = chunk_len[blockIdx.x];
   const float l2 = seg_l2[seg];
+  // fixed-order total over this variable's chunks: wave 0, lane-strided then xor-shuffle tree
+  if (threadIdx.x < 64) {
+    const int c0 = seg_first[seg], c1 = seg_first[seg + 1];
+    float sg = 0.f, sw = 0.f;
+    for (int c = c0 + (int)threadIdx.x; c < c1; c += 64) { sg += partial[c * 2]; sw += partial[c * 2 + 1]; }
+    sg = wave_sum(sg); sw = wave_sum(sw);
+    if (threadIdx.x == 0) {
+      tot[0] = sg; tot[1] = sw;
+      if ((int)blockIdx.x == c0) { stats[seg * 2] = sg; stats[seg * 2 + 1] = sw; }
+    }
+  }
+  __syncthreads();
   const float t = (float)(*step_t);  // already incremented (1-based)
   const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
   float clip = 1.f;
-  if (clipnorm > 0.f) clip = clipnorm / fmaxf(sqrtf(stats[seg * 2]), clipnorm);
+  if (clipnorm > 0.f) clip = clipnorm / fmaxf(sqrtf(tot[0]), clipnorm);
   for (int i = threadIdx.x; i < len; i += 256) {
     const long long o = beg + i;
     const float wi = w[o];
@@ -70,12 +88,6 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ w,
     m[o] = mi; v[o] = vi; w[o] = wn;
     if (shadow) shadow[o] = f32_to_bf16(wn);
   }
-}
-
-__global__ void step_inc_kernel(int* step_t, float* stats, int nstats) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *step_t += 1;
-  if (i < nstats) stats[i] = 0.f;
 }
 
 __global__ void cast_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
@@ -169,12 +181,14 @@ extern "C" int64_t mfp_adam_num_chunks(const int32_t* seg_off_host, int32_t nseg
 }
 
 // Fills host arrays (caller copies them to the device once): chunk_seg int32[nchunks],
-// chunk_beg int64[nchunks], chunk_len int32[nchunks].
+// chunk_beg int64[nchunks], chunk_len int32[nchunks], seg_first int32[nseg+1] (first chunk of
+// each variable).
 extern "C" int mfp_adam_chunk_table(const int32_t* seg_off_host, int32_t nseg, int32_t* chunk_seg,
-                                    int64_t* chunk_beg, int32_t* chunk_len) {
-  MFP_CHECK_ARG(seg_off_host && chunk_seg && chunk_beg && chunk_len && nseg > 0);
+                                    int64_t* chunk_beg, int32_t* chunk_len, int32_t* seg_first) {
+  MFP_CHECK_ARG(seg_off_host && chunk_seg && chunk_beg && chunk_len && seg_first && nseg > 0);
   int64_t k = 0;
   for (int s = 0; s < nseg; ++s) {
+    seg_first[s] = (int32_t)k;
     int64_t beg = seg_off_host[s], end = seg_off_host[s + 1];
     for (int64_t b = beg; b < end; b += ADAM_CHUNK) {
       chunk_seg[k] = s; chunk_beg[k] = b;
@@ -182,26 +196,24 @@ extern "C" int mfp_adam_chunk_table(const int32_t* seg_off_host, int32_t nseg, i
       ++k;
     }
   }
+  seg_first[nseg] = (int32_t)k;
   return MFP_OK;
 }
 
 extern "C" int mfp_adam_keras(float* w, const float* g, float* m, float* v, uint16_t* shadow,
-                                     const int32_t* chunk_seg, const int64_t* chunk_beg,
-                                     const int32_t* chunk_len, int64_t nchunks, const float* seg_l2,
-                                     float* stats, int32_t nseg, int32_t* step_t, float lr, float beta1,
-                                     float beta2, float eps, float clipnorm, float grad_scale,
-                                     mfp_stream_t stream) {
-  MFP_CHECK_ARG(w && g && m && v && chunk_seg && chunk_beg && chunk_len && seg_l2 && stats && step_t);
+                              const int32_t* chunk_seg, const int64_t* chunk_beg, const int32_t* chunk_len,
+                              const int32_t* seg_first, int64_t nchunks, const float* seg_l2, float* partial,
+                              float* stats, int32_t nseg, int32_t* step_t, float lr, float beta1, float beta2,
+                              float eps, float clipnorm, float grad_scale, mfp_stream_t stream) {
+  MFP_CHECK_ARG(w && g && m && v && chunk_seg && chunk_beg && chunk_len && seg_first && seg_l2 && partial && stats && step_t);
   MFP_CHECK_ARG(nchunks > 0 && nseg > 0);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(step_inc_kernel, dim3((2 * nseg + 255) / 256), dim3(256), 0, st, step_t, stats, 2 * nseg);
-  MFP_CHECK_LAUNCH();
   hipLaunchKernelGGL(adam_norm_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, w, g, chunk_seg,
-                     reinterpret_cast<const long long*>(chunk_beg), chunk_len, seg_l2, stats, grad_scale);
+                     reinterpret_cast<const long long*>(chunk_beg), chunk_len, seg_l2, partial, grad_scale, step_t);
   MFP_CHECK_LAUNCH();
   hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, w, g, m, v, shadow,
-                     chunk_seg, reinterpret_cast<const long long*>(chunk_beg), chunk_len, seg_l2, stats,
-                     step_t, lr, beta1, beta2, eps, clipnorm, grad_scale);
+                     chunk_seg, reinterpret_cast<const long long*>(chunk_beg), chunk_len, seg_first, seg_l2, partial,
+                     stats, step_t, lr, beta1, beta2, eps, clipnorm, grad_scale);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

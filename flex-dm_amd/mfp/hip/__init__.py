@@ -80,8 +80,8 @@ SIGNATURES = {
                                    c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mfp_adam_num_chunks": (c_int64, [POINTER(c_int32), c_int32]),
     "mfp_adam_chunk_table": (c_int32, [POINTER(c_int32), c_int32, POINTER(c_int32), POINTER(c_int64),
-                                       POINTER(c_int32)]),
-    "mfp_adam_keras": (c_int32, [c_void_p] * 8 + [c_int64, c_void_p, c_void_p, c_int32, c_void_p]
+                                       POINTER(c_int32), POINTER(c_int32)]),
+    "mfp_adam_keras": (c_int32, [c_void_p] * 9 + [c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]
                        + [c_float] * 6 + [c_void_p]),
     "mfp_cast_f32_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mfp_colsum_workspace_bytes": (c_size_t, [c_int32, c_int32]),

@@ -295,8 +295,11 @@ class AdamChunks:
         off = (ctypes.c_int32 * (nseg + 1))(*seg_off)
         n = lib.mfp_adam_num_chunks(off, nseg)
         cs, cb, cl = (ctypes.c_int32 * n)(), (ctypes.c_int64 * n)(), (ctypes.c_int32 * n)()
-        check(lib.mfp_adam_chunk_table(off, nseg, cs, cb, cl), "mfp_adam_chunk_table")
+        sf = (ctypes.c_int32 * (nseg + 1))()
+        check(lib.mfp_adam_chunk_table(off, nseg, cs, cb, cl, sf), "mfp_adam_chunk_table")
         self.nseg, self.nchunks = nseg, n
+        self.seg_first = torch.tensor(list(sf), dtype=torch.int32, device=device)
+        self.partial = torch.zeros((n, 2), dtype=torch.float32, device=device)
         self.chunk_seg = torch.tensor(list(cs), dtype=torch.int32, device=device)
         self.chunk_beg = torch.tensor(list(cb), dtype=torch.int64, device=device)
         self.chunk_len = torch.tensor(list(cl), dtype=torch.int32, device=device)
@@ -308,8 +311,8 @@ def adam_keras(w, g, m, v, shadow: Optional[torch.Tensor], chunks: AdamChunks, s
     lib = load()
     with _timed("adam_kernels", 0, w.numel() * (8 + 16 + 12 + (2 if shadow is not None else 0))):
       check(lib.mfp_adam_keras(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(chunks.chunk_seg),
-                             _ptr(chunks.chunk_beg), _ptr(chunks.chunk_len), chunks.nchunks,
-                             _ptr(seg_l2), _ptr(stats), chunks.nseg, _ptr(step_t), lr, beta1, beta2, eps,
+                             _ptr(chunks.chunk_beg), _ptr(chunks.chunk_len), _ptr(chunks.seg_first), chunks.nchunks,
+                             _ptr(seg_l2), _ptr(chunks.partial), _ptr(stats), chunks.nseg, _ptr(step_t), lr, beta1, beta2, eps,
                              clipnorm if clipnorm is not None else 0.0, grad_scale, _stream()),
           "mfp_adam_keras")
 

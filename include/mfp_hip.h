@@ -176,17 +176,20 @@ int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, const mfp_l
  *   g_eff *= clipnorm / max(||g_eff||_seg, clipnorm)   (Keras clipnorm, per variable)
  *   Keras Adam with lr_t = lr*sqrt(1-b2^t)/(1-b1^t), eps outside the sqrt.
  * stats f32 [nseg][2] receives {||g_eff||^2, sum w^2} (pre-update; sum w^2 gives the L2 loss).
+ * partial f32 [nchunks][2]: scratch for the per-chunk norm partials; they are combined per
+ * variable in a FIXED order (no float atomics) so that data-parallel replicas stay bit-identical.
  * shadow (bf16 copy of the updated weights, same layout) may be NULL.
  * step_t: device int32 scalar, incremented by the call before use (1-based).
  */
 int64_t mfp_adam_num_chunks(const int32_t* seg_off /*host [nseg+1]*/, int32_t nseg);
 int mfp_adam_chunk_table(const int32_t* seg_off /*host*/, int32_t nseg, int32_t* chunk_seg /*host*/,
-                         int64_t* chunk_beg /*host*/, int32_t* chunk_len /*host*/);
+                         int64_t* chunk_beg /*host*/, int32_t* chunk_len /*host*/,
+                         int32_t* seg_first /*host [nseg+1]*/);
 int mfp_adam_keras(float* w, const float* g, float* m, float* v, uint16_t* shadow,
                    const int32_t* chunk_seg, const int64_t* chunk_beg, const int32_t* chunk_len,
-                   int64_t nchunks, const float* seg_l2, float* stats, int32_t nseg, int32_t* step_t,
-                   float lr, float beta1, float beta2, float eps, float clipnorm, float grad_scale,
-                   mfp_stream_t stream);
+                   const int32_t* seg_first, int64_t nchunks, const float* seg_l2, float* partial,
+                   float* stats, int32_t nseg, int32_t* step_t, float lr, float beta1, float beta2,
+                   float eps, float clipnorm, float grad_scale, mfp_stream_t stream);
 int mfp_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, mfp_stream_t stream);
 
 /* dy = cdt( keep(seed,offset)[m][n] ? dx[m][n]/(1-p) : 0 ), colsum[n] = sum_m dy (bias grad).
