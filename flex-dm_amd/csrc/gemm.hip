@@ -24,6 +24,8 @@
 // four column bases 4NQ q + 4b.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -455,6 +457,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+#include "gemm_ws.h"
+
+int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu = n;
+  }
+  static int mt = 0;
+  if (mt == 0) { const char* e = getenv("MFP_GEMM_WS_MT"); mt = (e && e[0] == '4') ? 4 : 2; }
+  if (a->K == 256) return mt == 4 ? launch_ws_epi<8, 4>(a, p, ncu, st) : launch_ws_epi<8, 2>(a, p, ncu, st);
+  return launch_ws_epi<16, 2>(a, p, ncu, st);
+}
+
 template <typename T, bool AK, bool BK_, int MT, int NQ, int NBUF>
 int launch_one(const GemmParams& p0, int M, int N, int splitk, hipStream_t st) {
   using L = GemmLds<T, AK, BK_, MT, NQ, NBUF>;
@@ -580,6 +598,13 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   kchunk = ((kchunk + bk - 1) / bk) * bk;
   p.kchunk = kchunk;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const bool ws_off = getenv("MFP_GEMM_NO_WS") != nullptr;   // benchmarking only
+  if (!ws_off && ws_eligible(a, splitk)) {
+    int rcw = launch_ws_any(a, p, st);
+    if (rcw != MFP_OK) return rcw;
+    MFP_CHECK_LAUNCH();
+    return MFP_OK;
+  }
   int rc = a->in_dtype == MFP_BF16 ? launch_gemm<unsigned short>(a, p, splitk, st)
                                     : launch_gemm<float>(a, p, splitk, st);
   if (rc != MFP_OK) return rc;

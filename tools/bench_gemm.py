@@ -34,8 +34,13 @@ for name, layout, M, N, K, odt in shapes:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
+    # hipGraph replay: the Python/ctypes launch path (~15 us per call) must not be what is timed
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(reps): run()
+    gr.replay(); torch.cuda.synchronize()
     e0.record()
-    for _ in range(reps): run()
+    gr.replay()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     flops = 2.0 * M * N * K

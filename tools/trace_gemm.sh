@@ -3,4 +3,4 @@
 set -e
 cd "$(dirname "$0")/../flex-dm_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMFP_GEMM_TRACE -shared gemm.hip error.cpp -o ../../tools/libmfp_trace.so
-cd ../.. && python tools/trace_gemm.py
+cd ../.. && python tools/${TRACE_TOOL:-trace_gemm.py}
