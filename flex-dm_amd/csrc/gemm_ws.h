@@ -6,20 +6,23 @@
 //   decoder.py:39-43).
 //
 // Why a second kernel: on these shapes the weights are tiny (<= 700 KB) and re-used by all 32768
-// rows, while X and C stream through HBM exactly once.  The tile kernel in gemm.hip re-stages the
-// weight tile for every 64x128 output tile (2/3 of its load-path traffic) and its thousands of
-// short-lived workgroups run in lock-step load / multiply / store rounds (HBM ~38 % busy,
-// profiles/r01_gemm_qkv_timeline.txt).  Here instead:
-//   * ONE persistent workgroup per CU (4 waves, 1 per SIMD, up to 512 VGPRs each);
-//   * the workgroup's weight slice (BN = 256 columns x K=256, or 128 x 512: 128 KB) lives in
-//     REGISTERS for the whole kernel -- each wave holds its 16 NQ columns x K as MFMA fragments
-//     (128 VGPRs), loaded once;
-//   * X streams: 16 MT-row tiles, global -> registers (two tiles in flight) -> XOR-swizzled LDS
-//     (double-buffered, one barrier per tile) -> ds_read_b128 fragments shared by the 4 waves;
-//   * epilogue operands (residual / accumulate / ReLU mask) are prefetched one tile ahead so the
-//     in-order VMEM return queue never makes the epilogue wait behind the X prefetch;
-//   * blocks that share X rows (the N/BN column slices of one row group) are placed on the same
-//     XCD, so X is fetched from HBM once and re-read from that XCD's L2.
+// rows, while X and C stream through HBM exactly once -- the products are bound by the WRITE
+// stream (tools/ubench/hbm_write.hip: ~6.3 TB/s chip-wide = 11.7 B/clk per CU, and one wave gets
+// a 1 KB store accepted only every ~350 clk).  The tile kernel in gemm.hip re-stages the weight
+// tile for every 64x128 output tile and runs load / multiply / store rounds in lock-step.  Here:
+//   * ONE persistent workgroup per CU, 8 waves = 4 MATH waves + 4 MEMORY waves (2 per SIMD);
+//   * math waves keep the workgroup's weight slice (256 columns x K=256, or 128 x 512: 128 KB) in
+//     REGISTERS for the whole kernel (128 VGPRs of MFMA fragments per lane), read X fragments from
+//     LDS, multiply, add bias / ReLU and drop the tile into an LDS output stage -- they never
+//     touch vector memory, so a store that waits for the write path never stalls an MFMA;
+//   * memory waves do ALL vector memory: X tiles global -> registers (4 tiles in flight) ->
+//     XOR-swizzled LDS stage; epilogue operands (residual / accumulate / ReLU mask, prefetched
+//     two tiles ahead); and the output tile LDS -> (mask, dropout, residual) -> global as whole
+//     contiguous rows (1 KB per store instruction);
+//   * one barrier per tile orders both hand-offs (X stage t+1 filled / output stage t-1 drained
+//     while tile t is multiplied);
+//   * blocks that share X rows (the N/BN column slices of one row group) sit on the same XCD, so
+//     X comes from HBM once and is re-read from that XCD's L2.
 // Rows are split into `groups` contiguous ranges of 16-row units (ragged last tile per group).
 #pragma once
 
@@ -27,26 +30,31 @@ enum { WS_EPI_PLAIN = 0, WS_EPI_F32X = 1, WS_EPI_RELUBWD = 2 };
 
 // EPI: which extra epilogue operand streams in (none / f32 residual-or-accumulate / bf16 ReLU
 // mask); DROPOUT and OUT_BF16 are compile-time too: with no run-time flag branches and
-// out-of-range-dropping buffer stores the whole tile is ONE basic block, so the compiler's vmcnt
-// bookkeeping is exact (with control flow in the loop it falls back to vmcnt(0) per tile).
+// out-of-range-dropping buffer accesses every pipeline step is ONE basic block, so the compiler's
+// vmcnt bookkeeping is exact (with control flow in the loop it falls back to vmcnt(0) per tile).
 template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16>
-__global__ __launch_bounds__(256) void gemm_ws_kernel(GemmParams p, int groups, int slices) {
+__global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, int slices) {
   constexpr int NQ = 32 / KS, BM = 16 * MT, WBN = 16 * NQ, BN = 4 * WBN;
-  constexpr int ROWB = 64 * KS, CPR = ROWB / 16, STAGE = BM * ROWB;
+  constexpr int ROWB = 64 * KS, CPR = ROWB / 16, XSTAGE = BM * ROWB;      // X stage: [BM][K] bf16
   constexpr int A_CH = BM * CPR / 256;
-  static_assert((BM * CPR) % 256 == 0 && NQ >= 2, "tile/thread mismatch");
+  constexpr int OS = OUT_BF16 ? 2 : 4, OROWB = BN * OS, OCPR = OROWB / 16, OSTAGE = BM * OROWB;
+  constexpr int O_CH = BM * OCPR / 256;                                   // output chunks per memory thread
+  constexpr int OU = OUT_BF16 ? NQ / 2 : NQ;                              // 16-byte output units per lane and row
+  constexpr int XD = KS == 8 ? 4 : 2;   // X tiles in flight in registers (16 KB / 32 KB each)
+  constexpr int ED = 4;                 // rotating epilogue-operand sets (3 live: in use + two in flight)
+  static_assert((BM * CPR) % 256 == 0 && (BM * OCPR) % 256 == 0 && NQ >= 2, "tile/thread mismatch");
   constexpr unsigned int OOB = 0xFFFFFFF0u;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 stages of X
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* const xst = smem_raw;                 // 2 X stages
+  unsigned char* const ost = smem_raw + 2 * XSTAGE;    // 2 output stages
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
 #ifdef MFP_GEMM_TRACE
   int trace_i = 0;
 #define WS_STAMP() do { if (tid == 0 && trace_i < 24) p.trace[(long long)blockIdx.x * 24 + trace_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define WS_TSTAMP(t_, i_) do { if (tid == 0 && ((t_) == 4 || (t_) == 5)) p.trace[(long long)(256 + blockIdx.x) * 24 + ((t_) - 4) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WS_STAMP() do {} while (0)
-#define WS_TSTAMP(t_, i_) do {} while (0)
 #endif
   WS_STAMP();
 
@@ -63,256 +71,253 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(GemmParams p, int groups, 
   const int row_beg = u0 * 16, row_end = min(p.M, u1 * 16);
   const int ntiles = (u1 - u0 + MT - 1) / MT;
   if (ntiles <= 0) return;
-  const int n_wave = s * BN + wave * WBN;
-  // Output column of quad b for the lane group q (= lg of the output lane, = i >> 2 of the weight
-  // row feeding MFMA row i).  Chosen so that the four lane groups of one row write 64 CONTIGUOUS
-  // bytes per store instruction (f32: quad b at 16b + 4q; bf16: quad pair at 32(b/2) + 8q): the
-  // vector-memory path costs ~5 clk per 64-byte segment an instruction touches, so 16-byte pieces
-  // at a 32/64-byte stride made each store 2-4x as expensive (tools/ubench/hbm_write.hip).
-  auto colq = [&](int b, int q) {
-    return n_wave + (OUT_BF16 ? 32 * (b >> 1) + 8 * q + 4 * (b & 1) : 16 * b + 4 * q);
-  };
+  const int n_slice = s * BN;
 
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFFF, 0x00020000);
-  const void* xptr = (p.flags & MFP_GEMM_RESIDUAL) ? (const void*)p.residual
-                     : (EPI == WS_EPI_RELUBWD ? p.aux : (const void*)p.C);
-  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xptr), 0, 0x7FFFFFFF, 0x00020000);
-
-  // ---- X staging plan: chunk ch = tid + 256 c -> row ch / CPR, LDS slot ch % CPR holds the
-  // row's 16-byte chunk (slot ^ (row & 15)): the swizzle is applied on the SOURCE address so the
-  // ds_write stays linear and the fragment ds_read_b128 (16 rows x one chunk per lane group) is
-  // conflict-free.
-  unsigned int voa[A_CH];
-  int lsa[A_CH], rowc[A_CH];
+  if (wave < 4) {
+    // ======================================================================== MATH waves
+    // Output column (local to the wave's 16 NQ block) of quad b for lane group q: f32 16b + 4q,
+    // bf16 32(b/2) + 8q + 4(b%2) -- the lane's 16-byte unit (4 f32 / 8 bf16) is one stage chunk.
+    auto colq = [&](int b, int q) { return OUT_BF16 ? 32 * (b >> 1) + 8 * q + 4 * (b & 1) : 16 * b + 4 * q; };
+    const int n_wave = n_slice + wave * WBN;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, 0x7FFFFFFF, 0x00020000);
+    // weight row feeding MFMA row i = 4q + e of quad b is column colq(b, q) + e (transposed MFMA:
+    // the output lane (li, lg) then holds C[row li][colq(b, lg) + 0..3]).
+    bf16x8 wf[NQ][KS];
 #pragma unroll
-  for (int c = 0; c < A_CH; ++c) {
-    const int ch = tid + c * 256, row = ch / CPR, pc = ch % CPR, sc = pc ^ (row & 15);
-    rowc[c] = row;
-    voa[c] = (unsigned int)((row * p.lda + sc * 8) * 2);
-    lsa[c] = row * ROWB + pc * 16;
-  }
-  constexpr int XD = 4;   // X tiles in flight in registers (HBM latency under load ~2.7 us >> one 1.4 us step)
-  u32x4 xa[XD][A_CH];
-  auto gload = [&](u32x4 (&dst)[A_CH], int t) {
-    // branch-free: a dead tile / row past M turns the offset into 0xFFFFFFFF (out of range ->
-    // zeros, no access); pure integer arithmetic so the loop body stays one basic block.
-    const int row0 = row_beg + t * BM;
-    const int live = (t - ntiles) >> 31;                 // -1 while t < ntiles
-    const int so = (row0 * p.lda * 2) & live;
+    for (int b = 0; b < NQ; ++b) {
+      const int n = n_wave + colq(b, li >> 2) + (li & 3);
 #pragma unroll
-    for (int c = 0; c < A_CH; ++c) {
-      const int ok = live & ((row0 + rowc[c] - p.M) >> 31);
-      const unsigned int vo = voa[c] | ~(unsigned int)ok;
-      dst[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, vo, so, 0));
-    }
-  };
-  auto lstore = [&](const u32x4 (&src)[A_CH], int stage) {
-#pragma unroll
-    for (int c = 0; c < A_CH; ++c) *reinterpret_cast<u32x4*>(smem_raw + stage * STAGE + lsa[c]) = src[c];
-  };
-
-  // ---- epilogue operand prefetch (one tile ahead)
-  f32x4 ex[2][EPI == WS_EPI_F32X ? MT : 1][EPI == WS_EPI_F32X ? NQ : 1];
-  u32x4 exa[2][EPI == WS_EPI_RELUBWD ? MT : 1][EPI == WS_EPI_RELUBWD ? NQ / 2 : 1];   // bf16, per quad pair
-  unsigned int rc[2][MT];
-  // ROWSKIP off: read (and ignore) bytes of X instead of a null rowcode pointer
-  const unsigned int rsmask = (p.flags & MFP_GEMM_ROWSKIP) ? 0xFFu : 0u;
-  const unsigned char* rcp = (p.flags & MFP_GEMM_ROWSKIP) ? p.rowcode : reinterpret_cast<const unsigned char*>(p.A);
-  auto xload = [&](int set, int t) {
-    const int row0 = row_beg + t * BM;
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-      const int row = row0 + a * 16 + li;
-      const int rok = ((t - ntiles) >> 31) & ((row - row_end) >> 31);
-      if (EPI == WS_EPI_F32X) rc[set][a] = rcp[min(row, p.M - 1)];
-#pragma unroll
-      for (int b = 0; b < NQ; ++b) {
-        const int col = colq(b, lg);
-        const unsigned int bad = ~(unsigned int)(rok & ((col - p.N) >> 31));
-        if (EPI == WS_EPI_F32X) {
-          const unsigned int vo = (unsigned int)((row * p.ldc + col) * 4) | bad;
-          ex[set][a][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
-        }
-        if (EPI == WS_EPI_RELUBWD && (b & 1) == 0) {   // OUT_BF16 layout: quads b, b+1 are adjacent
-          const unsigned int vo = (unsigned int)((row * p.ldc + col) * 2) | bad;
-          exa[set][a][b >> 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
-        }
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned int vo = n < p.N ? (unsigned int)((n * p.ldb + ks * 32 + lg * 8) * 2) : OOB;
+        wf[b][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, 0, 0));
       }
     }
-  };
-
-  // ---- prologue: first two X tiles in flight, then the stationary weight fragments
+    f32x4 bias4[NQ];
 #pragma unroll
-  for (int i = 0; i < XD; ++i) gload(xa[i], i);
-  // weight row feeding MFMA row i = 4q + e of quad b is column colq(b, q) + e (transposed MFMA:
-  // the output lane (li, lg) then holds C[row li][colq(b, lg) + 0..3]).
-  bf16x8 wf[NQ][KS];
-#pragma unroll
-  for (int b = 0; b < NQ; ++b) {
-    const int n = colq(b, li >> 2) + (li & 3);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const unsigned int vo = n < p.N ? (unsigned int)((n * p.ldb + ks * 32 + lg * 8) * 2) : OOB;
-      wf[b][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, 0, 0));
+    for (int b = 0; b < NQ; ++b) {
+      const int col = n_wave + colq(b, lg);
+      bias4[b] = ((p.flags & MFP_GEMM_BIAS) && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col)
+                                                          : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-  }
-  f32x4 bias4[NQ];
+    const float relu_floor = (p.flags & MFP_GEMM_RELU) ? 0.f : -3.0e38f;   // branch-free ReLU switch
+    // fragment reads: row a*16 + li, logical chunk 4 ks + lg stored at slot chunk ^ li
+    const unsigned char* frag_base = xst + li * ROWB;
+    // output stage writes: row a*16 + li, logical 16-byte chunk c at slot c ^ (li & 7)
+    unsigned char* ostw = ost + li * OROWB;
+    int oslot[OU];
 #pragma unroll
-  for (int b = 0; b < NQ; ++b) {
-    const int col = colq(b, lg);
-    bias4[b] = ((p.flags & MFP_GEMM_BIAS) && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col)
-                                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  WS_STAMP();
-  lstore(xa[0], 0);
-  WS_STAMP();
-  gload(xa[0], XD);
-
-  f32x4 acc[2][MT][NQ];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) acc[1][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};   // read (masked) by step 0
-
-  const float inv_keep = DROPOUT ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const unsigned long long rng_off =
-      p.offset + ((DROPOUT && p.step_ptr) ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
-  const float relu_floor = (p.flags & MFP_GEMM_RELU) ? 0.f : -3.0e38f;   // branch-free ReLU switch
-  const unsigned char* frag_base = smem_raw + li * ROWB;
-  // Every prologue load (weights, bias, first tiles) retires HERE: a first use inside the loop
-  // would make the compiler place its preheader-derived vmcnt(N<=9) waits in the loop body, which
-  // in steady state drain the X prefetch and the stores every tile.
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  WS_STAMP();
-  __syncthreads();
-  WS_STAMP();
-
-  // One pipeline step t (0 .. ntiles):  MFMAs of tile t (stage `cur`, accumulators acc[cur])
-  // INTERLEAVED with the epilogue of tile t-1 (acc[cur ^ 1], operands ex[cur ^ 1]) and with the
-  // staging traffic (X(t+1) registers -> LDS, X(t+3) global -> registers).  With one wave per SIMD
-  // nothing else overlaps the ~600 clk of epilogue VALU and the ~150 clk each VMEM instruction
-  // needs to issue with the 1024 clk of MFMA work; back to back they made a tile 2900 clk.
-  // Step 0 has no epilogue (masked rows), step ntiles multiplies a stale stage (never stored).
-  auto tile = [&](auto tc, int t) {
-    constexpr int cur = decltype(tc)::value & 1, xi = (decltype(tc)::value + 1) % XD;
-    if (EPI != WS_EPI_PLAIN) xload(cur, t);      // consumed by the next step
-    const unsigned char* st = frag_base + cur * STAGE;
-    bf16x8 xf[KS][MT];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-        xf[ks][a] = *reinterpret_cast<const bf16x8*>(st + a * 16 * ROWB + (((ks * 4 + lg) ^ li) * 16));
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NQ; ++b)
-#ifdef WS_NO_MFMA
-          acc[cur][a][b] = (ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[cur][a][b]) + __builtin_bit_cast(f32x4, xf[ks][a]) * __builtin_bit_cast(f32x4, wf[b][ks])[0];
-#else
-          acc[cur][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              wf[b][ks], xf[ks][a], ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[cur][a][b], 0, 0, 0);
-#endif
-    lstore(xa[xi], cur ^ 1);          // X(t+1): loaded XD steps ago
-#ifndef WS_NO_LOAD
-    gload(xa[xi], t + 1 + XD);
-#endif
-    // ---- epilogue of tile t-1 (stores past row_end / N get an out-of-range offset and are dropped)
-    const int row0 = row_beg + (t - 1) * BM;
-    const int tok = ~((t - 1) >> 31);            // 0 at step 0
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-      const int row = row0 + a * 16 + li;
-      const int rok = tok & ((row - row_end) >> 31);
-      const bool skip = EPI == WS_EPI_F32X && (rc[cur ^ 1][a] & rsmask) != 0;
-      f32x4 v[NQ];
-#pragma unroll
-      for (int b = 0; b < NQ; ++b) {
-        const int col = colq(b, lg);
-        f32x4 x = acc[cur ^ 1][a][b] + bias4[b];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], relu_floor);
-        if (EPI == WS_EPI_RELUBWD) {
-          const unsigned int h0 = exa[cur ^ 1][a][b >> 1][2 * (b & 1)], h1 = exa[cur ^ 1][a][b >> 1][2 * (b & 1) + 1];
-          x[0] = bf16_to_f32((unsigned short)(h0 & 0xffff)) > 0.f ? x[0] : 0.f;
-          x[1] = bf16_to_f32((unsigned short)(h0 >> 16)) > 0.f ? x[1] : 0.f;
-          x[2] = bf16_to_f32((unsigned short)(h1 & 0xffff)) > 0.f ? x[2] : 0.f;
-          x[3] = bf16_to_f32((unsigned short)(h1 >> 16)) > 0.f ? x[3] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = skip ? 0.f : x[r];
-        if (DROPOUT) {
-          unsigned int rnd[4];
-          philox4x32(p.seed, (unsigned int)row, (unsigned int)(col >> 2), rng_off, rnd);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = philox_keep(rnd[r], p.dropout_p) ? x[r] * inv_keep : 0.f;
-        }
-        if (EPI == WS_EPI_F32X) x += ex[cur ^ 1][a][b];
-        v[b] = x;
-      }
-      if (OUT_BF16) {   // N % 8 == 0 (host): 16-byte units of 8 columns
-#pragma unroll
-        for (int b = 0; b < NQ; b += 2) {
-          const int col = colq(b, lg);
-          const unsigned int vo = (unsigned int)((row * p.ldc + col) * 2) | ~(unsigned int)(rok & ((col - p.N) >> 31));
-          const u32x4 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
-                            pack_bf16x2(v[b + 1][0], v[b + 1][1]), pack_bf16x2(v[b + 1][2], v[b + 1][3])};
-#ifndef WS_NO_STORE
-          __builtin_amdgcn_raw_buffer_store_b128(pk, rsc, vo, 0, 0);
-#else
-          if (vo == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(pk, rsc, vo, 0, 0);
-#endif
-        }
-      } else {
-#pragma unroll
-        for (int b = 0; b < NQ; ++b) {
-          const int col = colq(b, lg);
-          const unsigned int vo = (unsigned int)((row * p.ldc + col) * 4) | ~(unsigned int)(rok & ((col - p.N) >> 31));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[b]), rsc, vo, 0, 0);
-        }
-      }
-    }
-    // Issue order: every fragment ds_read, then per 8 MFMAs (128 clk of matrix pipe) one VMEM
-    // instruction and a slice of the epilogue VALU / ds_write work in the MFMA shadow.
-    constexpr int NMFMA = KS * MT * NQ, NVMEM = A_CH + MT * (OUT_BF16 ? NQ / 2 : NQ) + (EPI == WS_EPI_PLAIN ? 0 : MT * NQ);
-    constexpr int GROUPS = NMFMA / 8;
-    __builtin_amdgcn_sched_group_barrier(0x100, KS * MT, 0);
-#pragma unroll
-    for (int gI = 0; gI < GROUPS; ++gI) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                   // 8 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x030, (NVMEM + GROUPS - 1) / GROUPS, 0);       // VMEM r/w
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                    // ds_write
-      __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);                                  // VALU
-    }
+    for (int u = 0; u < OU; ++u) oslot[u] = ((wave * 4 * OU + 4 * u + lg) ^ (li & 7)) * 16;
+    // Every prologue load retires HERE: a first use inside the loop would make the compiler place
+    // its preheader-derived vmcnt waits in the loop body.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    WS_STAMP();
     __syncthreads();
     WS_STAMP();
-  };
 
-  // Pairs inside the loop, odd tail after it: a conditional second half inside the loop gives
-  // the compiler a (never taken) path with fewer VMEM ops between a load and its use, and it
-  // sizes every vmcnt for that path.  ntiles + 1 steps in total (the last one only drains).
-  static_assert(XD == 2 || XD == 4, "step loop is unrolled by XD");
-  int t = 0;
-  if (XD == 4) {
+    auto step = [&](auto tc, int t) {
+      constexpr int cur = decltype(tc)::value & 1;
+      const unsigned char* st = frag_base + cur * XSTAGE;
+      f32x4 acc[MT][NQ];
+      bf16x8 xf[KS][MT];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+          xf[ks][a] = *reinterpret_cast<const bf16x8*>(st + a * 16 * ROWB + (((ks * 4 + lg) ^ li) * 16));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < NQ; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                wf[b][ks], xf[ks][a], ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[a][b], 0, 0, 0);
+      // fragment reads run two k-steps ahead of their MFMAs (the memory waves sharing the SIMD
+      // issue no MFMAs, so nothing else hides the ds_read latency)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NQ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+      }
+      unsigned char* ow = ostw + cur * OSTAGE;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        f32x4 v[NQ];
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+          v[b] = acc[a][b] + bias4[b];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[b][r] = fmaxf(v[b][r], relu_floor);
+        }
+        if (OUT_BF16) {
+#pragma unroll
+          for (int b = 0; b < NQ; b += 2) {
+            const u32x4 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
+                              pack_bf16x2(v[b + 1][0], v[b + 1][1]), pack_bf16x2(v[b + 1][2], v[b + 1][3])};
+            *reinterpret_cast<u32x4*>(ow + a * 16 * OROWB + oslot[b >> 1]) = pk;
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < NQ; ++b)
+            *reinterpret_cast<f32x4*>(ow + a * 16 * OROWB + oslot[OUT_BF16 ? 0 : b]) = v[b];
+        }
+      }
+      __syncthreads();
+      WS_STAMP();
+    };
+    int t = 0;
     for (; t + 3 <= ntiles; t += 4) {
-      tile(std::integral_constant<int, 0>{}, t);
-      tile(std::integral_constant<int, 1>{}, t + 1);
-      tile(std::integral_constant<int, 2>{}, t + 2);
-      tile(std::integral_constant<int, 3>{}, t + 3);
+      step(std::integral_constant<int, 0>{}, t);
+      step(std::integral_constant<int, 1>{}, t + 1);
+      step(std::integral_constant<int, 2>{}, t + 2);
+      step(std::integral_constant<int, 3>{}, t + 3);
     }
-    if (t <= ntiles) tile(std::integral_constant<int, 0>{}, t);
-    if (t + 1 <= ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
-    if (t + 2 <= ntiles) tile(std::integral_constant<int, 2>{}, t + 2);
+    if (t <= ntiles) step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 <= ntiles) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 <= ntiles) step(std::integral_constant<int, 2>{}, t + 2);
   } else {
-    for (; t + 1 <= ntiles; t += 2) {
-      tile(std::integral_constant<int, 0>{}, t);
-      tile(std::integral_constant<int, 1>{}, t + 1);
+    // ====================================================================== MEMORY waves
+    const int mt = tid - 256;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFFF, 0x00020000);
+    const void* xptr = (p.flags & MFP_GEMM_RESIDUAL) ? (const void*)p.residual
+                       : (EPI == WS_EPI_RELUBWD ? p.aux : (const void*)p.C);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xptr), 0, 0x7FFFFFFF, 0x00020000);
+
+    // ---- X staging plan: chunk ch = mt + 256 c -> row ch / CPR, LDS slot ch % CPR holds the
+    // row's 16-byte chunk (slot ^ (row & 15)): the swizzle is applied on the SOURCE address so
+    // the ds_write stays linear and the fragment ds_read_b128 (16 rows x one chunk per lane
+    // group) is conflict-free.
+    static_assert(256 % CPR == 0, "X chunk column must not depend on c");
+    constexpr int XRS = 256 / CPR;                   // rows between a thread's consecutive chunks
+    const int xrow0 = mt / CPR, xpc = mt % CPR;
+    unsigned int voa[A_CH];
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) {
+      const int row = xrow0 + c * XRS, sc = xpc ^ (row & 15);
+      voa[c] = (unsigned int)((row * p.lda + sc * 8) * 2);
     }
-    if (t <= ntiles) tile(std::integral_constant<int, 0>{}, t);
+    const int lsa0 = xrow0 * ROWB + xpc * 16;
+    u32x4 xa[XD][A_CH];
+    auto gload = [&](u32x4 (&dst)[A_CH], int t) {
+      // branch-free: a dead tile / row past M turns the offset into 0xFFFFFFFF (out of range ->
+      // zeros, no access); pure integer arithmetic so the step stays one basic block.
+      const int row0 = row_beg + t * BM;
+      const int live = (t - ntiles) >> 31;                 // -1 while t < ntiles
+      const int so = (row0 * p.lda * 2) & live;
+#pragma unroll
+      for (int c = 0; c < A_CH; ++c) {
+        const int ok = live & ((row0 + xrow0 + c * XRS - p.M) >> 31);
+        const unsigned int vo = voa[c] | ~(unsigned int)ok;
+        dst[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, vo, so, 0));
+      }
+    };
+    auto lstore = [&](const u32x4 (&src)[A_CH], int stage) {
+#pragma unroll
+      for (int c = 0; c < A_CH; ++c) *reinterpret_cast<u32x4*>(xst + stage * XSTAGE + lsa0 + c * XRS * ROWB) = src[c];
+    };
+
+    // ---- output plan: chunk ch = mt + 256 i -> stage row ch / OCPR, logical chunk ch % OCPR: a
+    // wave instruction moves 64 consecutive chunks = 1 KB of contiguous output.  256 % OCPR == 0,
+    // so a thread keeps ONE chunk column and walks rows orow0 + i * ORS (nothing per-chunk is kept
+    // in registers: the memory waves need theirs for data in flight).
+    static_assert(256 % OCPR == 0, "output chunk column must not depend on i");
+    constexpr int ORS = 256 / OCPR;
+    const int orow0 = mt / OCPR, oc = mt % OCPR;
+    const int ocol = n_slice + oc * (16 / OS);
+    const unsigned int ocolb = (unsigned int)(ocol * OS);           // byte offset inside an output row
+    const unsigned int ocbad = ocol < p.N ? 0u : 0xFFFFFFFFu;
+    auto ols = [&](int i) { const int row = orow0 + i * ORS; return row * OROWB + ((oc ^ (row & 7)) * 16); };
+    // epilogue operands, requested two steps before their tile is drained
+    u32x4 ex[ED][EPI == WS_EPI_PLAIN ? 1 : O_CH];
+    unsigned int rcbits[ED];     // bit i: row of chunk i is skipped (ROWSKIP)
+    // ROWSKIP off: read (and ignore) bytes of X instead of a null rowcode pointer
+    const unsigned int rsmask = (p.flags & MFP_GEMM_ROWSKIP) ? 0xFFu : 0u;
+    const unsigned char* rcp = (p.flags & MFP_GEMM_ROWSKIP) ? p.rowcode : reinterpret_cast<const unsigned char*>(p.A);
+    auto xload = [&](int set, int t) {
+      const int row0 = row_beg + t * BM + orow0;
+      const int tok = ((t - ntiles) >> 31) & ~(t >> 31);
+      unsigned int bits = 0;
+#pragma unroll
+      for (int i = 0; i < O_CH; ++i) {
+        const int row = row0 + i * ORS;
+        const unsigned int bad = ocbad | ~(unsigned int)(tok & ((row - row_end) >> 31));
+        if (EPI == WS_EPI_F32X) bits |= ((rcp[max(0, min(row, p.M - 1))] & rsmask) ? 1u : 0u) << i;
+        if (EPI != WS_EPI_PLAIN) {   // same element size as the output (f32 residual / bf16 mask)
+          const unsigned int vo = ((unsigned int)(row * p.ldc * OS) + ocolb) | bad;
+          ex[set][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, 0, 0));
+        }
+      }
+      rcbits[set] = bits;
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int i = 0; i < XD; ++i) gload(xa[i], i);
+    if (EPI != WS_EPI_PLAIN) xload(0, 0);
+    lstore(xa[0], 0);
+    gload(xa[0], XD);
+    const float inv_keep = DROPOUT ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+    const unsigned long long rng_off =
+        p.offset + ((DROPOUT && p.step_ptr) ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), see the math waves
+    __syncthreads();
+
+    // step t: X(t+1) registers -> LDS stage; X(t+1+XD) global -> registers; operands of tile t+1
+    // requested; output tile t-1: LDS stage -> epilogue -> global
+    auto step = [&](auto tc, int t) {
+      constexpr int cur = decltype(tc)::value & 1, xi = (decltype(tc)::value + 1) % XD;
+      constexpr int eset = (decltype(tc)::value + ED - 1) % ED, pset = (decltype(tc)::value + 1) % ED;
+      lstore(xa[xi], cur ^ 1);          // X(t+1): loaded XD steps ago
+      gload(xa[xi], t + 1 + XD);
+      const int row0 = row_beg + (t - 1) * BM + orow0;
+      const int tok = ~((t - 1) >> 31);            // 0 at step 0 (no tile -1)
+      const unsigned char* orr = ost + (cur ^ 1) * OSTAGE;
+#pragma unroll
+      for (int i = 0; i < O_CH; ++i) {
+        const int row = row0 + i * ORS;
+        const unsigned int bad = ocbad | ~(unsigned int)(tok & ((row - row_end) >> 31));
+        u32x4 raw = *reinterpret_cast<const u32x4*>(orr + ols(i));
+        if (EPI == WS_EPI_RELUBWD) {   // bf16 values, bf16 mask: keep where the saved activation > 0
+          const u32x4 h = ex[eset][i];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned int lo = bf16_to_f32((unsigned short)(h[r] & 0xffffu)) > 0.f ? 0xFFFFu : 0u;
+            const unsigned int hi = bf16_to_f32((unsigned short)(h[r] >> 16)) > 0.f ? 0xFFFF0000u : 0u;
+            raw[r] &= lo | hi;
+          }
+        }
+        if (EPI == WS_EPI_F32X) {
+          f32x4 x = __builtin_bit_cast(f32x4, raw);
+          const bool skip = ((rcbits[eset] >> i) & 1u) != 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = skip ? 0.f : x[r];
+          if (DROPOUT) {
+            unsigned int rnd[4];
+            philox4x32(p.seed, (unsigned int)row, ocolb >> 4, rng_off, rnd);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = philox_keep(rnd[r], p.dropout_p) ? x[r] * inv_keep : 0.f;
+          }
+          x += __builtin_bit_cast(f32x4, ex[eset][i]);
+          raw = __builtin_bit_cast(u32x4, x);
+        }
+        const unsigned int vo = ((unsigned int)(row * p.ldc * OS) + ocolb) | bad;
+        __builtin_amdgcn_raw_buffer_store_b128(raw, rsc, vo, 0, 0);
+      }
+      if (EPI != WS_EPI_PLAIN) xload(pset, t + 1);   // after the drain: set `eset` is dead, 3 sets live
+      __syncthreads();
+    };
+    int t = 0;
+    for (; t + 3 <= ntiles; t += 4) {
+      step(std::integral_constant<int, 0>{}, t);
+      step(std::integral_constant<int, 1>{}, t + 1);
+      step(std::integral_constant<int, 2>{}, t + 2);
+      step(std::integral_constant<int, 3>{}, t + 3);
+    }
+    if (t <= ntiles) step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 <= ntiles) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 <= ntiles) step(std::integral_constant<int, 2>{}, t + 2);
   }
 #ifdef MFP_GEMM_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -340,8 +345,8 @@ inline bool ws_eligible(const mfp_gemm_args* a, int splitk) {
 
 template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16>
 int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
-  constexpr int NQ = 32 / KS, BN = 64 * NQ, STAGE = 16 * MT * 64 * KS;
-  constexpr int lds = 2 * STAGE;
+  constexpr int NQ = 32 / KS, BN = 64 * NQ, XSTAGE = 16 * MT * 64 * KS, OSTAGE = 16 * MT * BN * (OUT_BF16 ? 2 : 4);
+  constexpr int lds = 2 * XSTAGE + 2 * OSTAGE;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16>),
@@ -361,7 +366,7 @@ int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
     groups = (ncu / slices) / 8 * 8;
     if (groups < 8) groups = 8;
   }
-  hipLaunchKernelGGL((gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16>), dim3(groups * slices), dim3(256), lds, st, p,
+  hipLaunchKernelGGL((gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16>), dim3(groups * slices), dim3(512), lds, st, p,
                      groups, slices);
   return MFP_OK;
 }

@@ -270,6 +270,9 @@ class DecoderLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(fctx, h, ctx: StepCtx, keys: List[dict]):
+        # the unused output gradients (sums, logits) must NOT be materialised: autograd would
+        # zero-fill a [T, Upad] f32 tensor (181 MB at the Crello config) every step
+        fctx.set_materialize_grads(False)
         h_c = ctx.to_cdt(h.contiguous())
         logits = _heads_fwd(ctx, h_c)
         dl = ctx.store.scratch("dlogits", logits.shape, ctx.cdt)   # zeroed once: pad columns stay 0

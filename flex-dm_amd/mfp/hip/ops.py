@@ -158,6 +158,8 @@ def wgrad_splitk(T: int, M: int, N: int) -> int:
     """Split the token contraction so that ~2 workgroups per CU are in flight."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     sk = max(1, min(32, 288 // max(tiles, 1)))
+    if sk >= 8:
+        sk = (sk + 4) // 8 * 8   # multiples of 8: the kernel then keeps a k-chunk's tiles on one XCD
     while sk > 1 and T // sk < 256:
         sk //= 2
     return sk
