@@ -441,20 +441,29 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
 }
 
 // out[m][n] (+)= sum_z ws[z][m][n];  colsum[m] = sum_z ws_col[z][m].  N % 4 == 0.
+// Block = 32 float4 outputs x 8 z-groups (the group sums meet in LDS): a 256x256 gradient gives
+// 512 workgroups with splitk/8 loads per thread instead of 64 workgroups walking all splitk slabs.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws,
                                                             const float* __restrict__ ws_col,
                                                             float* __restrict__ C, float* __restrict__ colsum,
                                                             int M, int N, int ldc, int splitk, int accum) {
+  __shared__ float4 red[8][32];
   const long long total4 = (long long)M * N / 4;
   const long long total = (long long)M * N;
-  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4;
-       i4 += (long long)gridDim.x * blockDim.x) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int z = 0; z < splitk; ++z) {
+  const int q = threadIdx.x & 31, zg = threadIdx.x >> 5;
+  const long long i4 = (long long)blockIdx.x * 32 + q;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i4 < total4) {
+    for (int z = zg; z < splitk; z += 8) {
       const float4 v = *reinterpret_cast<const float4*>(ws + (long long)z * total + i4 * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  }
+  red[zg][q] = s;
+  __syncthreads();
+  if (zg == 0 && i4 < total4) {
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { const float4 v = red[g][q]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     const long long idx = i4 * 4, m = idx / N, n = idx % N;
     float4* c = reinterpret_cast<float4*>(C + m * ldc + n);
     if (accum) { const float4 o = *c; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
@@ -462,9 +471,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
   if (colsum != nullptr) {
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
-      float s = 0.f;
-      for (int z = 0; z < splitk; ++z) s += ws_col[(long long)z * M + m];
-      colsum[m] = s;
+      float t = 0.f;
+      for (int z = 0; z < splitk; ++z) t += ws_col[(long long)z * M + m];
+      colsum[m] = t;
     }
   }
 }
@@ -622,8 +631,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   MFP_CHECK_LAUNCH();
   if (ws_path) {
     long long total = (long long)a->M * a->N / 4;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((total + 31) / 32);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ws_col,
                        reinterpret_cast<float*>(a->C),
                        (a->flags & MFP_GEMM_COLSUM_A) ? a->colsum : nullptr, a->M, a->N, a->ldc,

@@ -223,9 +223,8 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
   }
 #undef LN_BWD
   MFP_CHECK_LAUNCH();
-  launch_reduce_rows(part, dgamma, dbeta, D, nblk, 2 * D, 3 * D, st);
-  MFP_CHECK_LAUNCH();
-  if (ddrop != nullptr) launch_reduce_rows(part + 2 * D, drop_colsum, drop_colsum, D, nblk, D, 3 * D, st);
+  // one launch: columns [0,D) -> dgamma, [D,2D) -> dbeta, [2D,3D) -> dropout bias gradient
+  launch_reduce_rows3(part, dgamma, dbeta, drop_colsum, D, 2 * D, nblk, ddrop != nullptr ? 3 * D : 2 * D, 3 * D, st);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -1,39 +1,56 @@
-// out[c] = sum_{p<P} part[p*pstride + c], c < N.  Block = 32 columns x 8 partial groups; the
-// 8 group sums meet in LDS.  Grid = ceil(N/32): full-chip parallel for the [P][N] partial
-// buffers of the LN / colsum / embedding backward kernels (all a few MB at most).
+// out[c] = sum_{p<P} part[p*pstride + c], c < N, routed to up to three output arrays by column
+// range (c < split1 -> out0, c < split2 -> out1, else out2).  Block = COLS columns x (256/COLS)
+// partial groups whose sums meet in LDS; grid = ceil(N/COLS).  Two shapes: COLS = 32 for the big
+// [P][N] partial buffers (embedding tables), COLS = 8 for the few-hundred-column LayerNorm /
+// bias partials, where 32-column blocks would leave the chip to 16-24 workgroups each walking
+// P/8 dependent loads (measured 9 us per launch on the critical path).
 #pragma once
 #include "common.h"
 
+template <int COLS>
 __global__ __launch_bounds__(256) static void reduce_rows_kernel(const float* __restrict__ part,
                                                                  float* __restrict__ out0,
-                                                                 float* __restrict__ out1, int split,
-                                                                 int P, long long N, long long pstride) {
-  __shared__ float red[8][33];
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const long long c = (long long)blockIdx.x * 32 + col;
+                                                                 float* __restrict__ out1,
+                                                                 float* __restrict__ out2, long long split1,
+                                                                 long long split2, int P, long long N,
+                                                                 long long pstride) {
+  constexpr int G = 256 / COLS;
+  __shared__ float red[G][COLS + 1];
+  const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
+  const long long c = (long long)blockIdx.x * COLS + col;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < N) {
     int p = grp;
-    for (; p + 24 < P; p += 32) {
+    for (; p + 3 * G < P; p += 4 * G) {
       s0 += part[(long long)p * pstride + c];
-      s1 += part[(long long)(p + 8) * pstride + c];
-      s2 += part[(long long)(p + 16) * pstride + c];
-      s3 += part[(long long)(p + 24) * pstride + c];
+      s1 += part[(long long)(p + G) * pstride + c];
+      s2 += part[(long long)(p + 2 * G) * pstride + c];
+      s3 += part[(long long)(p + 3 * G) * pstride + c];
     }
-    for (; p < P; p += 8) s0 += part[(long long)p * pstride + c];
+    for (; p < P; p += G) s0 += part[(long long)p * pstride + c];
   }
   red[grp][col] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (grp == 0 && c < N) {
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += red[g][col];
-    if (c < split) out0[c] = s; else out1[c - split] = s;
+    for (int g = 0; g < G; ++g) s += red[g][col];
+    if (c < split1) out0[c] = s;
+    else if (c < split2) out1[c - split1] = s;
+    else out2[c - split2] = s;
   }
 }
 
+static inline void launch_reduce_rows3(const float* part, float* out0, float* out1, float* out2, long long split1,
+                                       long long split2, int P, long long N, long long pstride, hipStream_t st) {
+  if (N <= 8192)
+    hipLaunchKernelGGL(reduce_rows_kernel<8>, dim3((unsigned)((N + 7) / 8)), dim3(256), 0, st, part, out0, out1, out2,
+                       split1, split2, P, N, pstride);
+  else
+    hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, part, out0, out1,
+                       out2, split1, split2, P, N, pstride);
+}
 static inline void launch_reduce_rows(const float* part, float* out0, float* out1, long long split, int P,
                                       long long N, long long pstride, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, part, out0, out1,
-                     (int)split, P, N, pstride);
+  launch_reduce_rows3(part, out0, out1, out1, split, N, P, N, pstride, st);
 }
