@@ -181,8 +181,9 @@ class BlockFn(torch.autograd.Function):
         d_o2 = ctx.handoff.pop(i, None)   # produced by the LN1 backward of block i+1 (fused)
         if d_o2 is None:
             d_o2 = ops.dropout_bwd(dx2, cdt, st.grad(p + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * i + 2, ctx.step_ptr)
-        dh = ops.gemm(d_o2, st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True, b_kmajor=False,
-                      out_dtype=cdt, relu_bwd_aux=h)
+        wt = st.cwt(p + "mlp/dense_1/kernel")     # [2D][D]: dgrad as a k-major product when kept
+        dh = ops.gemm(d_o2, wt if wt is not None else st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True,
+                      b_kmajor=wt is not None, out_dtype=cdt, relu_bwd_aux=h)
 
         def wgrads_mlp():
             ops.gemm(d_o2, h, D, 2 * D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_1/kernel"),
@@ -190,15 +191,18 @@ class BlockFn(torch.autograd.Function):
             ops.gemm(dh, y2, 2 * D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_0/kernel"),
                      colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
         ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
-        dy2 = ops.gemm(dh, st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True, b_kmajor=False, out_dtype=cdt)
+        wt = st.cwt(p + "mlp/dense_0/kernel")     # [D][2D]
+        dy2 = ops.gemm(dh, wt if wt is not None else st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True,
+                       b_kmajor=wt is not None, out_dtype=cdt)
         # LN2 backward also emits the masked/cast gradient of the attention Dropout + its bias grad
         dx1, d_o1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
                                       st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
                                       drop=(st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
                                             ctx.step_ptr))
         # ---- attention: x1 = x + drop(a Wo + bo)
-        da = ops.gemm(d_o1, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=False,
-                      out_dtype=cdt)
+        wt = st.cwt(p + "attn/combine_heads/kernel")
+        da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True,
+                      b_kmajor=wt is not None, out_dtype=cdt)
         dqkv = ops.attention_bwd(qkv, ctx.nvalid, a, da, lse, B, S, NUM_HEADS)
 
         def wgrads_attn():

@@ -326,6 +326,26 @@ def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
     return dst
 
 
+class TransposeTable:
+    """Device table of the [rows][cols] matrices (flat offset, rows, cols) whose transposed bf16
+    copy mfp_transpose_cast_bf16 maintains."""
+
+    def __init__(self, segs, device):
+        self.nseg = len(segs)
+        self.off = torch.tensor([s[0] for s in segs], dtype=torch.int64, device=device)
+        self.rows = torch.tensor([s[1] for s in segs], dtype=torch.int32, device=device)
+        self.cols = torch.tensor([s[2] for s in segs], dtype=torch.int32, device=device)
+        self.max_tiles = max(((r + 31) // 32) * ((c + 31) // 32) for _, r, c in segs)
+
+
+def transpose_cast_bf16(w: torch.Tensor, out: torch.Tensor, table: TransposeTable):
+    lib = load()
+    with _timed("cast_kernel", 0, 0):
+        check(lib.mfp_transpose_cast_bf16(_ptr(w), _ptr(out), _ptr(table.off), _ptr(table.rows), _ptr(table.cols),
+                                          table.nseg, table.max_tiles, _stream()), "mfp_transpose_cast_bf16")
+    return out
+
+
 def dropout_bwd(dx: torch.Tensor, out_dtype: torch.dtype, colsum: torch.Tensor, p: float, seed: int,
                 offset: int, step_ptr: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = load()

@@ -140,6 +140,18 @@ class ParamStore:
         self.g = torch.zeros(n, dtype=torch.float32, device=device)
         self.shadow = torch.zeros(n, dtype=torch.bfloat16, device=device) \
             if compute_dtype == torch.bfloat16 else None
+        # transposed bf16 copies ([in][out]) of the Dense kernels whose input gradient runs as a
+        # k-major weight-stationary product (K = out <= 512): MLP and attention output projection
+        self.shadow_t = None
+        self._ttable = None
+        if self.shadow is not None and torch.device(device).type == "cuda":
+            segs = [(s.offset, s.shape[0], s.shape[1]) for s in layout.segments.values()
+                    if s.transposed and ("/mlp/" in s.name or "/combine_heads/" in s.name)
+                    and s.shape[0] in (256, 512)]
+            if segs:
+                from mfp.hip import ops
+                self.shadow_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
+                self._ttable = ops.TransposeTable(segs, device)
         self.l2 = l2
         self.seg_l2 = torch.tensor([(l2 or 0.0) if s.l2 else 0.0 for s in layout.segments.values()],
                                    dtype=torch.float32, device=device)
@@ -191,10 +203,25 @@ class ParamStore:
         L = self.layout
         return buf[L.table_start:L.table_start + L.table_rows * L.D].view(L.table_rows, L.D)
 
+    def cwt(self, name: str) -> Optional[torch.Tensor]:
+        """[in][out] bf16 view of the Dense kernel ``name`` (None when no transposed shadow is kept)."""
+        if self.shadow_t is None:
+            return None
+        s = self.layout.segments[name]
+        if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and s.shape[0] in (256, 512)):
+            return None
+        return self.shadow_t[s.offset:s.offset + s.size].view(s.shape[1], s.shape[0])
+
+    def refresh_transposed(self):
+        if self.shadow_t is not None:
+            from mfp.hip import ops
+            ops.transpose_cast_bf16(self.w, self.shadow_t, self._ttable)
+
     def refresh_shadow(self):
         if self.shadow is not None:
             from mfp.hip import ops
             ops.cast_bf16(self.w, self.shadow)
+            self.refresh_transposed()
 
     # ------------------------------------------------------------------ init / (de)serialise
     def init_keras(self, seed: int = 0):

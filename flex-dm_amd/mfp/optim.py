@@ -24,6 +24,7 @@ class AdamKeras:
         st = self.store
         ops.adam_keras(st.w, st.g, self.m, self.v, st.shadow, self.chunks, st.seg_l2, self.stats,
                        self.step_t, self.lr, self.b1, self.b2, self.eps, self.clipnorm, grad_scale)
+        st.refresh_transposed()   # the Adam kernel refreshed the plain bf16 shadow itself
 
     def reg_loss(self) -> torch.Tensor:
         """sum_v l2_v * sum(w_v^2) with the weights as they were BEFORE the last step()."""

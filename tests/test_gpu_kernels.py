@@ -442,3 +442,21 @@ def test_cast_and_colsum():
     assert_close(out, x.double().sum(0), 1e-3, 1e-5, "colsum f32")
     ops.colsum(dst.reshape(1003, 264), out, 1003, 264)
     assert_close(out, x.to(torch.bfloat16).double().sum(0), 1e-3, 1e-5, "colsum bf16")
+
+
+def test_transpose_cast_bf16():
+    """Transposed bf16 shadow of matrices inside a flat buffer (dgrad weights of the ws GEMM)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    segs, off = [], 40
+    for r, c in [(256, 512), (512, 256), (256, 256), (40, 72)]:
+        segs.append((off, r, c))
+        off += r * c + 24
+    w = torch.randn(off, generator=g)
+    out = torch.full((off,), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_cast_bf16(w.to(DEV), out, ops.TransposeTable(segs, DEV))
+    got = out.float().cpu()
+    want = torch.full((off,), 7.0)
+    for o, r, c in segs:
+        want[o:o + r * c] = bf16_round(w[o:o + r * c].view(r, c).t().contiguous()).reshape(-1)
+    assert torch.equal(got, want)
