@@ -153,7 +153,7 @@ struct GemmLds {
 };
 
 template <typename T, bool A_KMAJOR, bool B_KMAJOR, int MT, int NQ, int NBUF>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
   using Cfg = GemmCfg<T>;
   using L = GemmLds<T, A_KMAJOR, B_KMAJOR, MT, NQ, NBUF>;
   constexpr int BM = L::BM, BN = L::BN, BK = Cfg::BK, EPC = Cfg::EPC;
