@@ -78,6 +78,37 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
   }
 }
 
+// P[t][r] = bf16(#index columns of token t addressing row r of the concatenated tables), r < ROWSP.
+// With it the table gradient is the product P^T[ROWS][T] * dh[T][D] on the wgrad GEMM (exact one-hot
+// counts 0..3 in bf16; dh in the compute dtype like every other weight gradient) -- off the
+// critical path on the side stream, instead of the LDS-atomic scatter kernel above (106 us).
+// One wave per token; a lane owns 32-bit words (two adjacent rows) l, l + 64, ...
+__global__ __launch_bounds__(256) void embed_onehot_kernel(const int* __restrict__ idx,
+                                                           const int* __restrict__ rowoff,
+                                                           unsigned int* __restrict__ P, int T, int NCOL,
+                                                           int ROWSP) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  int myrow = -1;
+  if (lane < NCOL) {
+    const int r = idx[(long long)t * NCOL + lane];
+    myrow = r < 0 ? -1 : rowoff[lane] + r;
+  }
+  const int words = ROWSP >> 1;
+  for (int w = lane; w < words; w += 64) {
+    int c0 = 0, c1 = 0;
+    for (int j = 0; j < NCOL; ++j) {
+      const int row = __shfl(myrow, j, 64);
+      c0 += row == 2 * w;
+      c1 += row == 2 * w + 1;
+    }
+    // bf16 bit patterns of 0, 1, 2, 3, ... (small integers are exact)
+    const unsigned int lo = f32_to_bf16((float)c0), hi = f32_to_bf16((float)c1);
+    P[(long long)t * words + w] = lo | (hi << 16);
+  }
+}
+
 // rowcode: 1 = all == 10.0 (<MASK>), 2 = all == 0.0 (<UNUSED>); one wave per row of K floats.
 __global__ __launch_bounds__(256) void row_flags_kernel(const float* __restrict__ x,
                                                         unsigned char* __restrict__ rowcode,
@@ -166,6 +197,15 @@ extern "C" int mfp_row_flags(const float* x, uint8_t* rowcode, int32_t* special_
   MFP_CHECK_ARG(x && rowcode && T > 0 && K > 0 && K % 4 == 0);
   hipLaunchKernelGGL(row_flags_kernel, dim3((T + 3) / 4), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, rowcode, special_idx, idx_stride, T, K);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_embed_onehot(const int32_t* idx, const int32_t* rowoff, uint16_t* P, int32_t T,
+                                int32_t NCOL, int32_t ROWSP, mfp_stream_t stream) {
+  MFP_CHECK_ARG(idx && rowoff && P && T > 0 && NCOL > 0 && NCOL <= 64 && ROWSP > 0 && ROWSP % 8 == 0);
+  hipLaunchKernelGGL(embed_onehot_kernel, dim3((T + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     idx, rowoff, reinterpret_cast<unsigned int*>(P), T, NCOL, ROWSP);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

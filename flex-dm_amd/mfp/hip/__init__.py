@@ -75,6 +75,7 @@ SIGNATURES = {
     "mfp_embed_pool_fwd": (c_int32, [c_void_p] * 4 + [c_int32] * 4 + [c_void_p]),
     "mfp_embed_pool_bwd": (c_int32, [c_void_p] * 5 + [c_size_t] + [c_int32] * 4 + [c_void_p]),
     "mfp_embed_pool_bwd_workspace_bytes": (c_size_t, [c_int32] * 4),
+    "mfp_embed_onehot": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mfp_row_flags": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p]),
     "mfp_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
                                    c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -78,7 +78,8 @@ def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
 def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     st, L = ctx.store, ctx.store.layout
     T, D = ctx.T, L.D
-    if L.num_keys:
+    onehot = ctx.cdt == torch.bfloat16   # table gradient as a wgrad GEMM (bf16 path); f32: exact scatter
+    if L.num_keys or onehot:
         dh_c = ctx.to_cdt(dh)
 
         def wgrads():
@@ -87,8 +88,13 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
                 ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
                          out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
                          colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
-        ctx.on_side(wgrads, dh_c, *xs, *codes)
-    ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
+            if onehot:
+                P = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
+                ops.gemm(P, dh_c, L.table_rows_pad, D, T, a_kmajor=False, b_kmajor=False,
+                         out=st.tables_padded(st.g), splitk=ops.wgrad_splitk(T, L.table_rows_pad, D))
+        ctx.on_side(wgrads, dh_c, idx_all, *xs, *codes)
+    if not onehot:
+        ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
     ctx.join_side()   # last node of the backward pass: every weight gradient is complete after this
 
 

@@ -248,6 +248,15 @@ def embed_pool_bwd(idx, rowoff, dout: torch.Tensor, dtables: torch.Tensor) -> to
     return dtables
 
 
+def embed_onehot(idx: torch.Tensor, rowoff: torch.Tensor, rows_pad: int) -> torch.Tensor:
+    lib = load()
+    T, ncol = idx.shape
+    P = torch.empty((T, rows_pad), dtype=torch.bfloat16, device=idx.device)
+    with _timed("embed_fwd_kernel", 0, T * rows_pad * 2):
+        check(lib.mfp_embed_onehot(_ptr(idx), _ptr(rowoff), _ptr(P), T, ncol, rows_pad, _stream()), "mfp_embed_onehot")
+    return P
+
+
 def row_flags(x: torch.Tensor, rowcode: torch.Tensor, special_idx: Optional[torch.Tensor] = None,
               idx_stride: int = 1):
     """x f32 [T,K] -> rowcode u8 [T]; optionally special_idx[t*stride] = rowcode-1."""

@@ -73,6 +73,11 @@ class ModelLayout:
             self.rowoff.append(rows)
             rows += 2
         self.table_rows = rows
+        # pad the concatenated tables to a multiple of 8 rows: the table gradient is a
+        # [rows][D] = onehot^T dh product on the wgrad GEMM (M % 8 == 0)
+        self.table_rows_pad = (rows + 7) // 8 * 8
+        if self.table_rows_pad > rows:
+            self._add("encoder/_pad/embeddings", (self.table_rows_pad - rows, D), False, False)
         for k in self.num_keys:
             width = self.columns[k]["shape"][-1]
             assert width % 8 == 0
@@ -97,24 +102,30 @@ class ModelLayout:
             self._add(p + "norm2/gamma", (D,), False, False)
             self._add(p + "norm2/beta", (D,), False, False)
 
-        # ---- decoder heads: rows [Upad][D] + bias [Upad]; per key a row block
+        # ---- decoder heads: rows [Upad][D] + bias [Upad]; per key a row block.  Every head starts
+        # at a multiple of 8 logits columns (zero-weight pad rows in between: 16-byte bf16 / float4
+        # access for the loss kernels and the GEMM epilogues); U counts the real units.
         self.head_cols: Dict[str, Tuple[int, int]] = {}
-        col = 0
+        col, real = 0, 0
         self.heads_start = self._cursor
+        pads = {}
         for k, c in self.columns.items():
             units = c["shape"][-1] * c["input_dim"] if c["type"] == "categorical" else c["shape"][-1]
             self._add("decoder/decoder_%s/kernel" % k, (units, D), True, True)
             self.head_cols[k] = (col, units)
             col += units
-        self.U = col
-        self.Upad = (col + 7) // 8 * 8
-        if self.Upad > self.U:
-            self._add("decoder/_pad/kernel", (self.Upad - self.U, D), False, False)
+            real += units
+            pads[k] = (-col) % 8
+            if pads[k]:
+                self._add("decoder/_pad/%s/kernel" % k, (pads[k], D), False, False)
+                col += pads[k]
+        self.U = real
+        self.Upad = col
         self.heads_bias_start = self._cursor
         for k in self.columns:
             self._add("decoder/decoder_%s/bias" % k, (self.head_cols[k][1],), True, False)
-        if self.Upad > self.U:
-            self._add("decoder/_pad/bias", (self.Upad - self.U,), False, False)
+            if pads[k]:
+                self._add("decoder/_pad/%s/bias" % k, (pads[k],), False, False)
         self.numel = self._cursor
         assert self.numel % 8 == 0
 
@@ -211,6 +222,12 @@ class ParamStore:
         if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and s.shape[0] in (256, 512)):
             return None
         return self.shadow_t[s.offset:s.offset + s.size].view(s.shape[1], s.shape[0])
+
+    def tables_padded(self, buf=None) -> torch.Tensor:
+        """[table_rows_pad][D] view: the tables plus the zero pad rows behind them."""
+        buf = self.w if buf is None else buf
+        L = self.layout
+        return buf[L.table_start:L.table_start + L.table_rows_pad * L.D].view(L.table_rows_pad, L.D)
 
     def refresh_transposed(self):
         if self.shadow_t is not None:

@@ -136,6 +136,13 @@ int mfp_embed_pool_bwd(const int32_t* idx, const int32_t* rowoff, const float* d
                        float* dtables, void* workspace, size_t workspace_bytes, int32_t T,
                        int32_t NCOL, int32_t ROWS, int32_t D, mfp_stream_t stream);
 size_t mfp_embed_pool_bwd_workspace_bytes(int32_t T, int32_t NCOL, int32_t ROWS, int32_t D);
+/* One-hot count matrix of the index columns: P bf16 [T][ROWSP] (ROWSP % 8 == 0, >= number of table
+ * rows), P[t][rowoff[c] + idx[t][c]] += 1 for every column c with idx >= 0.  The table gradient of
+ * Encoder.call's embedding sums (encoder.py:156-160,194-199) is then P^T * d(out) on mfp_gemm
+ * (a_kmajor = b_kmajor = 0), which replaces mfp_embed_pool_bwd on the bf16 path. */
+int mfp_embed_onehot(const int32_t* idx, const int32_t* rowoff, uint16_t* P, int32_t T, int32_t NCOL,
+                     int32_t ROWSP, mfp_stream_t stream);
+
 /* rowcode[t] = 1 if all(x[t]==10.0) (<MASK>), 2 if all(x[t]==0.0) (<UNUSED>, wins), else 0
  * (encoder.py:165-166; masking.py:8-9); special_idx[t*stride] = rowcode-1 (or -1). */
 int mfp_row_flags(const float* x, uint8_t* rowcode, int32_t* special_idx, int32_t idx_stride,

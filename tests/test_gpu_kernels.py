@@ -460,3 +460,31 @@ def test_transpose_cast_bf16():
     for o, r, c in segs:
         want[o:o + r * c] = bf16_round(w[o:o + r * c].view(r, c).t().contiguous()).reshape(-1)
     assert torch.equal(got, want)
+
+
+def test_embed_onehot_table_gradient():
+    """bf16 path: table gradient = onehot^T dh on the wgrad GEMM; exact against a double reference
+    on the bf16-rounded dh (counts are exact, accumulation is f32)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    T, D, dims = 2048, 64, [5, 9, 9, 20, 3]
+    ncol = len(dims) + 1                      # last column repeats table 1 (shared table, like color)
+    offs = [0]
+    for d in dims:
+        offs.append(offs[-1] + d)
+    rowoff = torch.tensor(offs[:-1] + [offs[1]], dtype=torch.int32)
+    rows = offs[-1]
+    rows_pad = (rows + 7) // 8 * 8
+    idx = torch.stack([torch.randint(-1, d, (T,), generator=g) for d in dims + [dims[1]]], dim=1).to(torch.int32)
+    dh = bf16_round(torch.randn(T, D, generator=g))
+    P = ops.embed_onehot(idx.to(DEV), rowoff.to(DEV), rows_pad)
+    want_P = torch.zeros(T, rows_pad)
+    for c in range(ncol):
+        ok = idx[:, c] >= 0
+        want_P[ok.nonzero()[:, 0], (rowoff[c] + idx[ok, c]).long()] += 1
+    assert torch.equal(P.float().cpu(), want_P)
+    out = torch.full((rows_pad, D), 9.0, device=DEV)
+    ops.gemm(P, dh.to(DEV, torch.bfloat16), rows_pad, D, T, a_kmajor=False, b_kmajor=False, out=out,
+             splitk=ops.wgrad_splitk(T, rows_pad, D))
+    want = want_P.double().t() @ dh.double()
+    assert_close(out, want, 1e-3, 1e-5, "onehot table gradient")
