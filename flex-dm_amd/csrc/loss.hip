@@ -28,118 +28,156 @@ __device__ __forceinline__ float token_weight(const mfp_loss_key& k, const int* 
   return w ? 1.f : 0.f;
 }
 
-constexpr int CE_TOK = 32;        // token rows per workgroup
+constexpr int CE_TOK = 16;        // token rows per workgroup
 constexpr int CE_MAX_RANGES = 4;  // contiguous column ranges holding categorical heads
+constexpr int CE_MAX_ITEMS = 16;  // (key, feature) items per token
+constexpr int CE_MAX_GAPS = 20;   // padding column runs (< 8 columns each) inside the ranges
 
 struct CeRanges {
   int beg[CE_MAX_RANGES], len[CE_MAX_RANGES], lds_off[CE_MAX_RANGES];
-  int n, width;  // width = sum(len) (+1 pad) = LDS row stride in floats
+  int n, width;     // width = LDS row stride in floats
+  int vec;          // 1: every range is 8-column aligned (beg, len, ld): 16-byte global access
+  int ngap, gap_pos[CE_MAX_GAPS], gap_len[CE_MAX_GAPS];   // LDS positions of padding columns
+  int nitem;
+  int item_key[CE_MAX_ITEMS], item_feat[CE_MAX_ITEMS], item_pos[CE_MAX_ITEMS], item_C[CE_MAX_ITEMS];
 };
 
-// Categorical heads, tile-wise.  The old per-item kernel was a chain of dependent global loads
-// (mask -> nvalid -> condition -> label -> logits) per 16-lane group: 165 us for ~70 MB.  Here a
-// workgroup bulk-loads CE_TOK rows of every categorical column range into LDS (all requests in
-// flight at once, row-contiguous), one THREAD then owns one (token, feature) item and walks its C
-// classes in LDS (odd row stride: conflict-free), writing d(logits) back in place; the rows are
-// finally stored coalesced.  Loss / score / denominator: block reduction + one atomic per key.
+// Categorical heads, tile-wise: a workgroup owns CE_TOK token rows.
+//  1. the rows of every categorical column range are bulk-loaded into LDS (16 lanes per row,
+//     float4 when the head layout is 8-aligned -- ModelLayout pads every head to that);
+//  2. one THREAD per (row, item) evaluates the weight (mask & condition & s < nvalid: a chain of
+//     dependent loads, issued for all 256 items at once) and active items are compacted;
+//  3. one 16-LANE GROUP per item: inactive items (~85 % under the 15 % masking rate) zero their
+//     classes, active ones run softmax / clipped CE / gradient with 16-lane shuffles (the previous
+//     kernel walked an item's classes serially in one thread: 102 us for 50 MB);
+//  4. rows go back as d(logits) in the compute dtype, 16 bytes per lane.
+// Loss / score / denominator: LDS accumulation + one global atomic per key and workgroup.
 template <typename TDL>
 __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ logits, TDL* __restrict__ dlogits,
                                                       int ld, LossKeys keys, CeRanges rg, const int* __restrict__ nvalid,
                                                       float* __restrict__ sums, int T, int S, float inv_B) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [CE_TOK][rg.width]
   __shared__ float red[MFP_MAX_LOSS_KEYS][3];
+  __shared__ int nactive;
+  __shared__ unsigned char active[CE_TOK * CE_MAX_ITEMS];   // compacted (row << 4 | item)
+  __shared__ unsigned char isact[CE_TOK][CE_MAX_ITEMS];
   const int t0 = blockIdx.x * CE_TOK;
   const int W = rg.width;
+  const int row16 = threadIdx.x >> 4, l16 = threadIdx.x & 15;
   if (threadIdx.x < MFP_MAX_LOSS_KEYS * 3) (&red[0][0])[threadIdx.x] = 0.f;
-  // ---- stage: every (row, range) segment, coalesced along the row
-  for (int r = 0; r < rg.n; ++r) {
-    const int len = rg.len[r];
-    for (int i = threadIdx.x; i < CE_TOK * len; i += 256) {
-      const int row = i / len, c = i % len, t = t0 + row;
-      tile[row * W + rg.lds_off[r] + c] = t < T ? logits[(long long)t * ld + rg.beg[r] + c] : 0.f;
-    }
-  }
-  __syncthreads();
-  // ---- phase A: thread = (token row, key, feature) item; inactive items (weight 0, ~85 % under the
-  // 15 % masking rate) just zero their d(logits); active ones are COMPACTED so that phase B runs
-  // without lane divergence.
-  __shared__ int nactive;
-  __shared__ unsigned short active[CE_TOK * 16];
   if (threadIdx.x == 0) nactive = 0;
-  int nitem_per_tok = 0;
-  for (int k = 0; k < keys.n; ++k) nitem_per_tok += keys.k[k].n_feat;
-  __syncthreads();
-  auto locate = [&](int it, int& row, int& k, int& f, int& pos) {
-    row = it / nitem_per_tok;
-    f = it % nitem_per_tok; k = 0;
-    while (f >= keys.k[k].n_feat) { f -= keys.k[k].n_feat; ++k; }
-    const int col = keys.k[k].col_off + f * keys.k[k].n_class;
-    pos = -1;
-    for (int r = 0; r < rg.n; ++r)
-      if (col >= rg.beg[r] && col < rg.beg[r] + rg.len[r]) pos = rg.lds_off[r] + col - rg.beg[r];
-  };
-  for (int it = threadIdx.x; it < CE_TOK * nitem_per_tok; it += 256) {
-    int row, k, f, pos;
-    locate(it, row, k, f, pos);
-    const int t = t0 + row;
-    if (t >= T) continue;
-    if (token_weight(keys.k[k], nvalid, t, S) == 0.f) {
-      float* z = tile + row * W + pos;
-      for (int j = 0; j < keys.k[k].n_class; ++j) z[j] = 0.f;
-    } else {
-      active[atomicAdd(&nactive, 1)] = (unsigned short)it;
+  // ---- 1. stage
+  {
+    const int t = t0 + row16;
+    for (int r = 0; r < rg.n; ++r) {
+      float* dst = tile + row16 * W + rg.lds_off[r];
+      const float* src = logits + (long long)t * ld + rg.beg[r];
+      if (rg.vec) {
+        for (int c4 = l16; c4 < rg.len[r] / 4; c4 += 16)
+          *reinterpret_cast<float4*>(dst + 4 * c4) = t < T ? *reinterpret_cast<const float4*>(src + 4 * c4)
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        for (int c = l16; c < rg.len[r]; c += 16) dst[c] = t < T ? src[c] : 0.f;
+      }
     }
   }
   __syncthreads();
-  // ---- phase B: active items spread round-robin over the 4 waves; one exp per class
+  for (int gI = 0; gI < rg.ngap; ++gI)      // padding columns: d(logits) = 0
+    if (l16 < rg.gap_len[gI]) tile[row16 * W + rg.gap_pos[gI] + l16] = 0.f;
+  // ---- 2. weights: thread = (row, item)
+  {
+    const int item = l16, t = t0 + row16;
+    bool act = false;
+    if (item < rg.nitem && t < T) act = token_weight(keys.k[rg.item_key[item]], nvalid, t, S) != 0.f;
+    isact[row16][item] = act ? 1 : 0;
+  }
+  __syncthreads();
+  if (isact[row16][l16]) active[atomicAdd(&nactive, 1)] = (unsigned char)(threadIdx.x);
+  // ---- 3a. inactive items zero their classes (group = 16 lanes, item a = group, group + 16, ...)
+  for (int a = row16; a < CE_TOK * rg.nitem; a += 16) {
+    const int row = a / rg.nitem, item = a % rg.nitem;
+    if (isact[row][item]) continue;
+    float* z = tile + row * W + rg.item_pos[item];
+    for (int j = l16; j < rg.item_C[item]; j += 16) z[j] = 0.f;
+  }
+  __syncthreads();
+  // ---- 3b. active items: one 16-lane group each
   const int na = nactive;
-  for (int a0 = 0; a0 < na; a0 += 256) {
-    const int a = a0 + (threadIdx.x & 63) * 4 + (threadIdx.x >> 6);
-    if (a >= na) continue;
-    int row, k, f, pos;
-    locate(active[a], row, k, f, pos);
-    const mfp_loss_key& key = keys.k[k];
-    const int t = t0 + row, C = key.n_class;
-    float* z = tile + row * W + pos;
-    const int y = reinterpret_cast<const int*>(key.target)[(long long)t * key.n_feat + f];
+  for (int a = row16; a < na; a += 16) {
+    const int code = active[a], row = code >> 4, item = code & 15;
+    const int kidx = rg.item_key[item], C = rg.item_C[item];
+    const mfp_loss_key& key = keys.k[kidx];
+    const int t = t0 + row;
+    float* z = tile + row * W + rg.item_pos[item];
+    const int y = reinterpret_cast<const int*>(key.target)[(long long)t * key.n_feat + rg.item_feat[item]];
+    // max / argmax (first index on ties, as the serial reference walk)
     float m = -INFINITY;
-    int am = 0;
-    for (int j = 0; j < C; ++j) { const float v = z[j]; if (v > m) { m = v; am = j; } }
+    int am = 0x7fffffff;
+    for (int j = l16; j < C; j += 16) { const float v = z[j]; if (v > m) { m = v; am = j; } }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const float om = __shfl_xor(m, o, 64);
+      const int oa = __shfl_xor(am, o, 64);
+      if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
     float se = 0.f;
-    for (int j = 0; j < C; ++j) { const float e = expf(z[j] - m); z[j] = e; se += e; }
+    for (int j = l16; j < C; j += 16) { const float e = expf(z[j] - m); z[j] = e; se += e; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
     const float inv = 1.f / se;
     float sq = 0.f, qy = 0.f;
-    for (int j = 0; j < C; ++j) {
+    for (int j = l16; j < C; j += 16) {
       const float pj = z[j] * inv;
       const float q = fminf(fmaxf(pj, 1e-7f), 1.f - 1e-7f);
       sq += q;
       if (j == y) qy = q;
     }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); qy += __shfl_xor(qy, o, 64); }
     const float loss = -logf(qy) + logf(sq);
     const float inv_sq = 1.f / sq, inv_qy = 1.f / qy;
     float gp = 0.f;
-    for (int j = 0; j < C; ++j) {
+    for (int j = l16; j < C; j += 16) {
       const float pj = z[j] * inv;
       const float g = (pj >= 1e-7f && pj <= 1.f - 1e-7f) ? ((j == y ? -inv_qy : 0.f) + inv_sq) : 0.f;
       gp += g * pj;
     }
-    for (int j = 0; j < C; ++j) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) gp += __shfl_xor(gp, o, 64);
+    for (int j = l16; j < C; j += 16) {
       const float pj = z[j] * inv;
       const float g = (pj >= 1e-7f && pj <= 1.f - 1e-7f) ? ((j == y ? -inv_qy : 0.f) + inv_sq) : 0.f;
       z[j] = pj * (g - gp) * inv_B;
     }
-    atomicAdd(&red[k][0], loss * inv_B);
-    atomicAdd(&red[k][1], am == y ? 1.f : 0.f);
-    atomicAdd(&red[k][2], 1.f);
+    if (l16 == 0) {
+      atomicAdd(&red[kidx][0], loss * inv_B);
+      atomicAdd(&red[kidx][1], am == y ? 1.f : 0.f);
+      atomicAdd(&red[kidx][2], 1.f);
+    }
   }
   __syncthreads();
-  // ---- store d(logits) rows coalesced, publish the sums
+  // ---- 4. store d(logits) rows, publish the sums
   if (dlogits) {
-    for (int r = 0; r < rg.n; ++r) {
-      const int len = rg.len[r];
-      for (int i = threadIdx.x; i < CE_TOK * len; i += 256) {
-        const int row = i / len, c = i % len, t = t0 + row;
-        if (t < T) cdt_traits<TDL>::store(dlogits + (long long)t * ld + rg.beg[r] + c, tile[row * W + rg.lds_off[r] + c]);
+    const int t = t0 + row16;
+    if (t < T) {
+      for (int r = 0; r < rg.n; ++r) {
+        const float* src = tile + row16 * W + rg.lds_off[r];
+        TDL* dst = dlogits + (long long)t * ld + rg.beg[r];
+        if (rg.vec) {
+          for (int c8 = l16; c8 < rg.len[r] / 8; c8 += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(src + 8 * c8);
+            const float4 b = *reinterpret_cast<const float4*>(src + 8 * c8 + 4);
+            if constexpr (sizeof(TDL) == 4) {
+              *reinterpret_cast<float4*>(dst + 8 * c8) = a;
+              *reinterpret_cast<float4*>(dst + 8 * c8 + 4) = b;
+            } else {
+              const u32x4 pk = {pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+              *reinterpret_cast<u32x4*>(dst + 8 * c8) = pk;
+            }
+          }
+        } else {
+          for (int c = l16; c < rg.len[r]; c += 16) cdt_traits<TDL>::store(dst + c, src[c]);
+        }
       }
     }
   }
@@ -150,29 +188,78 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
   }
 }
 
-template <typename TDL>
+constexpr int MSE_TOK = 16;   // tokens per workgroup (4 per wave)
+
+// Numerical heads.  VEC: the head is 8-column aligned and its width a multiple of 8 -> a lane owns
+// 8 consecutive columns (two float4 of predictions and targets, one 16-byte d(pred) store); the
+// token weights of the workgroup's MSE_TOK tokens are evaluated by its first lanes in one go.
+template <typename TDL, bool VEC>
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, TDL* __restrict__ dpred,
                                                   int ld, LossKeys keys, const int* __restrict__ nvalid,
                                                   float* __restrict__ sums, int T, int S, float inv_B) {
   __shared__ float red[3][4];
+  __shared__ float wt[MSE_TOK];
   const mfp_loss_key k = keys.k[blockIdx.y];
   const int W = k.n_class;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* target = reinterpret_cast<const float*>(k.target);
+  const int t0 = blockIdx.x * MSE_TOK;
+  if (threadIdx.x < MSE_TOK) wt[threadIdx.x] = t0 + (int)threadIdx.x < T ? token_weight(k, nvalid, t0 + threadIdx.x, S) : -1.f;
+  __syncthreads();
   float acc_loss = 0.f, acc_score = 0.f, acc_den = 0.f;
-  for (int t = blockIdx.x * 4 + wave; t < T; t += gridDim.x * 4) {
-    const float w = token_weight(k, nvalid, t, S);
+  for (int tt = wave; tt < MSE_TOK; tt += 4) {
+    const int t = t0 + tt;
+    const float w = wt[tt];
+    if (w < 0.f) break;
     const long long base = (long long)t * ld + k.col_off;
     if (w == 0.f) {
-      if (dpred) for (int j = lane; j < W; j += 64) cdt_traits<TDL>::store(dpred + base + j, 0.f);
+      if (dpred) {
+        if (VEC) {
+          for (int c = lane * 8; c < W; c += 512) {
+            if constexpr (sizeof(TDL) == 4) {
+              *reinterpret_cast<float4*>(dpred + base + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+              *reinterpret_cast<float4*>(dpred + base + c + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+              *reinterpret_cast<u32x4*>(dpred + base + c) = (u32x4){0u, 0u, 0u, 0u};
+            }
+          }
+        } else {
+          for (int j = lane; j < W; j += 64) cdt_traits<TDL>::store(dpred + base + j, 0.f);
+        }
+      }
       continue;
     }
     float sd = 0.f, sy = 0.f, sp = 0.f, syp = 0.f;
-    for (int j = lane; j < W; j += 64) {
-      const float p = pred[base + j], y = target[(long long)t * W + j];
-      const float d = p - y;
-      sd += d * d; sy += y * y; sp += p * p; syp += y * p;
-      if (dpred) cdt_traits<TDL>::store(dpred + base + j, 2.f * d * inv_B);
+    if (VEC) {
+      for (int c = lane * 8; c < W; c += 512) {
+        float p[8], y[8], d[8];
+        *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(pred + base + c);
+        *reinterpret_cast<float4*>(p + 4) = *reinterpret_cast<const float4*>(pred + base + c + 4);
+        *reinterpret_cast<float4*>(y) = *reinterpret_cast<const float4*>(target + (long long)t * W + c);
+        *reinterpret_cast<float4*>(y + 4) = *reinterpret_cast<const float4*>(target + (long long)t * W + c + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          d[e] = p[e] - y[e];
+          sd += d[e] * d[e]; sy += y[e] * y[e]; sp += p[e] * p[e]; syp += y[e] * p[e];
+          d[e] *= 2.f * inv_B;
+        }
+        if (dpred) {
+          if constexpr (sizeof(TDL) == 4) {
+            *reinterpret_cast<float4*>(dpred + base + c) = *reinterpret_cast<const float4*>(d);
+            *reinterpret_cast<float4*>(dpred + base + c + 4) = *reinterpret_cast<const float4*>(d + 4);
+          } else {
+            const u32x4 pk = {pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7])};
+            *reinterpret_cast<u32x4*>(dpred + base + c) = pk;
+          }
+        }
+      }
+    } else {
+      for (int j = lane; j < W; j += 64) {
+        const float p = pred[base + j], y = target[(long long)t * W + j];
+        const float d = p - y;
+        sd += d * d; sy += y * y; sp += p * p; syp += y * p;
+        if (dpred) cdt_traits<TDL>::store(dpred + base + j, 2.f * d * inv_B);
+      }
     }
     sd = wave_sum(sd); sy = wave_sum(sy); sp = wave_sum(sp); syp = wave_sum(syp);
     if (lane == 0) {
@@ -221,26 +308,69 @@ extern "C" int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, 
   MFP_CHECK_LAUNCH();
   const float inv_B = 1.0f / (float)B;
   if (cat.n > 0) {
-    // merge the categorical heads' columns into contiguous ranges (Crello: [0,319) and [1343,1378))
+    // Merge the categorical heads' columns into contiguous ranges.  Gaps of < 8 columns between
+    // heads (and behind the last head of a range, up to the next multiple of 8) are PADDING by
+    // contract (include/mfp_hip.h): their logits are ignored and their d(logits) written as 0, so
+    // they ride along and the ranges of an 8-aligned head layout stay 16-byte aligned
+    // (Crello: [0,320) and [1344,1384)).
+    struct Head { int beg, end, cat; };
+    Head hs[MFP_MAX_LOSS_KEYS];
+    for (int i = 0; i < nkeys; ++i)
+      hs[i] = Head{keys[i].col_off, keys[i].col_off + keys[i].n_feat * keys[i].n_class, keys[i].is_numerical ? 0 : 1};
+    for (int i = 1; i < nkeys; ++i)   // insertion sort by first column
+      for (int j = i; j > 0 && hs[j].beg < hs[j - 1].beg; --j) { Head t = hs[j]; hs[j] = hs[j - 1]; hs[j - 1] = t; }
     CeRanges rg;
-    rg.n = 0; rg.width = 0;
-    for (int i = 0; i < cat.n; ++i) {
-      const int beg = cat.k[i].col_off, len = cat.k[i].n_feat * cat.k[i].n_class;
-      if (rg.n > 0 && rg.beg[rg.n - 1] + rg.len[rg.n - 1] == beg) {
-        rg.len[rg.n - 1] += len;
+    rg.n = 0; rg.width = 0; rg.ngap = 0;
+    auto add_gap = [&](int col, int len) {   // position fixed up below (needs lds_off)
+      if (len > 0 && rg.ngap < CE_MAX_GAPS) { rg.gap_pos[rg.ngap] = col; rg.gap_len[rg.ngap] = len; rg.ngap++; }
+    };
+    for (int i = 0; i < nkeys; ++i) {
+      MFP_CHECK_ARG(i == 0 || hs[i].beg >= hs[i - 1].end);   // heads must not overlap
+      if (!hs[i].cat) continue;
+      const bool extend = rg.n > 0 && i > 0 && hs[i - 1].cat && hs[i].beg - (rg.beg[rg.n - 1] + rg.len[rg.n - 1]) < 8
+                          && hs[i].beg >= rg.beg[rg.n - 1] + rg.len[rg.n - 1];
+      if (extend) {
+        const int cur_end = rg.beg[rg.n - 1] + rg.len[rg.n - 1];
+        add_gap(cur_end, hs[i].beg - cur_end);
+        rg.len[rg.n - 1] = hs[i].end - rg.beg[rg.n - 1];
       } else {
         MFP_CHECK_ARG(rg.n < CE_MAX_RANGES);
-        rg.beg[rg.n] = beg; rg.len[rg.n] = len; rg.n++;
+        rg.beg[rg.n] = hs[i].beg; rg.len[rg.n] = hs[i].end - hs[i].beg; rg.n++;
+      }
+      // close the range at a multiple of 8 when the columns up to there are free
+      const int next_beg = i + 1 < nkeys ? hs[i + 1].beg : ld;
+      const int end = rg.beg[rg.n - 1] + rg.len[rg.n - 1], end8 = (end + 7) / 8 * 8;
+      if ((i + 1 == nkeys || !hs[i + 1].cat || hs[i + 1].beg - end >= 8) && end8 <= next_beg && end8 <= ld) {
+        add_gap(end, end8 - end);
+        rg.len[rg.n - 1] = end8 - rg.beg[rg.n - 1];
       }
     }
     for (int r = 0; r < rg.n; ++r) { rg.lds_off[r] = rg.width; rg.width += rg.len[r]; }
-    rg.width |= 1;   // odd row stride: threads of different rows hit different banks
+    for (int gI = 0; gI < rg.ngap; ++gI) {     // global column -> LDS position
+      for (int r = 0; r < rg.n; ++r)
+        if (rg.gap_pos[gI] >= rg.beg[r] && rg.gap_pos[gI] < rg.beg[r] + rg.len[r]) {
+          rg.gap_pos[gI] = rg.lds_off[r] + rg.gap_pos[gI] - rg.beg[r];
+          break;
+        }
+    }
+    rg.vec = (ld % 8 == 0) ? 1 : 0;
+    for (int r = 0; r < rg.n; ++r)
+      if (rg.beg[r] % 8 != 0 || rg.len[r] % 8 != 0) rg.vec = 0;
+    rg.width = (rg.width + 3) / 4 * 4 + 4;   // 16-byte rows; +4 floats: 16-lane groups of different rows hit different banks
     const size_t lds = (size_t)CE_TOK * rg.width * sizeof(float);
     MFP_CHECK_ARG(lds <= 60 * 1024);
-    {
-      int items = 0;
-      for (int i = 0; i < cat.n; ++i) items += cat.k[i].n_feat;
-      MFP_CHECK_ARG(items <= 16);   // active[] capacity
+    rg.nitem = 0;
+    for (int i = 0; i < cat.n; ++i) {
+      for (int f = 0; f < cat.k[i].n_feat; ++f) {
+        MFP_CHECK_ARG(rg.nitem < CE_MAX_ITEMS);
+        const int col = cat.k[i].col_off + f * cat.k[i].n_class;
+        int pos = -1;
+        for (int r = 0; r < rg.n; ++r)
+          if (col >= rg.beg[r] && col < rg.beg[r] + rg.len[r]) pos = rg.lds_off[r] + col - rg.beg[r];
+        rg.item_key[rg.nitem] = i; rg.item_feat[rg.nitem] = f; rg.item_pos[rg.nitem] = pos;
+        rg.item_C[rg.nitem] = cat.k[i].n_class;
+        rg.nitem++;
+      }
     }
     const int bx = (T + CE_TOK - 1) / CE_TOK;
     if (dl_dtype == MFP_F32)
@@ -250,12 +380,13 @@ extern "C" int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, 
     MFP_CHECK_LAUNCH();
   }
   if (num.n > 0) {
-    int bx = (T + 3) / 4;
-    if (bx > 4096) bx = 4096;
-    if (dl_dtype == MFP_F32)
-      hipLaunchKernelGGL(mse_kernel<float>, dim3(bx, num.n), dim3(256), 0, st, logits, (float*)dlogits, ld, num, nvalid, sums, T, S, inv_B);
-    else
-      hipLaunchKernelGGL(mse_kernel<unsigned short>, dim3(bx, num.n), dim3(256), 0, st, logits, (unsigned short*)dlogits, ld, num, nvalid, sums, T, S, inv_B);
+    const int bx = (T + MSE_TOK - 1) / MSE_TOK;
+    bool vec = ld % 8 == 0;
+    for (int i = 0; i < num.n; ++i) vec = vec && num.k[i].col_off % 8 == 0 && num.k[i].n_class % 8 == 0;
+#define MSE_LAUNCH(TT, V) hipLaunchKernelGGL((mse_kernel<TT, V>), dim3(bx, num.n), dim3(256), 0, st, logits, (TT*)dlogits, ld, num, nvalid, sums, T, S, inv_B)
+    if (dl_dtype == MFP_F32) { if (vec) MSE_LAUNCH(float, true); else MSE_LAUNCH(float, false); }
+    else { if (vec) MSE_LAUNCH(unsigned short, true); else MSE_LAUNCH(unsigned short, false); }
+#undef MSE_LAUNCH
     MFP_CHECK_LAUNCH();
   }
   return MFP_OK;

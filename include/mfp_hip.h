@@ -168,7 +168,9 @@ typedef struct mfp_loss_key {
 } mfp_loss_key;
 
 #define MFP_MAX_LOSS_KEYS 16
-/* logits f32 [T, ld]; dlogits cdt [T, ld] (may be NULL: metrics only);
+/* logits f32 [T, ld]; dlogits cdt [T, ld] (may be NULL: metrics only).  Heads must not overlap;
+ * runs of < 8 columns between categorical heads (and up to the next multiple of 8 behind one) are
+ * treated as padding: ignored in logits, written as 0 in dlogits;
  * sums f32 [nkeys][3] = {loss_sum (already / B), score_sum, den_sum}, zeroed by the call. */
 int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys /*host*/,
                      int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
