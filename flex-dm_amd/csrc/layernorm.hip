@@ -203,7 +203,7 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
                                  float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
                                  int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
                                  uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
-  MFP_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta);
+  MFP_CHECK_ARG(dy && x && gamma && mean && rstd && dx && (dgamma != nullptr) == (dbeta != nullptr));
   MFP_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024);
   MFP_CHECK_ARG((ddrop == nullptr) == (drop_colsum == nullptr) && drop_p >= 0.f && drop_p < 1.f);
   if (!workspace || workspace_bytes < mfp_layernorm_bwd_workspace_bytes(T, D)) {
@@ -223,8 +223,20 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
   }
 #undef LN_BWD
   MFP_CHECK_LAUNCH();
+  if (dgamma == nullptr) return MFP_OK;   // partials only: the caller reduces them (mfp_reduce_partials)
   // one launch: columns [0,D) -> dgamma, [D,2D) -> dbeta, [2D,3D) -> dropout bias gradient
   launch_reduce_rows3(part, dgamma, dbeta, drop_colsum, D, 2 * D, nblk, ddrop != nullptr ? 3 * D : 2 * D, 3 * D, st);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int32_t mfp_layernorm_bwd_partial_rows(int32_t T) { return (T + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
+
+extern "C" int mfp_reduce_partials(const float* part, float* out0, float* out1, float* out2, int64_t split1,
+                                   int64_t split2, int32_t P, int64_t N, int64_t pstride, mfp_stream_t stream) {
+  MFP_CHECK_ARG(part && out0 && P > 0 && N > 0 && pstride >= N && split1 >= 0 && split2 >= split1);
+  MFP_CHECK_ARG((split1 >= N || out1) && (split2 >= N || out2));
+  launch_reduce_rows3(part, out0, out1, out2, split1, split2, P, N, pstride, reinterpret_cast<hipStream_t>(stream));
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

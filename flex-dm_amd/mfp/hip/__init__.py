@@ -70,6 +70,8 @@ SIGNATURES = {
     "mfp_layernorm_bwd": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                     c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "mfp_layernorm_bwd_partial_rows": (c_int32, [c_int32]),
+    "mfp_reduce_partials": (c_int32, [c_void_p] * 4 + [c_int64, c_int64, c_int32, c_int64, c_int64, c_void_p]),
     "mfp_attention_fwd": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "mfp_attention_bwd": (c_int32, [c_void_p] * 6 + [c_int32] * 5 + [c_void_p]),
     "mfp_embed_pool_fwd": (c_int32, [c_void_p] * 4 + [c_int32] * 4 + [c_void_p]),

@@ -182,9 +182,11 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,
-                  dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None):
+                  dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None, defer=None):
     """``drop`` = (colsum_out [D], p, seed, offset, step_ptr): also return the dropout-masked,
-    compute-dtype copy of dx for the consuming Dense backward (fused mfp_dropout_bwd)."""
+    compute-dtype copy of dx for the consuming Dense backward (fused mfp_dropout_bwd).
+    ``defer(fn, *tensors)``: the parameter-gradient reduction (dgamma, dbeta, colsum -- only the
+    optimizer needs them) is handed to ``defer`` (StepCtx.on_side) instead of running in line."""
     lib = load()
     T, D = x.shape
     if dx is None:
@@ -192,13 +194,23 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma
     ddrop = torch.empty((T, D), dtype=dy.dtype, device=x.device) if drop is not None else None
     colsum, p_, seed_, off_, sp_ = drop if drop is not None else (None, 0.0, 0, 0, None)
     nbytes = lib.mfp_layernorm_bwd_workspace_bytes(T, D)
-    ws = workspace(nbytes, x.device)
+    # deferred reduction: the partials must outlive this call -> their own buffer, not the shared one
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if defer is not None else workspace(nbytes, x.device)
     nb = T * D * (_esz(dy) + 4 + (4 if dres is not None else 0) + 4 + (_esz(dy) if drop is not None else 0))
     with _timed("ln_bwd_kernel", 0, nb):
         check(lib.mfp_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
-                                    _ptr(dx), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), ws.numel(), T, D,
+                                    _ptr(dx), _ptr(None if defer is not None else dgamma),
+                                    _ptr(None if defer is not None else dbeta), ws.data_ptr(), ws.numel(), T, D,
                                     dt_code(dy.dtype), _ptr(ddrop), _ptr(colsum), float(p_), int(seed_), int(off_),
                                     _ptr(sp_), _stream()), "mfp_layernorm_bwd")
+    if defer is not None:
+        P = lib.mfp_layernorm_bwd_partial_rows(T)
+        n = 3 * D if drop is not None else 2 * D
+
+        def finish():
+            check(lib.mfp_reduce_partials(ws.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(colsum), D, 2 * D, P, n,
+                                          3 * D, _stream()), "mfp_reduce_partials")
+        defer(finish, ws)
     return (dx, ddrop) if drop is not None else dx
 
 

@@ -110,6 +110,14 @@ int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const 
                       int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D);
+/* dgamma == dbeta == NULL: mfp_layernorm_bwd leaves the per-workgroup partials
+ * [P = ceil(T/32)][3][D] (dgamma | dbeta | colsum(ddrop)) in `workspace` and the caller sums them
+ * later, off the critical path, with
+ *   out[c] = sum_{p<P} part[p*pstride + c], c < N;  c < split1 -> out0[c], c < split2 ->
+ *   out1[c - split1], else out2[c - split2]. */
+int32_t mfp_layernorm_bwd_partial_rows(int32_t T);
+int mfp_reduce_partials(const float* part, float* out0, float* out1, float* out2, int64_t split1,
+                        int64_t split2, int32_t P, int64_t N, int64_t pstride, mfp_stream_t stream);
 
 /* --------------------------------------------------------------------------- attention
  * MultiHeadSelfAttention.attention (transformer.py:60-76) fused: softmax(QK^T/sqrt(hd) +
