@@ -101,6 +101,37 @@ __device__ __forceinline__ bool philox_keep(unsigned int r, float p) {
   return (float)(r >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
+// ----------------------------------------------------------------------------- dropout RNG
+// Dropout masks use a cheaper counter-based generator than Philox: 32-bit integer multiplies are
+// quarter rate on CDNA (16 clk per wave instruction), so one Philox4x32-10 call (40 multiplies)
+// costs ~800 clk per 4 keep decisions -- the dropout epilogues and the fused LayerNorm-backward
+// consumer were VALU-bound on it.  Here: a 32-bit avalanche hash ("lowbias32": 2 multiplies,
+// measured bias 0.17 bits) of a per-row hash plus the column pair gives 2 x 16 uniform bits:
+//   key  = hash(seed, site offset + step * MFP_RNG_STEP_STRIDE)       once per kernel
+//   rowh = hash32(row * 0x9E3779B1 ^ key)                             once per row
+//   u16(col), u16(col + 1) = halves of hash32(rowh + (col >> 1))      col even
+//   keep iff u16 >= thr16 = round(p * 65536)   ([TF-EXT] tf.nn.dropout keeps where uniform >= rate)
+// ~7x fewer VALU cycles per decision; forward epilogue and backward consumers regenerate the
+// identical mask from (seed, offset, step, row, col).
+__device__ __forceinline__ unsigned int hash32(unsigned int x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned int drop_key(unsigned long long seed, unsigned long long rng_off) {
+  return hash32((unsigned int)seed ^ hash32((unsigned int)rng_off ^ 0x68E31DA4u) ^
+                (unsigned int)(seed >> 32) * 0x9E3779B1u ^ hash32((unsigned int)(rng_off >> 32) + 0xB5297A4Du));
+}
+__device__ __forceinline__ unsigned int drop_thr16(float p) { return (unsigned int)(p * 65536.f + 0.5f); }
+__device__ __forceinline__ unsigned int drop_row(unsigned int key, unsigned int row) {
+  return hash32(row * 0x9E3779B1u ^ key);
+}
+// keep decisions of the 4 consecutive columns col .. col+3 (col % 4 == 0) of the row hashed as rowh
+__device__ __forceinline__ void drop_keep4(unsigned int rowh, unsigned int col, unsigned int thr16, bool (&keep)[4]) {
+  const unsigned int a = hash32(rowh + (col >> 1)), b = hash32(rowh + (col >> 1) + 1u);
+  keep[0] = (a & 0xffffu) >= thr16; keep[1] = (a >> 16) >= thr16;
+  keep[2] = (b & 0xffffu) >= thr16; keep[3] = (b >> 16) >= thr16;
+}
+
 // ----------------------------------------------------------------------------- XCD-aware block order
 // Hardware places block b on XCD b % 8 (speed only, never correctness).  This bijective remap gives
 // every XCD a CONTIGUOUS range of logical ids, so neighbouring logical ids (tiles sharing an operand

@@ -72,6 +72,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   const int flags = p.flags;
   const float inv_keep = (flags & MFP_GEMM_DROPOUT) ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
   const unsigned long long rng_off = p.offset + (p.step_ptr ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  const unsigned int dkey = drop_key(p.seed, rng_off), dthr = drop_thr16(p.dropout_p);
   f32x4 bias4[NQ];
 #pragma unroll
   for (int b = 0; b < NQ; ++b) {
@@ -110,10 +111,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
       if (skip) x = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (flags & MFP_GEMM_DROPOUT) {
-        unsigned int rnd[4];
-        philox4x32(p.seed, (unsigned int)row, (unsigned int)(col >> 2), rng_off, rnd);
+        bool keep[4];
+        drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)col, dthr, keep);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = philox_keep(rnd[r], p.dropout_p) ? x[r] * inv_keep : 0.f;
+        for (int r = 0; r < 4; ++r) x[r] = keep[r] ? x[r] * inv_keep : 0.f;
       }
       if (flags & MFP_GEMM_RESIDUAL) x += *reinterpret_cast<const f32x4*>(p.residual + o);
       if (!p.out_bf16 && (flags & MFP_GEMM_ACCUM)) x += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + o);

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     const float inv_keep = DROPOUT ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
     const unsigned long long rng_off =
         p.offset + ((DROPOUT && p.step_ptr) ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+    const unsigned int dkey = drop_key(p.seed, rng_off), dthr = drop_thr16(p.dropout_p);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), see the math waves
     __syncthreads();
 
@@ -294,10 +295,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = skip ? 0.f : x[r];
           if (DROPOUT) {
-            unsigned int rnd[4];
-            philox4x32(p.seed, (unsigned int)row, ocolb >> 4, rng_off, rnd);
+            bool keep[4];
+            drop_keep4(drop_row(dkey, (unsigned int)row), ocolb >> 2, dthr, keep);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = philox_keep(rnd[r], p.dropout_p) ? x[r] * inv_keep : 0.f;
+            for (int r = 0; r < 4; ++r) x[r] = keep[r] ? x[r] * inv_keep : 0.f;
           }
           x += __builtin_bit_cast(f32x4, ex[eset][i]);
           raw = __builtin_bit_cast(u32x4, x);

@@ -63,8 +63,8 @@ constexpr int LN_BWD_ROWS = 32;  // rows per workgroup (4 waves x 8 rows); 64 an
 
 // Optional fused consumer: the LN-backward output dx is, in the DeepSVG block, immediately fed to
 // the backward of a Dropout + Dense pair (x1 = x + Dropout(Dense(.))): when `ddrop` is given the
-// kernel also emits ddrop = cdt(keep ? dx/(1-p) : 0) with the Philox keying of the GEMM epilogue
-// (a lane holds 4 consecutive columns = one Philox call) and the column sums of ddrop (the Dense
+// kernel also emits ddrop = cdt(keep ? dx/(1-p) : 0) with the dropout keying of the GEMM epilogue
+// (a lane holds 4 consecutive columns = one drop_keep4 call) and the column sums of ddrop (the Dense
 // bias gradient) as a third partial vector -- saving a full re-read of dx and two launches.
 template <typename TDY, int NVEC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long rng_off = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const unsigned int dkey = drop_key(seed, rng_off), dthr = drop_thr16(drop_p);
   float dg[NVEC * 4], db[NVEC * 4], dc[NVEC * 4];
 #pragma unroll
   for (int j = 0; j < NVEC * 4; ++j) { dg[j] = 0.f; db[j] = 0.f; dc[j] = 0.f; }
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     const int row = row0 + rr;
     if (row >= T) break;
     const float mu = mean[row], rs = rstd[row];
+    const unsigned int rowh = drop_row(dkey, (unsigned int)row);
     const float* xr = x + (long long)row * D;
     const TDY* dyr = dy + (long long)row * D;
     float xh[NVEC * 4], gy[NVEC * 4];
@@ -137,12 +139,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
       *reinterpret_cast<float4*>(dxr + c) = o;
       if (ddrop != nullptr) {
         if (drop_p > 0.f) {
-          unsigned int rnd[4];
-          philox4x32(seed, (unsigned int)row, (unsigned int)(c >> 2), rng_off, rnd);
-          o.x = philox_keep(rnd[0], drop_p) ? o.x * inv_keep : 0.f;
-          o.y = philox_keep(rnd[1], drop_p) ? o.y * inv_keep : 0.f;
-          o.z = philox_keep(rnd[2], drop_p) ? o.z * inv_keep : 0.f;
-          o.w = philox_keep(rnd[3], drop_p) ? o.w * inv_keep : 0.f;
+          bool keep[4];
+          drop_keep4(rowh, (unsigned int)c, dthr, keep);
+          o.x = keep[0] ? o.x * inv_keep : 0.f;
+          o.y = keep[1] ? o.y * inv_keep : 0.f;
+          o.z = keep[2] ? o.z * inv_keep : 0.f;
+          o.w = keep[3] ? o.w * inv_keep : 0.f;
         }
         TDY* dr = ddrop + (long long)row * D + c;
         if constexpr (sizeof(TDY) == 4) {

@@ -102,8 +102,7 @@ __global__ void cast_kernel(const float* __restrict__ src, unsigned short* __res
     for (long long j = n & ~3ll; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
 }
 
-// thread = (row, 4 consecutive columns): matches the Philox keying of the GEMM epilogue
-// (ctr = (row, col >> 2)).  Block = 256 threads = (N/4 column quads) x (1024/N rows per pass).
+// thread = (row, 4 consecutive columns): the dropout keying of the GEMM epilogue (common.h).  Block = 256 threads = (N/4 column quads) x (1024/N rows per pass).
 template <typename TOUT>
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dx, TOUT* __restrict__ dy,
                                                           float* __restrict__ colsum_part, int M, int N,
@@ -114,6 +113,7 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
   const unsigned long long offset = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
   const int nq = N >> 2;                      // column quads per row
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const unsigned int dkey = drop_key(seed, offset), dthr = drop_thr16(p);
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   for (int qb = blockIdx.x * 256; qb < nq; qb += gridDim.x * 256) {   // usually one pass
     // threads cover quads [qb, qb+256) of a row when nq >= 256, else several rows at once
@@ -126,12 +126,12 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
         const long long o = (long long)r * N + q * 4;
         float4 v = *reinterpret_cast<const float4*>(dx + o);
         if (p > 0.f) {
-          unsigned int rnd[4];
-          philox4x32(seed, (unsigned int)r, (unsigned int)q, offset, rnd);
-          v.x = philox_keep(rnd[0], p) ? v.x * inv_keep : 0.f;
-          v.y = philox_keep(rnd[1], p) ? v.y * inv_keep : 0.f;
-          v.z = philox_keep(rnd[2], p) ? v.z * inv_keep : 0.f;
-          v.w = philox_keep(rnd[3], p) ? v.w * inv_keep : 0.f;
+          bool keep[4];
+          drop_keep4(drop_row(dkey, (unsigned int)r), (unsigned int)(q * 4), dthr, keep);
+          v.x = keep[0] ? v.x * inv_keep : 0.f;
+          v.y = keep[1] ? v.y * inv_keep : 0.f;
+          v.z = keep[2] ? v.z * inv_keep : 0.f;
+          v.w = keep[3] ? v.w * inv_keep : 0.f;
         }
         if constexpr (sizeof(TOUT) == 4) {
           *reinterpret_cast<float4*>(dy + o) = v;

@@ -86,7 +86,7 @@ typedef struct mfp_gemm_args {
   float dropout_p;
   uint64_t seed;
   uint64_t offset;
-  const int32_t* step_ptr; /* device; Philox offset += *step_ptr * MFP_RNG_STEP_STRIDE (graph replay) */
+  const int32_t* step_ptr; /* device; RNG offset += *step_ptr * MFP_RNG_STEP_STRIDE (graph replay) */
 } mfp_gemm_args;
 
 int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);
@@ -102,7 +102,7 @@ int mfp_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
 /* dx[t] = (dres ? dres[t] : 0) + LN'(dy)[t]; dgamma/dbeta f32 [D].
  * workspace: mfp_layernorm_bwd_workspace_bytes(T,D). dx may alias dres.
  * Optional fused consumer (ddrop != NULL): also writes ddrop = cdt(keep ? dx/(1-p) : 0) with the
- * Philox stream of MFP_GEMM_DROPOUT / mfp_dropout_bwd and drop_colsum[D] = column sums of ddrop
+ * dropout stream of MFP_GEMM_DROPOUT / mfp_dropout_bwd and drop_colsum[D] = column sums of ddrop
  * (the gradient of the Dense bias behind the Dropout, transformer.py:218-219,224-225). */
 int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx, float* dgamma,
@@ -219,7 +219,7 @@ int mfp_transpose_cast_bf16(const float* w, uint16_t* out, const int64_t* seg_of
                             const int32_t* seg_cols, int32_t nseg, int32_t max_tiles, mfp_stream_t stream);
 
 /* dy = cdt( keep(seed,offset)[m][n] ? dx[m][n]/(1-p) : 0 ), colsum[n] = sum_m dy (bias grad).
- * Same Philox stream as MFP_GEMM_DROPOUT for equal (seed, offset); p == 0 -> plain cast.
+ * Same dropout stream as MFP_GEMM_DROPOUT for equal (seed, offset); p == 0 -> plain cast.
  * workspace: mfp_colsum_workspace_bytes(M, N). */
 size_t mfp_colsum_workspace_bytes(int32_t M, int32_t N);
 int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* workspace, size_t workspace_bytes,
