@@ -27,7 +27,10 @@ class StepCtx:
     def __init__(self, store, B: int, S: int, nvalid: torch.Tensor, training: bool, dropout: float,
                  seed: int, step_ptr: Optional[torch.Tensor], side_stream=None):
         self.store, self.B, self.S, self.T = store, B, S, B * S
-        self.side = side_stream
+        # side_stream: one HIP stream or a list; [0] carries the per-block weight gradients, the others
+        # let the independent gradient products at the very end of the backward pass run side by side
+        self.sides = list(side_stream) if isinstance(side_stream, (list, tuple)) else ([side_stream] if side_stream is not None else [])
+        self.side = self.sides[0] if self.sides else None
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
         self.nvalid = nvalid
         self.training = training
@@ -36,7 +39,7 @@ class StepCtx:
         self.step_ptr = step_ptr
         self.cdt = store.compute_dtype
 
-    def on_side(self, fn, *tensors):
+    def on_side(self, fn, *tensors, which: int = 0):
         """Run ``fn`` (weight-gradient GEMMs: off the critical path, only Adam needs them) on the
         side HIP stream, forked after everything enqueued so far on the current stream.  Every
         kernel of the step leaves most of a CU idle (profiles/r01_gemm_qkv_timeline.txt), so the
@@ -44,16 +47,17 @@ class StepCtx:
         before the gradients are consumed."""
         if self.side is None:
             return fn()
+        side = self.sides[which % len(self.sides)]
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             fn()
         for t in tensors:   # their memory must not be recycled by main-stream allocations too early
-            t.record_stream(self.side)
+            t.record_stream(side)
 
     def join_side(self):
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+        for side in self.sides:
+            torch.cuda.current_stream().wait_stream(side)
 
     def to_cdt(self, x: torch.Tensor) -> torch.Tensor:
         if self.cdt == torch.float32:
@@ -82,17 +86,22 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     if L.num_keys or onehot:
         dh_c = ctx.to_cdt(dh)
 
-        def wgrads():
-            for j, k in enumerate(L.num_keys):
-                width = xs[j].shape[1]
-                ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
-                         out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
-                         colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
-            if onehot:
-                P = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
-                ops.gemm(P, dh_c, L.table_rows_pad, D, T, a_kmajor=False, b_kmajor=False,
-                         out=st.tables_padded(st.g), splitk=ops.wgrad_splitk(T, L.table_rows_pad, D))
-        ctx.on_side(wgrads, dh_c, idx_all, *xs, *codes)
+        # the last products of the backward pass: nothing on the main stream overlaps them any more,
+        # so the independent ones go to different side streams and share the chip
+        def wgrad_dense(j, k):
+            width = xs[j].shape[1]
+            ops.gemm(dh_c, xs[j], D, width, T, a_kmajor=False, b_kmajor=False,
+                     out=st.grad("encoder/input_%s/kernel" % k), rowskip_a=codes[j],
+                     colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
+
+        def wgrad_tables():
+            P = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
+            ops.gemm(P, dh_c, L.table_rows_pad, D, T, a_kmajor=False, b_kmajor=False,
+                     out=st.tables_padded(st.g), splitk=ops.wgrad_splitk(T, L.table_rows_pad, D))
+        if onehot:
+            ctx.on_side(wgrad_tables, dh_c, idx_all, which=0)
+        for j, k in enumerate(L.num_keys):
+            ctx.on_side(lambda j=j, k=k: wgrad_dense(j, k), dh_c, xs[j], codes[j], which=j + 1)
     if not onehot:
         ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
     ctx.join_side()   # last node of the backward pass: every weight gradient is complete after this

@@ -265,8 +265,8 @@ class MFP:
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, targets, masks)
             loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True)
         loss.backward()
-        if self.model.side_stream is not None:   # weight gradients run on the side stream
-            torch.cuda.current_stream().wait_stream(self.model.side_stream)
+        for side in self.model.side_streams:   # weight gradients run on the side streams
+            torch.cuda.current_stream().wait_stream(side)
         return sums
 
     def _apply(self):

@@ -44,14 +44,16 @@ class Model:
         self.decoder = Decoder(input_columns, self.store, context=context, latent_dim=latent_dim,
                                dropout=dropout, l2=l2)
         self.step_ptr = None  # device int32 step counter (set by the optimizer) for dropout offsets
-        self.side_stream = torch.cuda.Stream(device=self.store.device) if self.store.device.type == "cuda" else None
+        cuda = self.store.device.type == "cuda"
+        self.side_stream = torch.cuda.Stream(device=self.store.device) if cuda else None
+        self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=self.store.device) for _ in range(2)] if cuda else []
         self._first = _first_seq_key(input_columns)
 
     def make_ctx(self, inputs: Dict, training: bool) -> StepCtx:
         B, S = inputs[self._first].shape[:2]
         nvalid = (inputs["length"].reshape(-1) + 1).to(torch.int32)
         return StepCtx(self.store, B, S, nvalid, training, self.dropout, self.seed, self.step_ptr,
-                       self.side_stream if training else None)
+                       self.side_streams if training and self.side_streams else None)
 
     def hidden(self, inputs: Dict, training: bool = False, ctx: Optional[StepCtx] = None):
         ctx = ctx or self.make_ctx(inputs, training)
