@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 #include "gemm_ws.h"
+#include "gemm_wg.h"
 
 int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
   static int ncu = 0;
@@ -626,7 +627,10 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
     MFP_CHECK_LAUNCH();
     return MFP_OK;
   }
-  int rc = a->in_dtype == MFP_BF16 ? launch_gemm<unsigned short>(a, p, splitk, st)
+  static const bool wg_off = getenv("MFP_GEMM_NO_WG") != nullptr;   // benchmarking only
+  int rc;
+  if (!wg_off && ws_path && wg_eligible(a, splitk)) rc = launch_wg(p, a->M, a->N, splitk, st);
+  else rc = a->in_dtype == MFP_BF16 ? launch_gemm<unsigned short>(a, p, splitk, st)
                                     : launch_gemm<float>(a, p, splitk, st);
   if (rc != MFP_OK) return rc;
   MFP_CHECK_LAUNCH();

@@ -155,11 +155,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
 
 
 def wgrad_splitk(T: int, M: int, N: int) -> int:
-    """Split the token contraction so that ~2 workgroups per CU are in flight."""
+    """Split the token contraction so that the 128x128 output tiles x splits give about one
+    persistent workgroup per CU (the streaming wgrad kernel keeps 8 waves and ~80 KB of LDS per
+    workgroup: one per CU), in multiples of 8 (a k-chunk's tiles then share an XCD)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    sk = max(1, min(32, 288 // max(tiles, 1)))
+    sk = max(1, 256 // max(tiles, 1))
     if sk >= 8:
-        sk = (sk + 4) // 8 * 8   # multiples of 8: the kernel then keeps a k-chunk's tiles on one XCD
+        sk = sk // 8 * 8
     while sk > 1 and T // sk < 256:
         sk //= 2
     return sk
