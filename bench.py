@@ -55,6 +55,23 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic_per_launch(kernel):
+    """HBM bytes per launch of `kernel` from the L2 memory-side counters (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes over this same bench command, FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md; tools/pmc_step.sh writes the file).  None when not collected."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        table = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    tot, calls = 0.0, 0.0
+    for k, v in table.items():
+        if k.startswith(kernel.split("<")[0]) and (kernel.startswith("gemm_w") or k == kernel):
+            tot += (v["read_mb"] + v["write_mb"]) * 1e6
+            calls += v["calls_per_step"]
+    return tot / calls if calls else None
+
+
 def cpu_baseline(ic, budget_s=12.0):
     """Oracle (checker only) timed as the CPU baseline: same train step, eager torch-CPU f32."""
     import torch
@@ -181,14 +198,19 @@ def main():
         total_ms = sum(a[3] for a in agg.values())
         table = sorted(agg.items(), key=lambda kv: -kv[1][3])
         name, (cnt, flops, nbytes, ms) = table[0]
-        if flops > 0:
-            achieved = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None}
+        # every kernel of this path is a skinny product or an element stream: price the dominant one
+        # against BOTH roofs and report the one it is closer to (the binding roof)
+        tf = flops / (ms * 1e-3) / 1e12
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        f_mfma, f_hbm = tf / MFMA_BF16_DENSE_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
+        if f_hbm >= f_mfma:
+            roof = {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": f_hbm, "mfma_frac": f_mfma}
         else:
-            achieved = nbytes / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+            roof = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": f_mfma, "hbm_frac": f_hbm}
+        roof["algorithmic_bytes_per_launch"] = nbytes / cnt
+        roof["traffic"] = pmc_traffic_per_launch(name)
         roof.update({"launches_per_step": cnt // nprof, "avg_launch_us": 1e3 * ms / cnt,
                      "share_of_instrumented_kernel_time": ms / total_ms,
                      "step": {"achieved": step_tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -147,8 +147,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
     if nbytes:
         ws = workspace(nbytes, A.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    name = "gemm_kernel<%s,%s,%s>" % ("bf16" if A.dtype == torch.bfloat16 else "f32",
-                                      "Ak" if a_kmajor else "Am", "Bk" if b_kmajor else "Bn")
+    bf = A.dtype == torch.bfloat16
+    if bf and a_kmajor and b_kmajor and K in (256, 512) and splitk == 1:
+        name = "gemm_ws_kernel"          # weight-stationary Dense forward / dgrad (csrc/gemm_ws.h)
+    elif bf and not a_kmajor and not b_kmajor and splitk >= 8 and splitk % 8 == 0:
+        name = "gemm_wg_kernel"          # streaming weight gradient (csrc/gemm_wg.h) + split-K reduce
+    else:
+        name = "gemm_kernel<%s,%s,%s>" % ("bf16" if bf else "f32", "Ak" if a_kmajor else "Am",
+                                          "Bk" if b_kmajor else "Bn")
     with _timed(name, 2 * M * N * K, (M * K + N * K) * _esz(A) + M * N * _esz(out)):
         check(lib.mfp_gemm(ctypes.byref(a), _stream()), "mfp_gemm")
     return out

@@ -41,3 +41,10 @@ for k in names:
     R += r; W += w
     print("%-72s %8.1f %10.1f %10.1f" % (k, tot["FETCH_SIZE"][k][0] / nsteps, r, w))
 print("%-72s %8s %10.1f %10.1f   total %.1f MB/step" % ("TOTAL", "", R, W, R + W))
+import json
+json.dump({"note": "HBM MB per train step per kernel; read = 2 x FETCH_SIZE (gfx950), write = WRITE_SIZE; rocprofv3 --pmc, separate passes",
+           "steps_in_window": nsteps, "total_read_mb": R, "total_write_mb": W,
+           "kernels": {k: {"calls_per_step": tot["FETCH_SIZE"][k][0] / nsteps,
+                           "read_mb": 2 * tot["FETCH_SIZE"][k][1] / 1024 / nsteps,
+                           "write_mb": tot["WRITE_SIZE"][k][1] / 1024 / nsteps} for k in names}},
+          open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
