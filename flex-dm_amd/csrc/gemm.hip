@@ -491,6 +491,9 @@ int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
     ncu = n;
   }
   if (a->K == 256) return launch_ws_epi<8, 2>(a, p, ncu, st);
+  if (a->K == 768)   // plain epilogue only (ws_eligible): the fused-QKV input gradient
+    return a->out_dtype == MFP_BF16 ? launch_ws<24, 2, WS_EPI_PLAIN, false, true>(p, ncu, st)
+                                    : launch_ws<24, 2, WS_EPI_PLAIN, false, false>(p, ncu, st);
   return launch_ws_epi<16, 2>(a, p, ncu, st);
 }
 

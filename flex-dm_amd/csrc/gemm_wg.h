@@ -24,7 +24,6 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
   constexpr int CS_LD = BN + 4;                                            // f32 row stride of the output stage
   static_assert(CH == 4, "64 x 128 tile = 1024 chunks over 256 memory threads");
   static_assert(BM * CS_LD * 4 <= 2 * STAGE_B, "output stage aliases the two operand stages");
-  constexpr unsigned int OOB = 0xFFFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ float colsum_s[16][BM];   // memory waves: per row-group column sums of A
 

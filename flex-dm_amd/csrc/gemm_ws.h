@@ -34,15 +34,15 @@ enum { WS_EPI_PLAIN = 0, WS_EPI_F32X = 1, WS_EPI_RELUBWD = 2 };
 // vmcnt bookkeeping is exact (with control flow in the loop it falls back to vmcnt(0) per tile).
 template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, int slices) {
-  constexpr int NQ = 32 / KS, BM = 16 * MT, WBN = 16 * NQ, BN = 4 * WBN;
+  constexpr int NQ = KS == 8 ? 4 : (KS == 16 ? 2 : 1), BM = 16 * MT, WBN = 16 * NQ, BN = 4 * WBN;
   constexpr int ROWB = 64 * KS, CPR = ROWB / 16, XSTAGE = BM * ROWB;      // X stage: [BM][K] bf16
   constexpr int A_CH = BM * CPR / 256;
   constexpr int OS = OUT_BF16 ? 2 : 4, OROWB = BN * OS, OCPR = OROWB / 16, OSTAGE = BM * OROWB;
   constexpr int O_CH = BM * OCPR / 256;                                   // output chunks per memory thread
-  constexpr int OU = OUT_BF16 ? NQ / 2 : NQ;                              // 16-byte output units per lane and row
+  constexpr bool PAIRED = OUT_BF16 && NQ >= 2;   // bf16 quads b, b+1 adjacent: one 16-byte stage unit
   constexpr int XD = KS == 8 ? 4 : 2;   // X tiles in flight in registers (16 KB / 32 KB each)
   constexpr int ED = 4;                 // rotating epilogue-operand sets (3 live: in use + two in flight)
-  static_assert((BM * CPR) % 256 == 0 && (BM * OCPR) % 256 == 0 && NQ >= 2, "tile/thread mismatch");
+  static_assert((BM * CPR) % 256 == 0 && (BM * OCPR) % 256 == 0 && NQ >= 1, "tile/thread mismatch");
   constexpr unsigned int OOB = 0xFFFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* const xst = smem_raw;                 // 2 X stages
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     // ======================================================================== MATH waves
     // Output column (local to the wave's 16 NQ block) of quad b for lane group q: f32 16b + 4q,
     // bf16 32(b/2) + 8q + 4(b%2) -- the lane's 16-byte unit (4 f32 / 8 bf16) is one stage chunk.
-    auto colq = [&](int b, int q) { return OUT_BF16 ? 32 * (b >> 1) + 8 * q + 4 * (b & 1) : 16 * b + 4 * q; };
+    auto colq = [&](int b, int q) { return PAIRED ? 32 * (b >> 1) + 8 * q + 4 * (b & 1) : 16 * b + 4 * q; };
     const int n_wave = n_slice + wave * WBN;
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, 0x7FFFFFFF, 0x00020000);
     // weight row feeding MFMA row i = 4q + e of quad b is column colq(b, q) + e (transposed MFMA:
@@ -102,11 +102,15 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     const float relu_floor = (p.flags & MFP_GEMM_RELU) ? 0.f : -3.0e38f;   // branch-free ReLU switch
     // fragment reads: row a*16 + li, logical chunk 4 ks + lg stored at slot chunk ^ li
     const unsigned char* frag_base = xst + li * ROWB;
-    // output stage writes: row a*16 + li, logical 16-byte chunk c at slot c ^ (li & 7)
+    // output stage writes: row a*16 + li, byte offset `o` of the row at slot (o/16) ^ (li & 7)
     unsigned char* ostw = ost + li * OROWB;
-    int oslot[OU];
+    auto oaddr = [&](int b) {
+      const int o = (wave * WBN + colq(b, lg)) * OS;
+      return (((o >> 4) ^ (li & 7)) << 4) + (o & 15);
+    };
+    int oslot[NQ];
 #pragma unroll
-    for (int u = 0; u < OU; ++u) oslot[u] = ((wave * 4 * OU + 4 * u + lg) ^ (li & 7)) * 16;
+    for (int b = 0; b < NQ; ++b) oslot[b] = oaddr(b);
     // Every prologue load retires HERE: a first use inside the loop would make the compiler place
     // its preheader-derived vmcnt waits in the loop body.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -150,17 +154,21 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[b][r] = fmaxf(v[b][r], relu_floor);
         }
-        if (OUT_BF16) {
+        if (PAIRED) {
 #pragma unroll
           for (int b = 0; b < NQ; b += 2) {
             const u32x4 pk = {pack_bf16x2(v[b][0], v[b][1]), pack_bf16x2(v[b][2], v[b][3]),
-                              pack_bf16x2(v[b + 1][0], v[b + 1][1]), pack_bf16x2(v[b + 1][2], v[b + 1][3])};
-            *reinterpret_cast<u32x4*>(ow + a * 16 * OROWB + oslot[b >> 1]) = pk;
+                              pack_bf16x2(v[(b + 1) % NQ][0], v[(b + 1) % NQ][1]),
+                              pack_bf16x2(v[(b + 1) % NQ][2], v[(b + 1) % NQ][3])};
+            *reinterpret_cast<u32x4*>(ow + a * 16 * OROWB + oslot[b]) = pk;
           }
+        } else if (OUT_BF16) {   // NQ == 1: one quad = 8 bytes
+          const u32x2 pk = {pack_bf16x2(v[0][0], v[0][1]), pack_bf16x2(v[0][2], v[0][3])};
+          *reinterpret_cast<u32x2*>(ow + a * 16 * OROWB + oslot[0]) = pk;
         } else {
 #pragma unroll
           for (int b = 0; b < NQ; ++b)
-            *reinterpret_cast<f32x4*>(ow + a * 16 * OROWB + oslot[OUT_BF16 ? 0 : b]) = v[b];
+            *reinterpret_cast<f32x4*>(ow + a * 16 * OROWB + oslot[b]) = v[b];
         }
       }
       __syncthreads();
@@ -189,16 +197,15 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     // row's 16-byte chunk (slot ^ (row & 15)): the swizzle is applied on the SOURCE address so
     // the ds_write stays linear and the fragment ds_read_b128 (16 rows x one chunk per lane
     // group) is conflict-free.
-    static_assert(256 % CPR == 0, "X chunk column must not depend on c");
-    constexpr int XRS = 256 / CPR;                   // rows between a thread's consecutive chunks
-    const int xrow0 = mt / CPR, xpc = mt % CPR;
     unsigned int voa[A_CH];
+    int lsa[A_CH], xrow[A_CH];
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
-      const int row = xrow0 + c * XRS, sc = xpc ^ (row & 15);
+      const int ch = mt + c * 256, row = ch / CPR, pc = ch % CPR, sc = pc ^ (row & 15);
+      xrow[c] = row;
       voa[c] = (unsigned int)((row * p.lda + sc * 8) * 2);
+      lsa[c] = row * ROWB + pc * 16;
     }
-    const int lsa0 = xrow0 * ROWB + xpc * 16;
     u32x4 xa[XD][A_CH];
     auto gload = [&](u32x4 (&dst)[A_CH], int t) {
       // branch-free: a dead tile / row past M turns the offset into 0xFFFFFFFF (out of range ->
@@ -208,14 +215,14 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
       const int so = (row0 * p.lda * 2) & live;
 #pragma unroll
       for (int c = 0; c < A_CH; ++c) {
-        const int ok = live & ((row0 + xrow0 + c * XRS - p.M) >> 31);
+        const int ok = live & ((row0 + xrow[c] - p.M) >> 31);
         const unsigned int vo = voa[c] | ~(unsigned int)ok;
         dst[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, vo, so, 0));
       }
     };
     auto lstore = [&](const u32x4 (&src)[A_CH], int stage) {
 #pragma unroll
-      for (int c = 0; c < A_CH; ++c) *reinterpret_cast<u32x4*>(xst + stage * XSTAGE + lsa0 + c * XRS * ROWB) = src[c];
+      for (int c = 0; c < A_CH; ++c) *reinterpret_cast<u32x4*>(xst + stage * XSTAGE + lsa[c]) = src[c];
     };
 
     // ---- output plan: chunk ch = mt + 256 i -> stage row ch / OCPR, logical chunk ch % OCPR: a
@@ -329,7 +336,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
 // Host side: can this call take the weight-stationary kernel?
 inline bool ws_eligible(const mfp_gemm_args* a, int splitk) {
   if (!(a->a_kmajor && a->b_kmajor) || a->in_dtype != MFP_BF16 || splitk != 1) return false;
-  if (a->K != 256 && a->K != 512) return false;
+  if (a->K != 256 && a->K != 512 && a->K != 768) return false;
+  if (a->K == 768 && (a->flags & ~(MFP_GEMM_BIAS | MFP_GEMM_RELU))) return false;   // plain epilogue only
   const int f = a->flags;
   if (f & (MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A)) return false;
   const bool f32x = (f & (MFP_GEMM_RESIDUAL | MFP_GEMM_ACCUM)) != 0;
@@ -346,7 +354,7 @@ inline bool ws_eligible(const mfp_gemm_args* a, int splitk) {
 
 template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16>
 int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
-  constexpr int NQ = 32 / KS, BN = 64 * NQ, XSTAGE = 16 * MT * 64 * KS, OSTAGE = 16 * MT * BN * (OUT_BF16 ? 2 : 4);
+  constexpr int NQ = KS == 8 ? 4 : (KS == 16 ? 2 : 1), BN = 64 * NQ, XSTAGE = 16 * MT * 64 * KS, OSTAGE = 16 * MT * BN * (OUT_BF16 ? 2 : 4);
   constexpr int lds = 2 * XSTAGE + 2 * OSTAGE;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {

@@ -171,19 +171,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, fl
 
 // The chunk table (segment id, start, length per <=4096-element chunk) is static per model: it
 // is built once on the host into caller memory and uploaded by the caller (no library state).
-// out[off + c*rows + r] = bf16(w[off + r*cols + c]) for each listed [rows][cols] matrix of the flat
+// out[ooff + c*old + r] = bf16(w[off + r*cols + c]) for each listed [rows][cols] matrix of the flat
 // buffer: the transposed bf16 shadow that lets a dgrad (dY * W with W stored [out][in]) run as the
-// k-major weight-stationary product.  grid = (max tiles of 32x32, matrices).
+// k-major weight-stationary product (old > rows places several matrices side by side, e.g. the
+// fused QKV transposed as one [D][3D]).  grid = (max tiles of 32x32, matrices).
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ w,
                                                              unsigned short* __restrict__ out,
                                                              const long long* __restrict__ seg_off,
                                                              const int* __restrict__ seg_rows,
-                                                             const int* __restrict__ seg_cols) {
+                                                             const int* __restrict__ seg_cols,
+                                                             const long long* __restrict__ seg_ooff,
+                                                             const int* __restrict__ seg_old) {
   __shared__ float tile[32][33];
   const int sgi = blockIdx.y, rows = seg_rows[sgi], cols = seg_cols[sgi];
   const int tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
   if ((int)blockIdx.x >= tiles_c * tiles_r) return;
-  const long long off = seg_off[sgi];
+  const long long off = seg_off[sgi], ooff = seg_ooff[sgi];
+  const int old = seg_old[sgi];
   const int r0 = (blockIdx.x / tiles_c) * 32, c0 = (blockIdx.x % tiles_c) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + ty + 8 * k, r = r0 + tx;
-    if (r < rows && c < cols) out[off + (long long)c * rows + r] = f32_to_bf16(tile[tx][ty + 8 * k]);
+    if (r < rows && c < cols) out[ooff + (long long)c * old + r] = f32_to_bf16(tile[tx][ty + 8 * k]);
   }
 }
 
@@ -316,12 +320,13 @@ extern "C" int mfp_colsum(const void* X, float* colsum, void* workspace, size_t 
 }
 
 extern "C" int mfp_transpose_cast_bf16(const float* w, uint16_t* out, const int64_t* seg_off,
-                                       const int32_t* seg_rows, const int32_t* seg_cols, int32_t nseg,
+                                       const int32_t* seg_rows, const int32_t* seg_cols,
+                                       const int64_t* seg_ooff, const int32_t* seg_old, int32_t nseg,
                                        int32_t max_tiles, mfp_stream_t stream) {
-  MFP_CHECK_ARG(w && out && seg_off && seg_rows && seg_cols && nseg > 0 && max_tiles > 0);
+  MFP_CHECK_ARG(w && out && seg_off && seg_rows && seg_cols && seg_ooff && seg_old && nseg > 0 && max_tiles > 0);
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((unsigned)max_tiles, (unsigned)nseg), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), w, out, reinterpret_cast<const long long*>(seg_off),
-                     seg_rows, seg_cols);
+                     seg_rows, seg_cols, reinterpret_cast<const long long*>(seg_ooff), seg_old);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

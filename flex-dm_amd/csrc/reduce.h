@@ -18,18 +18,18 @@ __global__ __launch_bounds__(256) static void reduce_rows_kernel(const float* __
   __shared__ float red[G][COLS + 1];
   const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
   const long long c = (long long)blockIdx.x * COLS + col;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // 8 independent loads in flight per thread: the kernel is a chain of dependent L2/HBM round
+  // trips otherwise (P/G rows per thread, ~1 us each)
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < N) {
     int p = grp;
-    for (; p + 3 * G < P; p += 4 * G) {
-      s0 += part[(long long)p * pstride + c];
-      s1 += part[(long long)(p + G) * pstride + c];
-      s2 += part[(long long)(p + 2 * G) * pstride + c];
-      s3 += part[(long long)(p + 3 * G) * pstride + c];
+    for (; p + 7 * G < P; p += 8 * G) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += part[(long long)(p + u * G) * pstride + c];
     }
-    for (; p < P; p += G) s0 += part[(long long)p * pstride + c];
+    for (; p < P; p += G) s[0] += part[(long long)p * pstride + c];
   }
-  red[grp][col] = (s0 + s1) + (s2 + s3);
+  red[grp][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (grp == 0 && c < N) {
     float s = 0.f;

@@ -86,7 +86,7 @@ SIGNATURES = {
                                        POINTER(c_int32), POINTER(c_int32)]),
     "mfp_adam_keras": (c_int32, [c_void_p] * 9 + [c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]
                        + [c_float] * 6 + [c_void_p]),
-    "mfp_transpose_cast_bf16": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_void_p]),
+    "mfp_transpose_cast_bf16": (c_int32, [c_void_p] * 7 + [c_int32, c_int32, c_void_p]),
     "mfp_cast_f32_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mfp_colsum_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mfp_dropout_bwd": (c_int32, [c_void_p] * 4 + [c_size_t, c_int32, c_int32, c_float, c_uint64,

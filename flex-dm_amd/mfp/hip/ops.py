@@ -356,22 +356,26 @@ def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
 
 
 class TransposeTable:
-    """Device table of the [rows][cols] matrices (flat offset, rows, cols) whose transposed bf16
-    copy mfp_transpose_cast_bf16 maintains."""
+    """Device table of the [rows][cols] matrices (flat offset, rows, cols[, out offset, out row
+    stride]) whose transposed bf16 copy mfp_transpose_cast_bf16 maintains."""
 
     def __init__(self, segs, device):
+        segs = [tuple(s) + ((s[0], s[1]) if len(s) == 3 else ()) for s in segs]
         self.nseg = len(segs)
         self.off = torch.tensor([s[0] for s in segs], dtype=torch.int64, device=device)
         self.rows = torch.tensor([s[1] for s in segs], dtype=torch.int32, device=device)
         self.cols = torch.tensor([s[2] for s in segs], dtype=torch.int32, device=device)
-        self.max_tiles = max(((r + 31) // 32) * ((c + 31) // 32) for _, r, c in segs)
+        self.ooff = torch.tensor([s[3] for s in segs], dtype=torch.int64, device=device)
+        self.old = torch.tensor([s[4] for s in segs], dtype=torch.int32, device=device)
+        self.max_tiles = max(((s[1] + 31) // 32) * ((s[2] + 31) // 32) for s in segs)
 
 
 def transpose_cast_bf16(w: torch.Tensor, out: torch.Tensor, table: TransposeTable):
     lib = load()
     with _timed("cast_kernel", 0, 0):
         check(lib.mfp_transpose_cast_bf16(_ptr(w), _ptr(out), _ptr(table.off), _ptr(table.rows), _ptr(table.cols),
-                                          table.nseg, table.max_tiles, _stream()), "mfp_transpose_cast_bf16")
+                                          _ptr(table.ooff), _ptr(table.old), table.nseg, table.max_tiles, _stream()),
+              "mfp_transpose_cast_bf16")
     return out
 
 

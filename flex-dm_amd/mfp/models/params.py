@@ -159,6 +159,13 @@ class ParamStore:
             segs = [(s.offset, s.shape[0], s.shape[1]) for s in layout.segments.values()
                     if s.transposed and ("/mlp/" in s.name or "/combine_heads/" in s.name)
                     and s.shape[0] in (256, 512)]
+            # fused Q|K|V ([3D][D], three adjacent variables) -> one [D][3D] block at the query offset
+            if 3 * layout.D == 768:
+                for i in range(layout.L):
+                    q = layout.segments["blocks/seq2seq_%d/attn/dense_query/kernel" % i]
+                    for j, nm in enumerate(("dense_query", "dense_key", "dense_value")):
+                        sg = layout.segments["blocks/seq2seq_%d/attn/%s/kernel" % (i, nm)]
+                        segs.append((sg.offset, sg.shape[0], sg.shape[1], q.offset + j * layout.D, 3 * layout.D))
             if segs:
                 from mfp.hip import ops
                 self.shadow_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
@@ -219,6 +226,10 @@ class ParamStore:
         if self.shadow_t is None:
             return None
         s = self.layout.segments[name]
+        if name.endswith("attn/dense_query/kernel"):     # the fused Q|K|V block, [D][3D]
+            if 3 * self.layout.D != 768:
+                return None
+            return self.shadow_t[s.offset:s.offset + 3 * s.size].view(s.shape[1], 3 * s.shape[0])
         if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and s.shape[0] in (256, 512)):
             return None
         return self.shadow_t[s.offset:s.offset + s.size].view(s.shape[1], s.shape[0])

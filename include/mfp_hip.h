@@ -211,12 +211,14 @@ int mfp_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, mfp_stream_t s
 
 /* Transposed bf16 shadow of Dense kernels inside the flat parameter buffer: for each listed matrix
  * (flat offset, rows, cols; row-major [rows][cols] = Keras kernel stored [out][in]) writes
- * out[off + c*rows + r] = bf16(w[off + r*cols + c]).  seg_* are DEVICE arrays of nseg entries;
+ * out[ooff + c*old + r] = bf16(w[off + r*cols + c]) (old >= rows: output row stride, so that the
+ * fused Q|K|V kernels become one [D][3D] matrix).  seg_* are DEVICE arrays of nseg entries;
  * max_tiles = max over matrices of ceil(rows/32)*ceil(cols/32).  With it the input-gradient of a
  * Dense layer (reference architecture/transformer.py:85-98 backward) is the same k-major product as
  * its forward. */
 int mfp_transpose_cast_bf16(const float* w, uint16_t* out, const int64_t* seg_off, const int32_t* seg_rows,
-                            const int32_t* seg_cols, int32_t nseg, int32_t max_tiles, mfp_stream_t stream);
+                            const int32_t* seg_cols, const int64_t* seg_ooff, const int32_t* seg_old,
+                            int32_t nseg, int32_t max_tiles, mfp_stream_t stream);
 
 /* dy = cdt( keep(seed,offset)[m][n] ? dx[m][n]/(1-p) : 0 ), colsum[n] = sum_m dy (bias grad).
  * Same dropout stream as MFP_GEMM_DROPOUT for equal (seed, offset); p == 0 -> plain cast.

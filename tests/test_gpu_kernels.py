@@ -452,13 +452,23 @@ def test_transpose_cast_bf16():
     for r, c in [(256, 512), (512, 256), (256, 256), (40, 72)]:
         segs.append((off, r, c))
         off += r * c + 24
+    # three [64][32] matrices transposed side by side into one [32][192] block
+    trio = off
+    for jx in range(3):
+        segs.append((off, 64, 32, trio + jx * 64, 192))
+        off += 64 * 32
     w = torch.randn(off, generator=g)
     out = torch.full((off,), 7.0, dtype=torch.bfloat16, device=DEV)
     ops.transpose_cast_bf16(w.to(DEV), out, ops.TransposeTable(segs, DEV))
     got = out.float().cpu()
     want = torch.full((off,), 7.0)
-    for o, r, c in segs:
-        want[o:o + r * c] = bf16_round(w[o:o + r * c].view(r, c).t().contiguous()).reshape(-1)
+    for sg in segs:
+        o, r, c = sg[:3]
+        if len(sg) == 3:
+            want[o:o + r * c] = bf16_round(w[o:o + r * c].view(r, c).t().contiguous()).reshape(-1)
+        else:
+            jx = (sg[3] - trio) // 64
+            want[trio:trio + 32 * 192].view(32, 192)[:, jx * 64:(jx + 1) * 64] = bf16_round(w[o:o + r * c].view(r, c).t())
     assert torch.equal(got, want)
 
 
