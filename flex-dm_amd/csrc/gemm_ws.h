@@ -73,24 +73,56 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
   if (ntiles <= 0) return;
   const int n_slice = s * BN;
 
+  // ---- weight slice -> registers of the math waves, through LDS: all 512 threads copy half of the
+  // slice (the rows of two math waves, <= 64 KB) with FULL-LINE coalesced loads into a row-major,
+  // XOR-swizzled image; those two waves then pick their MFMA fragments with ds_read_b128.
+  // (Fragment-shaped global loads -- 16 rows x 64 B per instruction -- took 4.4 us per launch for
+  // the 128 KB slice: tools/trace_gemm_ws.py.)  The image aliases the X / output stages, which are
+  // idle until the pipeline starts.
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, 0x7FFFFFFF, 0x00020000);
+  constexpr int WROWS = BN / 2, WCH = WROWS * CPR / 512;
+  static_assert((WROWS * CPR) % 512 == 0 && WROWS * ROWB <= 2 * XSTAGE + 2 * OSTAGE, "weight staging image");
+  // row -> li of the lane that reads it (its swizzle key): row = colq(b, q) + e with li = 4q + e
+  auto w_stage = [&](int r) {
+    u32x4 v[WCH];
+#pragma unroll
+    for (int c = 0; c < WCH; ++c) {
+      const int ch = tid + c * 512, row = ch / CPR, pc = ch % CPR, rl = row % WBN;
+      const int key = PAIRED ? 4 * ((rl >> 3) & 3) + (rl & 3) : (rl & 15);
+      const int n = n_slice + r * WROWS + row;
+      const unsigned int vo = n < p.N ? (unsigned int)((n * p.ldb + (pc ^ key) * 8) * 2) : OOB;
+      v[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, 0, 0));
+    }
+#pragma unroll
+    for (int c = 0; c < WCH; ++c) {
+      const int ch = tid + c * 512;
+      *reinterpret_cast<u32x4*>(smem_raw + (ch / CPR) * ROWB + (ch % CPR) * 16) = v[c];
+    }
+  };
+
   if (wave < 4) {
     // ======================================================================== MATH waves
     // Output column (local to the wave's 16 NQ block) of quad b for lane group q: f32 16b + 4q,
     // bf16 32(b/2) + 8q + 4(b%2) -- the lane's 16-byte unit (4 f32 / 8 bf16) is one stage chunk.
     auto colq = [&](int b, int q) { return PAIRED ? 32 * (b >> 1) + 8 * q + 4 * (b & 1) : 16 * b + 4 * q; };
     const int n_wave = n_slice + wave * WBN;
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, 0x7FFFFFFF, 0x00020000);
     // weight row feeding MFMA row i = 4q + e of quad b is column colq(b, q) + e (transposed MFMA:
     // the output lane (li, lg) then holds C[row li][colq(b, lg) + 0..3]).
     bf16x8 wf[NQ][KS];
 #pragma unroll
-    for (int b = 0; b < NQ; ++b) {
-      const int n = n_wave + colq(b, li >> 2) + (li & 3);
+    for (int r = 0; r < 2; ++r) {
+      w_stage(r);
+      __syncthreads();
+      if ((wave >> 1) == r) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const unsigned int vo = n < p.N ? (unsigned int)((n * p.ldb + ks * 32 + lg * 8) * 2) : OOB;
-        wf[b][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, 0, 0));
+        for (int b = 0; b < NQ; ++b) {
+          const unsigned char* wrow = smem_raw + ((wave & 1) * WBN + colq(b, li >> 2) + (li & 3)) * ROWB;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            wf[b][ks] = *reinterpret_cast<const bf16x8*>(wrow + (((ks * 4 + lg) ^ li) * 16));
+        }
       }
+      __syncthreads();
     }
     f32x4 bias4[NQ];
 #pragma unroll
@@ -262,6 +294,12 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     // ---- prologue
 #pragma unroll
     for (int i = 0; i < XD; ++i) gload(xa[i], i);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {       // weight staging rounds (barriers mirror the math waves)
+      w_stage(r);
+      __syncthreads();
+      __syncthreads();
+    }
     if (EPI != WS_EPI_PLAIN) xload(0, 0);
     lstore(xa[0], 0);
     gload(xa[0], XD);
