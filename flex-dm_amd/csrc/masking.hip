@@ -76,11 +76,18 @@ __global__ __launch_bounds__(256) void mask_kernel(MaskCols cols, int* __restric
     philox4x32(seed, (unsigned int)b, 0xE1E0E1E0u, off, r);
     sel = min((int)(u01(r[0]) * (float)nv), nv - 1);
   }
+  // every column's decision at once: lane k decides column k (Philox4x32-10 is ~800 clk; one
+  // after the other, wave-uniform, the 12 columns of Crello made this kernel VALU-bound at 75 us)
+  int mycode = 0;
+  bool mymfp = false;
+  if (lane < cols.n) {
+    unsigned int extra;
+    mycode = decide(cols.c[lane], lane, t, s, nv, task, sel, seed, off, &mymfp, &extra);
+  }
   for (int k = 0; k < cols.n; ++k) {
     const mfp_mask_col& col = cols.c[k];
-    bool mfp;
-    unsigned int extra;
-    const int code = decide(col, k, t, s, nv, task, sel, seed, off, &mfp, &extra);  // wave-uniform
+    const int code = __shfl(mycode, k, 64);
+    const bool mfp = __shfl((int)mymfp, k, 64) != 0;
     if (lane == 0) col.mask_out[t] = mfp ? 1 : 0;
     if (!col.is_numerical) {
       if (lane < col.n_feat) {
@@ -129,7 +136,41 @@ __global__ __launch_bounds__(256) void mask_kernel(MaskCols cols, int* __restric
   }
 }
 
+// tasks[b] ~ Categorical(probs) (reference mfp.py:34-43,301: tfp Categorical(logits=log probs)):
+// inverse-CDF on one Philox uniform per document.
+struct TaskProbs { float cdf[16]; int n; };
+__global__ void sample_tasks_kernel(TaskProbs tp, int* __restrict__ tasks, int B, unsigned long long seed,
+                                    unsigned long long offset0, const int* __restrict__ step_ptr) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const unsigned long long off = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  unsigned int r[4];
+  philox4x32(seed, (unsigned int)b, 0x7A5C7A5Cu, off, r);
+  const float u = u01(r[0]) * tp.cdf[tp.n - 1];
+  int k = 0;
+  while (k < tp.n - 1 && u >= tp.cdf[k]) ++k;
+  tasks[b] = k;
+}
+
 }  // namespace
+
+extern "C" int mfp_sample_tasks(const float* probs, int32_t n, int32_t* tasks, int32_t B, uint64_t seed,
+                                uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(probs && tasks && n > 0 && n <= 16 && B > 0);
+  TaskProbs tp;
+  tp.n = n;
+  float c = 0.f;
+  for (int i = 0; i < n; ++i) {
+    MFP_CHECK_ARG(probs[i] >= 0.f);
+    c += probs[i];
+    tp.cdf[i] = c;
+  }
+  MFP_CHECK_ARG(c > 0.f);
+  hipLaunchKernelGGL(sample_tasks_kernel, dim3((B + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     tp, tasks, B, seed, offset, step_ptr);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
 
 extern "C" int mfp_mask_tokens(const mfp_mask_col* cols, int32_t ncols, int32_t* idx_all, int32_t NCOL,
                                const int32_t* nvalid, const int32_t* tasks, int32_t B, int32_t S, uint64_t seed,

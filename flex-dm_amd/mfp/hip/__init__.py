@@ -92,6 +92,7 @@ SIGNATURES = {
     "mfp_dropout_bwd": (c_int32, [c_void_p] * 4 + [c_size_t, c_int32, c_int32, c_float, c_uint64,
                                                    c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_colsum": (c_int32, [c_void_p] * 3 + [c_size_t] + [c_int32] * 4 + [c_void_p]),
+    "mfp_sample_tasks": (c_int32, [POINTER(c_float), c_int32, c_void_p, c_int32, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_mask_tokens": (c_int32, [POINTER(MaskCol), c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                   c_int32, c_uint64, c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_debug_tr_probe": (c_int32, [c_void_p, c_void_p, c_void_p]),

@@ -400,6 +400,17 @@ def colsum(X: torch.Tensor, out: torch.Tensor, M: int, N: int, ld: Optional[int]
     return out
 
 
+def sample_tasks(probs: Sequence[float], B: int, seed: int, offset: int, step_ptr: Optional[torch.Tensor],
+                 device) -> torch.Tensor:
+    """int32 [B] ~ Categorical(probs) in one launch (torch.multinomial is ~8 tiny kernels)."""
+    lib = load()
+    tasks = torch.empty((B,), dtype=torch.int32, device=device)
+    arr = (ctypes.c_float * len(probs))(*[float(x) for x in probs])
+    check(lib.mfp_sample_tasks(arr, len(probs), _ptr(tasks), B, int(seed), int(offset), _ptr(step_ptr), _stream()),
+          "mfp_sample_tasks")
+    return tasks
+
+
 def mask_tokens(cols: Sequence[dict], idx_all: torch.Tensor, nvalid: torch.Tensor, tasks: torch.Tensor,
                 B: int, S: int, seed: int, offset: int, step_ptr: Optional[torch.Tensor], x_dtype: torch.dtype):
     """Fused preprocess_for_train (see mfp_mask_tokens).  cols: dicts with is_numerical, n_feat,

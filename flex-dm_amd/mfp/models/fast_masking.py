@@ -59,6 +59,7 @@ class FusedMasker:
                 xs.append(x)
                 codes.append(code)
             descr.append(d)
-        ops.mask_tokens(descr, idx_all, nvalid, tasks.to(torch.int32), B, S, self.seed, 0, step_ptr, cdt)
+        ops.mask_tokens(descr, idx_all, nvalid, tasks if tasks.dtype == torch.int32 else tasks.to(torch.int32), B, S,
+                        self.seed, 0, step_ptr, cdt)
         masks = {c["key"]: masks_u8[i].view(B, S) for i, c in enumerate(self.cols)}
         return idx_all, codes, xs, masks

@@ -29,6 +29,11 @@ logger = logging.getLogger(__name__)
 logger.setLevel(logging.INFO)
 
 
+def ops_hip():
+    from mfp.hip import ops
+    return ops
+
+
 def get_task_probs(task_names: List[str], masking_method: str) -> List[float]:
     """reference mfp.py:34-43 (the Categorical's probabilities)."""
     used_names = masking_method.split("_")
@@ -250,7 +255,12 @@ class MFP:
 
     def _forward_backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         B = batch["left"].shape[0]
-        tasks = self.sample_tasks(B)
+        if self.fast_masking and self.input_dtype == "set" and self.model.store.device.type == "cuda":
+            # one launch on the step's counter-based stream (torch.multinomial is ~8 tiny kernels)
+            tasks = ops_hip().sample_tasks(self.task_probs, B, self._masker.seed, 1, self.model.step_ptr,
+                                           self.model.store.device)
+        else:
+            tasks = self.sample_tasks(B)
         if self.sort_pos and self.task_names.index("pos") in self._active_tasks:
             raise NotImplementedError("RICO position-sorted training loss is a 'next' row (SURVEY.md §8f-4)")
         if self.fast_masking and self.input_dtype == "set":

@@ -261,6 +261,11 @@ int mfp_mask_tokens(const mfp_mask_col* cols /*host*/, int32_t ncols, int32_t* i
                     const int32_t* nvalid, const int32_t* tasks, int32_t B, int32_t S, uint64_t seed,
                     uint64_t offset, const int32_t* step_ptr, int32_t x_dtype, mfp_stream_t stream);
 
+/* tasks[b] ~ Categorical(probs / sum(probs)), b < B (reference mfp.py:34-43,301): one counter-based
+ * uniform per document, offset as in mfp_mask_tokens.  probs: HOST array of n <= 16 weights. */
+int mfp_sample_tasks(const float* probs /*host*/, int32_t n, int32_t* tasks, int32_t B, uint64_t seed,
+                     uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
+
 /* Hardware probe (tests only): lane mapping of ds_read_b64_tr_b16.  byte_addr int32 [64]
  * (8-byte aligned offsets into a 4 KiB LDS image whose b16 element e holds e); out u16 [64][4]. */
 int mfp_debug_tr_probe(const int32_t* byte_addr, uint16_t* out, mfp_stream_t stream);

@@ -144,3 +144,20 @@ def test_masks_change_with_step_counter():
     model.optimizer.step_t += 1
     c = model._masker(batch, tasks, ctx.nvalid, B, S, model.optimizer.step_t)[3]["left"].clone()
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_sample_tasks_distribution_and_step_offset():
+    """mfp_sample_tasks: Categorical(probs) by inverse CDF; zero-probability tasks never drawn; the
+    device step counter moves the stream."""
+    from mfp.hip import ops
+    probs = [0.0, 1.0, 1.0, 0.0, 2.0]
+    B = 200000
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    t0 = ops.sample_tasks(probs, B, 1234, 1, step, "cuda")
+    cnt = torch.bincount(t0.long(), minlength=5).double().cpu() / B
+    want = torch.tensor(probs, dtype=torch.float64) / sum(probs)
+    assert cnt[0] == 0 and cnt[3] == 0
+    assert (cnt - want).abs().max() < 5e-3, cnt
+    assert torch.equal(t0, ops.sample_tasks(probs, B, 1234, 1, step, "cuda"))
+    step += 1
+    assert not torch.equal(t0, ops.sample_tasks(probs, B, 1234, 1, step, "cuda"))
