@@ -72,6 +72,36 @@ def pmc_traffic_per_launch(kernel):
     return tot / calls if calls else None
 
 
+def measured_peaks(device):
+    """datasheet peaks next to what the box actually delivers -- a hipBLASLt
+    bf16 GEMM (torch.matmul, 8192^3) for the matrix pipe and a 1 GiB device copy / fill for HBM."""
+    import torch
+    out = {}
+    a = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=device, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        torch.matmul(a, b)
+    e1.record(); torch.cuda.synchronize()
+    out["hipblaslt_bf16_gemm_8192_tflops"] = 10 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    del a, b
+    src = torch.empty(1 << 28, device=device, dtype=torch.float32)
+    dst = torch.empty_like(src)
+    for fn, key, nbytes in ((lambda: dst.copy_(src), "copy_gbs_read_plus_write", 2 * src.numel() * 4),
+                            (lambda: dst.fill_(1.0), "fill_gbs_write", src.numel() * 4)):
+        for _ in range(2):
+            fn()
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        out[key] = 5 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return out
+
+
 def cpu_baseline(ic, budget_s=12.0):
     """Oracle (checker only) timed as the CPU baseline: same train step, eager torch-CPU f32."""
     import torch
@@ -216,6 +246,14 @@ def main():
                      "step": {"achieved": step_tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": step_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS},
                      "kernels_us_per_step": {k: round(1e3 * v[3] / nprof, 1) for k, v in table}})
+        try:
+            mp = measured_peaks(device)
+            roof["measured_peaks"] = mp
+            roof["frac_of_measured_peak"] = (roof["achieved"] / mp["copy_gbs_read_plus_write"] if roof["bound"] == "hbm"
+                                             else roof["achieved"] / mp["hipblaslt_bf16_gemm_8192_tflops"])
+            roof["step"]["frac_of_measured_gemm_peak"] = step_tflops / mp["hipblaslt_bf16_gemm_8192_tflops"]
+        except Exception as exc:   # measurement aid only: never fail the bench line over it
+            roof["measured_peaks"] = "unavailable: %s" % exc
         out["roofline"] = roof
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(ic)
