@@ -18,14 +18,15 @@ struct LossKeys {
   int n;
 };
 
+// The three loads are issued unconditionally and independently (one memory latency, not a chain of
+// three): these kernels are latency-bound, their workgroups live for a handful of round trips.
 __device__ __forceinline__ float token_weight(const mfp_loss_key& k, const int* nvalid, int t, int S) {
   const int b = t / S, s = t % S;
-  bool w = k.mask[t] != 0 && s < nvalid[b];
-  if (w && k.cond_idx != nullptr) {
-    const int v = k.cond_idx[(long long)t * k.cond_stride];
-    w = v >= 0 && v < 32 && ((k.cond_bits >> v) & 1u);
-  }
-  return w ? 1.f : 0.f;
+  const unsigned char m = k.mask[t];
+  const int nv = nvalid[b];
+  const int v = k.cond_idx != nullptr ? k.cond_idx[(long long)t * k.cond_stride] : 0;
+  const bool c = k.cond_idx == nullptr || (v >= 0 && v < 32 && ((k.cond_bits >> v) & 1u));
+  return (m != 0 && s < nv && c) ? 1.f : 0.f;
 }
 
 constexpr int CE_TOK = 16;        // token rows per workgroup
@@ -61,11 +62,24 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
   __shared__ int nactive;
   __shared__ unsigned char active[CE_TOK * CE_MAX_ITEMS];   // compacted (row << 4 | item)
   __shared__ unsigned char isact[CE_TOK][CE_MAX_ITEMS];
+  __shared__ int ylabel[CE_TOK][CE_MAX_ITEMS];
   const int t0 = blockIdx.x * CE_TOK;
   const int W = rg.width;
   const int row16 = threadIdx.x >> 4, l16 = threadIdx.x & 15;
   if (threadIdx.x < MFP_MAX_LOSS_KEYS * 3) (&red[0][0])[threadIdx.x] = 0.f;
   if (threadIdx.x == 0) nactive = 0;
+  // ---- weights and labels first: thread = (row, item); their (small, scattered) loads are in
+  // flight together with the bulk staging loads below
+  bool act = false;
+  int ylab = 0;
+  {
+    const int item = l16, t = t0 + row16;
+    if (item < rg.nitem && t < T) {
+      const mfp_loss_key& key = keys.k[rg.item_key[item]];
+      act = token_weight(key, nvalid, t, S) != 0.f;
+      ylab = reinterpret_cast<const int*>(key.target)[(long long)t * key.n_feat + rg.item_feat[item]];
+    }
+  }
   // ---- 1. stage
   {
     const int t = t0 + row16;
@@ -81,16 +95,11 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
       }
     }
   }
+  isact[row16][l16] = act ? 1 : 0;
+  ylabel[row16][l16] = ylab;
   __syncthreads();
   for (int gI = 0; gI < rg.ngap; ++gI)      // padding columns: d(logits) = 0
     if (l16 < rg.gap_len[gI]) tile[row16 * W + rg.gap_pos[gI] + l16] = 0.f;
-  // ---- 2. weights: thread = (row, item)
-  {
-    const int item = l16, t = t0 + row16;
-    bool act = false;
-    if (item < rg.nitem && t < T) act = token_weight(keys.k[rg.item_key[item]], nvalid, t, S) != 0.f;
-    isact[row16][item] = act ? 1 : 0;
-  }
   __syncthreads();
   if (isact[row16][l16]) active[atomicAdd(&nactive, 1)] = (unsigned char)(threadIdx.x);
   // ---- 3a. inactive items zero their classes (group = 16 lanes, item a = group, group + 16, ...)
@@ -106,10 +115,8 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
   for (int a = row16; a < na; a += 16) {
     const int code = active[a], row = code >> 4, item = code & 15;
     const int kidx = rg.item_key[item], C = rg.item_C[item];
-    const mfp_loss_key& key = keys.k[kidx];
-    const int t = t0 + row;
     float* z = tile + row * W + rg.item_pos[item];
-    const int y = reinterpret_cast<const int*>(key.target)[(long long)t * key.n_feat + rg.item_feat[item]];
+    const int y = ylabel[row][item];
     // max / argmax (first index on ties, as the serial reference walk)
     float m = -INFINITY;
     int am = 0x7fffffff;
