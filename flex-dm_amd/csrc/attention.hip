@@ -234,6 +234,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(const bf16_t* __restrict
   stage_head<HD, HDP, LDH>(Qs, base, D3, S, SP);
   stage_head<HD, HDP, LDH>(Ks, base + D, D3, S, SP);
   stage_head<HD, HDP, LDH>(Vs, base + 2 * D, D3, S, SP);
+  // The score math is VALU-issue-bound (64 % of SIMD cycles issuing, 14 VALU per score): work in
+  // the exp2 domain with the additive key term (0 / -1e9 log2 e for masked / -inf past S) read
+  // from an LDS table: fma, max | sub, exp2, add per score.
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  float* Mb = reinterpret_cast<float*>(Vs + SP * LDH);
+  for (int j = threadIdx.x; j < SP; j += blockDim.x) Mb[j] = j < S ? (j < nv ? 0.f : -1e9f * LOG2E) : -INFINITY;
+  const float c2 = scale * LOG2E;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int nkt = SP / 16;
@@ -250,13 +257,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(const bf16_t* __restrict
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(Ks, LDH, kt * 16 + li, ks * 32, lg), bq[ks], acc, 0, 0, 0);
+        const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mb + kt * 16 + 4 * lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = kt * 16 + 4 * lg + r;
-          float v = acc[r] * scale + (j < nv ? 0.f : -1e9f);
-          v = j < S ? v : -INFINITY;
-          acc[r] = v;
-          m = fmaxf(m, v);
+          acc[r] = __builtin_fmaf(acc[r], c2, mb4[r]);
+          m = fmaxf(m, acc[r]);
         }
         s[kt] = acc;
       }
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(const bf16_t* __restrict
       if (kt < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s[kt][r] - m);
+          const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);
           s[kt][r] = p;
           l += p;
         }
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(const bf16_t* __restrict
         u32x2 pk = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
         *reinterpret_cast<u32x2*>(orow + dt * 16 + 4 * lg) = pk;
       }
-      if (lg == 0) lse[((long long)b * H + h) * S + q] = m + __logf(l);
+      if (lg == 0) lse[((long long)b * H + h) * S + q] = (m + __builtin_amdgcn_logf(l)) * LN2;   // natural-log lse
     }
   }
 }
@@ -533,7 +538,7 @@ int fwd_hd(const void* qkv, const int* nvalid, void* out, float* lse, int B, int
   } else {
     constexpr int LDH = (HD < 32 ? 32 : HD) + 8;
     const int SP = (S + 31) & ~31;
-    size_t lds = (size_t)3 * SP * LDH * sizeof(bf16_t);
+    size_t lds = (size_t)3 * SP * LDH * sizeof(bf16_t) + (size_t)SP * sizeof(float);
     if (SP <= 128) {
       if (int rc = set_lds(attn_fwd_bf16<HD, 8>, lds)) return rc;
       hipLaunchKernelGGL((attn_fwd_bf16<HD, 8>), grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);

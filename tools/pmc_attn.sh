@@ -14,7 +14,7 @@ import csv, glob, collections
 agg = collections.OrderedDict()
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "attn_bwd" not in r["Kernel_Name"]: continue
+        if "${KFILTER:-attn_bwd}" not in r["Kernel_Name"]: continue
         agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k, v in agg.items():
     print("%-28s n=%d  mean per dispatch %.4g" % (k, len(v), sum(v)/len(v)))
