@@ -498,3 +498,28 @@ def test_embed_onehot_table_gradient():
              splitk=ops.wgrad_splitk(T, rows_pad, D))
     want = want_P.double().t() @ dh.double()
     assert_close(out, want, 1e-3, 1e-5, "onehot table gradient")
+
+
+def test_layernorm_bwd_deferred_partials():
+    """mfp_layernorm_bwd with dgamma = dbeta = NULL leaves the partials; mfp_reduce_partials sums
+    them later (ops.layernorm_bwd(defer=...)) -- same result as the in-line reduction."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    T, D = 1000, 256
+    x = torch.randn(T, D, generator=g).to(DEV)
+    gamma, beta = (torch.rand(D, generator=g) + 0.5).to(DEV), torch.randn(D, generator=g).to(DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, torch.bfloat16)
+    dy = torch.randn(T, D, generator=g).to(DEV, torch.bfloat16)
+    dres = torch.randn(T, D, generator=g).to(DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    outs = []
+    for deferred in (False, True):
+        dg, db, cs = torch.empty(D, device=DEV), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+        pending = []
+        dx, dd = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dg, db, drop=(cs, 0.1, 7, 3, step),
+                                   defer=(lambda fn, *t: pending.append(fn)) if deferred else None)
+        for fn in pending:
+            fn()
+        outs.append((dx, dd, dg, db, cs))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
