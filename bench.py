@@ -201,9 +201,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": "Crello Ours-IMP train step (masking_method=%s): d_model=%d, %d DeepSVG blocks, "
+        "config": {"workload": "Crello Ours-%s train step (masking_method=%s): d_model=%d, %d DeepSVG blocks, "
                                "seq_len=%d, %d documents/GPU, dropout 0.1, l2 1e-2, Adam lr 1e-4 clipnorm 1.0"
-                               % (args.masking_method, D_MODEL, NUM_BLOCKS, S, B),
+                               % ("IMP" if args.masking_method == "random" else "EXP", args.masking_method, D_MODEL,
+                                  NUM_BLOCKS, S, B),
                    "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
                    "launch": "eager" if args.no_graph else "hipGraph replay",
                    "params": L.numel, "train_flop_per_element": fpe},
