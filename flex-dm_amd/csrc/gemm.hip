@@ -150,7 +150,7 @@ struct GemmLds {
   static constexpr int A_ROWS = A_KMAJOR ? BM : BK, A_COLS = A_KMAJOR ? BK : BM, LDA_S = A_COLS + PAD;
   static constexpr int B_ROWS = B_KMAJOR ? BN : BK, B_COLS = B_KMAJOR ? BK : BN, LDB_S = B_COLS + PAD;
   static constexpr int A_ELEMS = A_ROWS * LDA_S, B_ELEMS = B_ROWS * LDB_S;
-  static constexpr size_t BYTES = (size_t)NBUF * (A_ELEMS + B_ELEMS) * sizeof(T) + BM * sizeof(float);
+  static constexpr size_t BYTES = (size_t)NBUF * (A_ELEMS + B_ELEMS) * sizeof(T) + (A_KMAJOR ? (size_t)BM : (size_t)(256 / (A_COLS / GemmCfg<T>::EPC)) * BM) * sizeof(float);
 };
 
 template <typename T, bool A_KMAJOR, bool B_KMAJOR, int MT, int NQ, int NBUF>
@@ -404,13 +404,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
 
   // ---- bias-gradient column sums of A = dY (wgrad, n-tile 0 only)
   if (!A_KMAJOR && do_colsum) {
-    if (tid < BM) colsum_s[tid] = 0.f;
+    // per-thread sums -> LDS [row group][column], summed in a FIXED order (float atomics made the
+    // bias gradients differ in the last bit from run to run)
+    constexpr int NG = NT / A_CPR;
     __syncthreads();
-    int col = (tid % A_CPR) * EPC;
+    const int col = (tid % A_CPR) * EPC, grp = tid / A_CPR;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) atomicAdd(&colsum_s[col + e], csum[e]);
+    for (int e = 0; e < EPC; ++e) colsum_s[grp * BM + col + e] = csum[e];
     __syncthreads();
-    if (tid < BM && m0 + tid < p.M) p.ws_col[(long long)kz * p.M + m0 + tid] = colsum_s[tid];
+    if (tid < BM && m0 + tid < p.M) {
+      float sacc = 0.f;
+#pragma unroll 4
+      for (int gI = 0; gI < NG; ++gI) sacc += colsum_s[gI * BM + tid];
+      p.ws_col[(long long)kz * p.M + m0 + tid] = sacc;
+    }
   }
 
   // ---- epilogue: lane owns rows .. + 16a + li and columns nb .. nb + 4NQ - 1

@@ -31,6 +31,7 @@ class StepCtx:
         # let the independent gradient products at the very end of the backward pass run side by side
         self.sides = list(side_stream) if isinstance(side_stream, (list, tuple)) else ([side_stream] if side_stream is not None else [])
         self.side = self.sides[0] if self.sides else None
+        self.mid = None     # activation entering block L/2 (set by Blocks; see MFP.capture_train_step)
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
         self.nvalid = nvalid
         self.training = training

@@ -44,6 +44,10 @@ class Blocks:
 
     def __call__(self, seq, mask, ctx: StepCtx):
         # the key-padding mask enters the kernels as ctx.nvalid (= length + 1 per document)
-        for layer in self.seq2seq.values():
+        # ctx.mid: the activation entering block L/2 -- where the data-parallel step cuts its backward
+        # pass in two, so that the gradients of the upper half are all-reduced under the lower half
+        for i, layer in enumerate(self.seq2seq.values()):
+            if i == self.num_blocks // 2 and i > 0:
+                ctx.mid = seq
             seq = layer(seq, ctx)
         return seq

@@ -253,8 +253,10 @@ class MFP:
             self.optimizer = AdamKeras(self.model.store, learning_rate=learning_rate, clipnorm=clipnorm)
         self.model.step_ptr = self.optimizer.step_t
 
-    def _forward_backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def _forward(self, batch: Dict[str, torch.Tensor]):
+        """masking -> encoder -> blocks -> heads + losses.  Returns (loss, sums, ctx or None)."""
         B = batch["left"].shape[0]
+        ctx = None
         if self.fast_masking and self.input_dtype == "set" and self.model.store.device.type == "cuda":
             # one launch on the step's counter-based stream (torch.multinomial is ~8 tiny kernels)
             tasks = ops_hip().sample_tasks(self.task_probs, B, self._masker.seed, 1, self.model.step_ptr,
@@ -274,9 +276,16 @@ class MFP:
                 active_tasks=self._active_tasks)
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, targets, masks)
             loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True)
-        loss.backward()
+        return loss, sums, ctx
+
+    def _join_sides(self):
         for side in self.model.side_streams:   # weight gradients run on the side streams
             torch.cuda.current_stream().wait_stream(side)
+
+    def _forward_backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        loss, sums, _ = self._forward(batch)
+        loss.backward()
+        self._join_sides()
         return sums
 
     def _apply(self):
@@ -297,7 +306,8 @@ class MFP:
 
     def capture_train_step(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2):
         """Capture the whole train step into hipGraphs (launch-bound inner loop: ~10^2 kernels of
-        ~10 us).  With world_size > 1 the step is two graphs with the RCCL all-reduce between."""
+        ~10 us).  With world_size > 1 the step is three graphs with the RCCL all-reduce of the upper
+        gradient bucket overlapping the lower half of the backward pass."""
         assert self.optimizer is not None, "call compile() first"
         static = {k: v.clone() for k, v in example_batch.items()}
         side = torch.cuda.Stream()
@@ -310,14 +320,32 @@ class MFP:
         torch.cuda.synchronize()
         multi = dp.world_size() > 1
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            static_sums = self._forward_backward(static)
-            if not multi:
+        g2 = g3 = None
+        split = self.model.layout.bucket_split()
+        grad = self.model.store.g
+        if not multi:
+            with torch.cuda.graph(g1):
+                static_sums = self._forward_backward(static)
                 self._apply()
-        g2 = None
-        if multi:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+        else:
+            # N > 1: the backward pass is cut at the input of block L/2.  Graph 1 = forward + upper
+            # half of the backward; its gradients [split, end) (upper blocks + heads) are all-reduced
+            # ASYNCHRONOUSLY while graph 2 runs the lower half; then [0, split); graph 3 = Adam.
+            with torch.cuda.graph(g1):
+                loss, static_sums, ctx = self._forward(static)
+                cut = ctx.mid if (ctx is not None and split > 0) else None
+                if cut is not None:
+                    dcut = torch.autograd.grad(loss, cut)[0]
+                else:
+                    loss.backward()
+                self._join_sides()
+            if cut is not None:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    cut.backward(dcut)
+                    self._join_sides()
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3, pool=g1.pool()):
                 self.optimizer.step(grad_scale=1.0 / dp.world_size())
 
         def replay(batch):
@@ -326,13 +354,20 @@ class MFP:
                     static[k].copy_(v, non_blocking=True)
             g1.replay()
             if multi:
-                dp.allreduce_gradients(self.model.store.g)
-                g2.replay()
+                if g2 is not None:
+                    w_hi = dp.allreduce_gradients(grad[split:], async_op=True)   # overlaps graph 2
+                    g2.replay()
+                    w_lo = dp.allreduce_gradients(grad[:split], async_op=True)
+                    w_hi.wait()
+                    w_lo.wait()
+                else:
+                    dp.allreduce_gradients(grad)
+                g3.replay()
             self.last_sums = static_sums
             return static_sums
 
         self._graph = replay
-        self._graph_objs = (g1, g2, static, static_sums)
+        self._graph_objs = (g1, g2, g3, static, static_sums)
         self.static_batch = static   # a loader that writes the next batch here avoids the copy
         return replay
 

@@ -134,6 +134,13 @@ class ModelLayout:
         self.segments[name] = seg
         self._cursor += seg.size
 
+    def bucket_split(self) -> int:
+        """Flat offset of the first variable of block L/2: [split, numel) = upper blocks + heads are
+        complete after the first half of the backward pass, [0, split) after the second."""
+        if self.L < 2:
+            return 0
+        return self.segments["blocks/seq2seq_%d/attn/dense_query/kernel" % (self.L // 2)].offset
+
     def seg_offsets(self) -> List[int]:
         return [s.offset for s in self.segments.values()] + [self.numel]
 

@@ -240,3 +240,41 @@ def test_two_rank_step_on_one_gpu_over_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
     assert d["params_in_sync"] is True
+
+
+def test_split_backward_equals_single_backward():
+    """The data-parallel step cuts the backward pass at the input of block L/2 (gradients of the upper
+    half are all-reduced while the lower half runs): autograd.grad(loss, cut) followed by
+    cut.backward(dcut) must leave exactly the gradients of one loss.backward()."""
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    B, S = 8, 32
+    batch = synthetic_batch(ic, B, S, seed=3, ragged=True, device=DEV)
+    model = MFP(ic, num_blocks=4, latent_dim=128, dropout=0.1, l2=1e-2, masking_method="random",
+                dtype="bf16", device=DEV)
+    model.compile(learning_rate=1e-3)
+    g = model.model.store.g
+    split = model.model.layout.bucket_split()
+    assert 0 < split < g.numel()
+    g.fill_(float("nan"))
+    loss, sums, ctx = model._forward(batch)     # the step counter does not move: same masks / dropout
+    loss.backward()
+    model._join_sides()
+    torch.cuda.synchronize()
+    ref, ref_sums = g.clone(), sums.clone()
+    g.fill_(float("nan"))
+    loss, sums, ctx = model._forward(batch)
+    assert ctx.mid is not None
+    dcut = torch.autograd.grad(loss, ctx.mid)[0]
+    model._join_sides()
+    torch.cuda.synchronize()
+    # upper bucket complete; the lower one is still (almost) untouched -- only the bias gradient that
+    # the fused LayerNorm backward of block L/2 emits for block L/2-1 has landed
+    assert torch.equal(g[split:], ref[split:])
+    assert torch.isnan(g[:split]).float().mean() > 0.99
+    ctx.mid.backward(dcut)
+    model._join_sides()
+    torch.cuda.synchronize()
+    assert torch.allclose(sums, ref_sums, rtol=1e-5, atol=1e-5)   # loss sums: float atomics across workgroups
+    assert torch.equal(g, ref)
