@@ -497,7 +497,16 @@ int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     ncu = n;
   }
-  if (a->K == 256) return launch_ws_epi<8, 2>(a, p, ncu, st);
+  // narrow column slices (half the weight prologue per CU, twice the row tiles per workgroup) pay
+  // off when a full-width slice would leave a workgroup only a handful of 32-row tiles
+  static const char* nv = getenv("MFP_WS_NARROW");   // experiment switch: 0 never, 1 N <= 256, 2 always
+  const int narrow_mode = nv ? nv[0] - '0' : 1;
+  const bool narrow = narrow_mode == 2 || (narrow_mode == 1 && a->N <= 256);
+  if (a->K == 256) {
+    if (narrow) return launch_ws_epi<8, 2, true>(a, p, ncu, st);
+    return launch_ws_epi<8, 2>(a, p, ncu, st);
+  }
+  if (a->K == 512 && narrow_mode == 2) return launch_ws_epi<16, 2, true>(a, p, ncu, st);
   if (a->K == 768)   // plain epilogue only (ws_eligible): the fused-QKV input gradient
     return a->out_dtype == MFP_BF16 ? launch_ws<24, 2, WS_EPI_PLAIN, false, true>(p, ncu, st)
                                     : launch_ws<24, 2, WS_EPI_PLAIN, false, false>(p, ncu, st);

@@ -32,9 +32,12 @@ enum { WS_EPI_PLAIN = 0, WS_EPI_F32X = 1, WS_EPI_RELUBWD = 2 };
 // mask); DROPOUT and OUT_BF16 are compile-time too: with no run-time flag branches and
 // out-of-range-dropping buffer accesses every pipeline step is ONE basic block, so the compiler's
 // vmcnt bookkeeping is exact (with control flow in the loop it falls back to vmcnt(0) per tile).
-template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16>
+// NARROW halves the workgroup's column slice (K = 256: 128 instead of 256 columns): half the weight
+// prologue per CU and twice the row tiles per workgroup -- for the N = 256 layers, whose 128 rows per
+// workgroup at full width are only 4 pipeline steps behind a 4 us prologue.
+template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16, bool NARROW = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, int slices) {
-  constexpr int NQ = KS == 8 ? 4 : (KS == 16 ? 2 : 1), BM = 16 * MT, WBN = 16 * NQ, BN = 4 * WBN;
+  constexpr int NQ = (KS == 8 ? 4 : (KS == 16 ? 2 : 1)) >> (NARROW ? 1 : 0), BM = 16 * MT, WBN = 16 * NQ, BN = 4 * WBN;
   constexpr int ROWB = 64 * KS, CPR = ROWB / 16, XSTAGE = BM * ROWB;      // X stage: [BM][K] bf16
   constexpr int A_CH = BM * CPR / 256;
   constexpr int OS = OUT_BF16 ? 2 : 4, OROWB = BN * OS, OCPR = OROWB / 16, OSTAGE = BM * OROWB;
@@ -390,13 +393,13 @@ inline bool ws_eligible(const mfp_gemm_args* a, int splitk) {
   return true;
 }
 
-template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16>
+template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16, bool NARROW = false>
 int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
-  constexpr int NQ = KS == 8 ? 4 : (KS == 16 ? 2 : 1), BN = 64 * NQ, XSTAGE = 16 * MT * 64 * KS, OSTAGE = 16 * MT * BN * (OUT_BF16 ? 2 : 4);
+  constexpr int NQ = (KS == 8 ? 4 : (KS == 16 ? 2 : 1)) >> (NARROW ? 1 : 0), BN = 64 * NQ, XSTAGE = 16 * MT * 64 * KS, OSTAGE = 16 * MT * BN * (OUT_BF16 ? 2 : 4);
   constexpr int lds = 2 * XSTAGE + 2 * OSTAGE;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16, NARROW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_gemm: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
@@ -413,18 +416,18 @@ int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
     groups = (ncu / slices) / 8 * 8;
     if (groups < 8) groups = 8;
   }
-  hipLaunchKernelGGL((gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16>), dim3(groups * slices), dim3(512), lds, st, p,
+  hipLaunchKernelGGL((gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16, NARROW>), dim3(groups * slices), dim3(512), lds, st, p,
                      groups, slices);
   return MFP_OK;
 }
 
-template <int KS, int MT>
+template <int KS, int MT, bool NARROW = false>
 int launch_ws_epi(const mfp_gemm_args* a, const GemmParams& p, int ncu, hipStream_t st) {
   const int f = a->flags;
   if (f & (MFP_GEMM_RESIDUAL | MFP_GEMM_ACCUM))
-    return (f & MFP_GEMM_DROPOUT) ? launch_ws<KS, MT, WS_EPI_F32X, true, false>(p, ncu, st)
-                                  : launch_ws<KS, MT, WS_EPI_F32X, false, false>(p, ncu, st);
-  if (f & MFP_GEMM_RELU_BWD) return launch_ws<KS, MT, WS_EPI_RELUBWD, false, true>(p, ncu, st);
-  return a->out_dtype == MFP_BF16 ? launch_ws<KS, MT, WS_EPI_PLAIN, false, true>(p, ncu, st)
-                                  : launch_ws<KS, MT, WS_EPI_PLAIN, false, false>(p, ncu, st);
+    return (f & MFP_GEMM_DROPOUT) ? launch_ws<KS, MT, WS_EPI_F32X, true, false, NARROW>(p, ncu, st)
+                                  : launch_ws<KS, MT, WS_EPI_F32X, false, false, NARROW>(p, ncu, st);
+  if (f & MFP_GEMM_RELU_BWD) return launch_ws<KS, MT, WS_EPI_RELUBWD, false, true, NARROW>(p, ncu, st);
+  return a->out_dtype == MFP_BF16 ? launch_ws<KS, MT, WS_EPI_PLAIN, false, true, NARROW>(p, ncu, st)
+                                  : launch_ws<KS, MT, WS_EPI_PLAIN, false, false, NARROW>(p, ncu, st);
 }
