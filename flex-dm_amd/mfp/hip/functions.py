@@ -31,6 +31,8 @@ class StepCtx:
         # let the independent gradient products at the very end of the backward pass run side by side
         self.sides = list(side_stream) if isinstance(side_stream, (list, tuple)) else ([side_stream] if side_stream is not None else [])
         self.side = self.sides[0] if self.sides else None
+        self.dh_c = None    # compute-dtype copy of the encoder output gradient (block 0's LN1 backward)
+        self.onehot = None  # one-hot count matrix of the index columns (built during the forward pass)
         self.mid = None     # activation entering block L/2 (set by Blocks; see MFP.capture_train_step)
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
         self.nvalid = nvalid
@@ -72,6 +74,12 @@ class StepCtx:
 def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
     st, L = ctx.store, ctx.store.layout
     T, D = ctx.T, L.D
+    if ctx.training and ctx.cdt == torch.bfloat16 and ctx.side is not None:
+        # the table gradient's one-hot operand depends on the indices only: build it now, off the
+        # critical path, instead of at the tail of the backward pass where nothing overlaps it
+        def build():
+            ctx.onehot = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
+        ctx.on_side(build, idx_all, which=2)
     h = ops.embed_pool_fwd(idx_all, st.rowoff, st.tables())
     for j, k in enumerate(L.num_keys):
         width = xs[j].shape[1]
@@ -85,7 +93,8 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     T, D = ctx.T, L.D
     onehot = ctx.cdt == torch.bfloat16   # table gradient as a wgrad GEMM (bf16 path); f32: exact scatter
     if L.num_keys or onehot:
-        dh_c = ctx.to_cdt(dh)
+        dh_c = ctx.dh_c if (ctx.dh_c is not None and ctx.dh_c.shape == dh.shape) else ctx.to_cdt(dh)
+        ctx.dh_c = None
 
         # the last products of the backward pass: nothing on the main stream overlaps them any more,
         # so the independent ones go to different side streams and share the chip
@@ -96,13 +105,14 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
                      colsum=st.grad("encoder/input_%s/bias" % k), splitk=ops.wgrad_splitk(T, D, width))
 
         def wgrad_tables():
-            P = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
+            P = ctx.onehot if ctx.onehot is not None else ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
+            ctx.onehot = None
             ops.gemm(P, dh_c, L.table_rows_pad, D, T, a_kmajor=False, b_kmajor=False,
                      out=st.tables_padded(st.g), splitk=ops.wgrad_splitk(T, L.table_rows_pad, D))
-        if onehot:
-            ctx.on_side(wgrad_tables, dh_c, idx_all, which=0)
+        if onehot:   # stream 2: the one-hot operand was built there during the forward pass (in order)
+            ctx.on_side(wgrad_tables, dh_c, idx_all, which=2)
         for j, k in enumerate(L.num_keys):
-            ctx.on_side(lambda j=j, k=k: wgrad_dense(j, k), dh_c, xs[j], codes[j], which=j + 1)
+            ctx.on_side(lambda j=j, k=k: wgrad_dense(j, k), dh_c, xs[j], codes[j], which=j % 2)
     if not onehot:
         ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
     ctx.join_side()   # last node of the backward pass: every weight gradient is complete after this
@@ -239,8 +249,15 @@ class BlockFn(torch.autograd.Function):
                                               ctx.step_ptr))
             ctx.handoff[i - 1] = nxt
         else:
-            dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
-                                   st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"))
+            if cdt == torch.bfloat16:
+                # block 0: the fused consumer at rate 0 is a plain compute-dtype copy of dx -- what the
+                # encoder's weight-gradient products read (saves the cast pass at the end of the step)
+                dx, ctx.dh_c = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
+                                                 st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"),
+                                                 drop=(st.scratch("ln_dummy_colsum", (D,), torch.float32), 0.0, 0, 0, None))
+            else:
+                dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
+                                       st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"))
         fctx.saved = None
         return dx, None, None
 
