@@ -523,3 +523,26 @@ def test_layernorm_bwd_deferred_partials():
         outs.append((dx, dd, dg, db, cs))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,T,sk", [(256, 512, 4096, 8), (344, 256, 4096, 16), (1384, 256, 2048, 8), (136, 72, 1100, 8)])
+def test_gemm_streaming_wgrad(M, N, T, sk):
+    """gemm_wg_kernel (bf16, splitk % 8 == 0): C = A^T B over the token dimension with ragged last
+    k-tiles / tiles, fused bias-gradient column sums and skipped rows, against a double reference."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + T)
+    A = bf16_round(torch.randn(T, M, generator=g))
+    Bm = bf16_round(torch.randn(T, N, generator=g))
+    code = (torch.rand(T, generator=g) < 0.25).to(torch.uint8)
+    out = torch.full((M, N), 5.0, device=DEV)
+    colsum = torch.full((M,), 5.0, device=DEV)
+    ops.gemm(A.to(DEV, torch.bfloat16), Bm.to(DEV, torch.bfloat16), M, N, T, a_kmajor=False, b_kmajor=False, out=out,
+             colsum=colsum, rowskip_a=code.to(DEV), splitk=sk)
+    keep = (code == 0).double()[:, None]
+    want = (A.double() * keep).t() @ Bm.double()
+    assert_close(out, want, 2e-4 * math.sqrt(T), 1e-5, "streaming wgrad")
+    assert_close(colsum, (A.double() * keep).sum(0), 2e-4 * math.sqrt(T), 1e-5, "bias gradient")
+    out2 = torch.empty((M, N), device=DEV)
+    ops.gemm(A.to(DEV, torch.bfloat16), Bm.to(DEV, torch.bfloat16), M, N, T, a_kmajor=False, b_kmajor=False, out=out2,
+             splitk=sk)
+    assert_close(out2, A.double().t() @ Bm.double(), 2e-4 * math.sqrt(T), 1e-5, "streaming wgrad plain")
