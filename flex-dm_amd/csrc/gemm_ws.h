@@ -1,6 +1,6 @@
 // Weight-stationary streaming GEMM for the Dense layers of the MFP path (gfx950, bf16 operands).
 //
-//   C[M][N] = epilogue( X[M][K] * Wt[N][K]^T ),  K = 256 or 512,  M = batch*seq_len elements (huge),
+//   C[M][N] = epilogue( X[M][K] * Wt[N][K]^T ),  K = 256, 512 or 768,  M = batch*seq_len elements (huge),
 //   N = 256..1384: every Dense forward of the model, and every dgrad whose weight has a transposed
 //   bf16 shadow (reference: architecture/transformer.py:85-98,163-169, encoder.py:88-92,
 //   decoder.py:39-43).
@@ -11,8 +11,9 @@
 // a 1 KB store accepted only every ~350 clk).  The tile kernel in gemm.hip re-stages the weight
 // tile for every 64x128 output tile and runs load / multiply / store rounds in lock-step.  Here:
 //   * ONE persistent workgroup per CU, 8 waves = 4 MATH waves + 4 MEMORY waves (2 per SIMD);
-//   * math waves keep the workgroup's weight slice (256 columns x K=256, or 128 x 512: 128 KB) in
-//     REGISTERS for the whole kernel (128 VGPRs of MFMA fragments per lane), read X fragments from
+//   * math waves keep the workgroup's weight slice (256 columns x K=256, 128 x 512, 64 x 768; half
+//     that for the N <= 256 layers: NARROW) in REGISTERS for the whole kernel (<= 128 VGPRs of MFMA
+//     fragments per lane, filled once through LDS with full-line loads), read X fragments from
 //     LDS, multiply, add bias / ReLU and drop the tile into an LDS output stage -- they never
 //     touch vector memory, so a store that waits for the write path never stalls an MFMA;
 //   * memory waves do ALL vector memory: X tiles global -> registers (4 tiles in flight) ->
