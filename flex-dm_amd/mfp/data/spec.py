@@ -11,9 +11,11 @@ Mirrors the *contract* of the reference's ``DataSpec`` (reference
   layout (int32 ``(B,S,N)`` categorical, float32 ``(B,S,512)`` numerical, zero-based
   ``length (B,1)``, zero padding past ``length``; reference ``spec.py:255-285``).
 
-The TFRecord reader itself (``tf.data`` + Keras preprocessing layers) is out of scope for
-this round: batches are *synthetic*, drawn with the distributions of
-SURVEY.md §8d.  The schema is held as Python tables below rather than YAML; the values
+Batches are *synthetic* (distributions of SURVEY.md §8d) unless ``path`` holds the reference's
+``<split>-*.tfrecord`` files: those are read without TensorFlow by ``mfp.data.tfrecord`` and
+preprocessed here with the semantics of the reference's Keras layers (SURVEY.md §8f row 3;
+reference spec.py:88-134,213-287, discretizer.py:5-31).  The schema is held as Python tables
+below rather than YAML; the values
 (bins, shapes, loss conditions, column order) are those of the reference's
 ``crello-spec.yml`` / ``rico-spec.yml``.  Vocabulary sizes that the reference reads from
 ``vocabulary.json`` (absent from the reference tree) default to the synthetic values of
@@ -60,7 +62,7 @@ _SCHEMAS = {
         ("width", _disc(64)),
         ("height", _disc(64)),
         ("opacity", _disc(8)),
-        ("color", dict(_disc(16, shape=(3,)),
+        ("color", dict(_disc(16, shape=(3,)), min=0.0, max=255.0, raw="int64",   # crello-spec.yml:80-92
                        loss_condition=("type", ["textElement", "coloredBackground"]))),
         ("image_embedding", dict(kind="float", shape=(512,), is_sequence=True,
                                  loss_condition=("type", ["svgElement", "imageElement",
@@ -242,6 +244,195 @@ def synthetic_batch(
     return batch
 
 
+# --------------------------------------------------------------------------- real data (TFRecord)
+def _raw_kind(col: Dict) -> str:
+    """Feature type a column is stored with in the SequenceExample (the spec's ``dtype``)."""
+    if "raw" in col:
+        return col["raw"]
+    k = col["kind"]
+    if k == "demo":
+        return "bytes"
+    if k == "lookup":
+        return "bytes" if any(isinstance(v, str) for v in col["vocab"]) else "int64"
+    if k in ("discretize", "float"):
+        return "float"
+    return "int64"
+
+
+def lookup_indices(values, vocab: List, name: str = "") -> np.ndarray:
+    """Keras StringLookup / IntegerLookup as the reference configures them (spec.py:103-134): the index
+    of a token is its position in ``get_vocabulary()`` (= ``vocab`` here: mask token or OOV token
+    first when the layer has one); tokens outside it map to the OOV slot 0 when the vocabulary
+    starts with ``[UNK]`` / ``-1`` and are an error otherwise (``num_oov_indices: 0``)."""
+    table = {(v.encode() if isinstance(v, str) else v): i for i, v in enumerate(vocab)}
+    has_oov = len(vocab) > 0 and vocab[0] in ("[UNK]", -1)
+    flat = np.asarray(values, dtype=object).reshape(-1)
+    out = np.empty(flat.shape, dtype=np.int32)
+    for i, v in enumerate(flat):
+        if isinstance(v, (np.integer,)):
+            v = int(v)
+        j = table.get(v)
+        if j is None:
+            if not has_oov:
+                raise ValueError("column %s: %r is not in the vocabulary and the lookup has no OOV slot" % (name, v))
+            j = 0
+        out[i] = j
+    return out.reshape(np.asarray(values, dtype=object).shape)
+
+
+def discretize(x: np.ndarray, lo: float, hi: float, bins: int) -> np.ndarray:
+    """Keras Discretization(linspace(lo, hi, bins)[1:]) (spec.py:95-100): class = number of
+    boundaries <= x (tf Bucketize), i.e. 0 .. bins-1."""
+    boundaries = np.linspace(lo, hi, bins)[1:]
+    return np.searchsorted(boundaries, np.asarray(x, dtype=np.float32), side="right").astype(np.int32)
+
+
+def parse_examples(records: List[bytes], schema, device: str = "cpu", include_demo: bool = False,
+                   seq_len: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """``tf.io.parse_sequence_example`` on a batch of serialized records + the per-column
+    preprocessing + the int64 -> int32 cast of reference spec.py:255-285.  Sequence features are
+    zero / empty-string padded to the longest document of the batch BEFORE preprocessing, as the
+    batched TF parser does.  demo_only columns come back as Python lists of bytes."""
+    from mfp.data import tfrecord
+    parsed = [tfrecord.parse_sequence_example(r) for r in records]
+    B = len(parsed)
+    S = 1
+    for _, lists in parsed:
+        for steps in lists.values():
+            S = max(S, len(steps))
+    if seq_len is not None:       # fixed-shape batches (hipGraph replay): pad every batch to seq_len
+        if S > seq_len:
+            raise ValueError("document of %d elements does not fit seq_len=%d" % (S, seq_len))
+        S = seq_len
+    out: Dict[str, torch.Tensor] = {}
+    for key, col in schema:
+        if col["kind"] == "demo" and not include_demo:
+            continue
+        raw, width = _raw_kind(col), int(np.prod(col.get("shape", (1,))))
+        pad = b"" if raw == "bytes" else 0
+        is_seq = bool(col.get("is_sequence", False))
+        if is_seq:
+            arr = np.empty((B, S, width), dtype=object if raw == "bytes" else (np.float32 if raw == "float" else np.int64))
+            arr[...] = pad
+            for b, (_, lists) in enumerate(parsed):
+                for t, step in enumerate(lists.get(key, [])):
+                    vals = list(step)
+                    if len(vals) != width:
+                        raise ValueError("column %s: step of %d values, expected %d" % (key, len(vals), width))
+                    arr[b, t, :] = vals
+        else:
+            arr = np.empty((B, width), dtype=object if raw == "bytes" else (np.float32 if raw == "float" else np.int64))
+            arr[...] = pad
+            for b, (ctx, _) in enumerate(parsed):
+                vals = list(ctx.get(key, []))
+                if len(vals) != width:
+                    raise ValueError("column %s: %d context values, expected %d" % (key, len(vals), width))
+                arr[b, :] = vals
+        kind = col["kind"]
+        if kind == "demo":
+            out[key] = arr.tolist()
+            continue
+        if kind == "lookup":
+            arr = lookup_indices(arr, col["vocab"], key)
+        elif kind == "discretize":
+            arr = discretize(arr, col.get("min", 0.0), col.get("max", 1.0), col["bins"])
+        elif kind == "float":
+            arr = arr.astype(np.float32)
+        else:
+            arr = arr.astype(np.int32)
+        out[key] = torch.from_numpy(np.ascontiguousarray(arr))
+    if device != "cpu":
+        out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in out.items()}
+    return out
+
+
+class _TFRecordDataset:
+    """Iterable over the batches of ``<path>/<split>-*.tfrecord`` (reference make_dataset,
+    spec.py:213-253): list files, (shuffle), (repeat), batch, parse + preprocess."""
+
+    def __init__(self, files, schema, batch_size, shuffle, repeat, device, seed=0, seq_len=None):
+        self._seq_len = seq_len
+        self._files, self._schema, self._bs = files, schema, batch_size
+        self._shuffle, self._repeat, self._device = bool(shuffle), repeat, device
+        self._rng = np.random.default_rng(seed)
+        self._count = None
+
+    def _records(self) -> List[bytes]:
+        from mfp.data import tfrecord
+        recs: List[bytes] = []
+        for f in self._files:
+            recs.extend(tfrecord.read_records(f))
+        return recs
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        recs = self._records()
+        self._count = len(recs)
+        while True:
+            order = self._rng.permutation(len(recs)) if self._shuffle else np.arange(len(recs))
+            for i in range(0, len(recs), self._bs):
+                yield parse_examples([recs[j] for j in order[i:i + self._bs]], self._schema, self._device,
+                                     seq_len=self._seq_len)
+            if not self._repeat:
+                return
+
+    def __len__(self):
+        if self._count is None:
+            self._count = len(self._records())
+        return int(np.ceil(self._count / self._bs))
+
+
+def write_synthetic_tfrecords(data_dir: str, name: str, docs: Dict[str, int], seq_len: int = 12, seed: int = 0,
+                              shards: int = 2) -> Dict[str, list]:
+    """Write ``<split>-0000i.tfrecord`` shards + ``count.json`` with random RAW documents (strings,
+    unbucketed floats) of dataset ``name`` -- the format the reference's converters produce.
+    Returns the raw documents per split (for tests)."""
+    from mfp.data import tfrecord
+    rng = np.random.default_rng(seed)
+    schema = _resolve_schema(name, None)
+    os.makedirs(data_dir, exist_ok=True)
+    raw_docs: Dict[str, list] = {}
+    for split, n_docs in docs.items():
+        out = []
+        for d in range(n_docs):
+            n = int(rng.integers(1, seq_len + 1))
+            ctx, lists = {}, {}
+            for key, col in schema:
+                raw, width = _raw_kind(col), int(np.prod(col.get("shape", (1,))))
+
+                def draw():
+                    if key == "length":
+                        return np.array([n], dtype=np.int64)
+                    if col["kind"] == "lookup":
+                        vocab = [v for v in col["vocab"] if v not in ("", "[UNK]", -1)]
+                        pick = [vocab[int(i)] for i in rng.integers(0, len(vocab), size=width)]
+                        return pick if raw == "bytes" else np.array(pick, dtype=np.int64)
+                    if col["kind"] == "demo":
+                        return ["doc%d" % d] * width
+                    if col["kind"] == "int":
+                        return rng.integers(0, col["max"] + 1, size=width).astype(np.int64)
+                    if col["kind"] == "discretize":
+                        lo, hi = col.get("min", 0.0), col.get("max", 1.0)
+                        if raw == "int64":
+                            return rng.integers(int(lo), int(hi) + 1, size=width).astype(np.int64)
+                        return (lo + (hi - lo) * rng.random(width)).astype(np.float32)
+                    v = rng.standard_normal(width).astype(np.float32)
+                    return v / np.linalg.norm(v)
+                if col.get("is_sequence", False):
+                    lists[key] = [draw() for _ in range(n)]
+                else:
+                    ctx[key] = draw()
+            out.append((ctx, lists))
+        raw_docs[split] = out
+        per = int(np.ceil(n_docs / shards))
+        for sh in range(shards):
+            chunk = out[sh * per:(sh + 1) * per]
+            tfrecord.write_records(os.path.join(data_dir, "%s-%05d.tfrecord" % (split, sh)),
+                                   (tfrecord.encode_sequence_example(c, l) for c, l in chunk))
+    with open(os.path.join(data_dir, "count.json"), "w") as f:
+        json.dump({k: v for k, v in docs.items()}, f)
+    return raw_docs
+
+
 class _SyntheticDataset:
     """Iterable of synthetic batches; stands in for the reference's ``tf.data`` pipeline."""
 
@@ -272,8 +463,9 @@ class DataSpec(object):
     """Drop-in for the reference ``DataSpec(name, path, batch_size)`` (spec.py:24-76).
 
     ``path`` is either ``"synthetic"`` / ``"synthetic:<seq_len>[:<docs>]"`` or a directory;
-    a directory is consulted for ``vocabulary.json`` / ``count.json`` (spec.py:74-86) and
-    batches are still synthetic until the TFRecord reader lands.
+    a directory is consulted for ``vocabulary.json`` / ``count.json`` (spec.py:74-86) and, when it
+    holds ``<split>-*.tfrecord`` files, ``make_dataset`` reads them (TensorFlow-free reader,
+    ``mfp.data.tfrecord``); otherwise batches are synthetic.
     """
 
     def __init__(self, name, path, batch_size=8, seq_len: Optional[int] = None,
@@ -300,6 +492,7 @@ class DataSpec(object):
             if os.path.exists(cpath):
                 with open(cpath) as f:
                     self._splits = json.load(f)
+        self._fixed_seq_len = seq_len      # None: pad each batch to its longest document (the reference)
         self._seq_len = seq_len or 50
         if not hasattr(self, "_splits"):
             docs = docs or 4 * batch_size
@@ -330,6 +523,13 @@ class DataSpec(object):
                      parallel=None, cache=None):
         assert split in self._splits, "split must be one of (%s)" % ", ".join(self._splits)
         bs = batch_size or self._batch_size
+        if not self._path.startswith("synthetic"):
+            from mfp.data import tfrecord
+            files = tfrecord.list_split_files(self._path, split)
+            if files:
+                logger.info("TFRecord from %s (%d files)", os.path.join(self._path, split + "-*.tfrecord"), len(files))
+                return _TFRecordDataset(files, self._schema, bs, shuffle, repeat, self._device,
+                                        seq_len=self._fixed_seq_len)
         seed = {"train": 0, "val": 100003, "test": 200003}.get(split, 300007)
         return _SyntheticDataset(self.make_input_columns(), bs, self._seq_len,
                                  self.steps_per_epoch(split, bs), seed, self._ragged, repeat,

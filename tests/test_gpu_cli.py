@@ -42,3 +42,19 @@ def test_train_cli_crello_bf16_graph(tmp_path):
           "--num_blocks", "1", "--batch_size", "16", "--num_epochs", "2", "--validation_freq", "2",
           "--masking_method", "elem_pos_attr_img_txt", "--dtype", "bf16", "--use_graph", "--verbose", "0"])
     assert os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))
+
+
+def test_train_cli_on_tfrecord_directory(tmp_path, capsys):
+    """--data_dir pointing at <split>-*.tfrecord files (the reference's dataset layout): read by the
+    TensorFlow-free reader, variable sequence length per batch, eager f32 steps."""
+    from mfp.data.spec import write_synthetic_tfrecords
+    from mfp.main import main
+    data = str(tmp_path / "crello")
+    write_synthetic_tfrecords(data, "crello", {"train": 24, "val": 8, "test": 8}, seq_len=9, seed=2)
+    job = str(tmp_path / "job3")
+    main(["--dataset_name", "crello", "--data_dir", data, "--job-dir", job, "--latent_dim", "128",
+          "--num_blocks", "1", "--batch_size", "8", "--num_epochs", "1", "--validation_freq", "1",
+          "--masking_method", "random", "--dtype", "fp32", "--verbose", "0"])
+    out = capsys.readouterr().out
+    assert "total_score" in out
+    assert os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))
