@@ -20,11 +20,13 @@ struct LossKeys {
 
 // The three loads are issued unconditionally and independently (one memory latency, not a chain of
 // three): these kernels are latency-bound, their workgroups live for a handful of round trips.
-__device__ __forceinline__ float token_weight(const mfp_loss_key& k, const int* nvalid, int t, int S) {
+// `tt` = row of the TARGET tensors that sits at position t (== t unless the loss is position-sorted:
+// the mfp mask and the sequence mask stay positional, metrics.py:251,263).
+__device__ __forceinline__ float token_weight(const mfp_loss_key& k, const int* nvalid, int t, int tt, int S) {
   const int b = t / S, s = t % S;
   const unsigned char m = k.mask[t];
   const int nv = nvalid[b];
-  const int v = k.cond_idx != nullptr ? k.cond_idx[(long long)t * k.cond_stride] : 0;
+  const int v = k.cond_idx != nullptr ? k.cond_idx[(long long)tt * k.cond_stride] : 0;
   const bool c = k.cond_idx == nullptr || (v >= 0 && v < 32 && ((k.cond_bits >> v) & 1u));
   return (m != 0 && s < nv && c) ? 1.f : 0.f;
 }
@@ -56,7 +58,8 @@ struct CeRanges {
 template <typename TDL>
 __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ logits, TDL* __restrict__ dlogits,
                                                       int ld, LossKeys keys, CeRanges rg, const int* __restrict__ nvalid,
-                                                      float* __restrict__ sums, int T, int S, float inv_B) {
+                                                      float* __restrict__ sums, int T, int S, float inv_B,
+                                                      const int* __restrict__ pred_row, const int* __restrict__ true_row) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [CE_TOK][rg.width]
   __shared__ float red[MFP_MAX_LOSS_KEYS][3];
   __shared__ int nactive;
@@ -76,16 +79,18 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
     const int item = l16, t = t0 + row16;
     if (item < rg.nitem && t < T) {
       const mfp_loss_key& key = keys.k[rg.item_key[item]];
-      act = token_weight(key, nvalid, t, S) != 0.f;
-      ylab = reinterpret_cast<const int*>(key.target)[(long long)t * key.n_feat + rg.item_feat[item]];
+      const int tt = true_row ? true_row[t] : t;
+      act = token_weight(key, nvalid, t, tt, S) != 0.f;
+      ylab = reinterpret_cast<const int*>(key.target)[(long long)tt * key.n_feat + rg.item_feat[item]];
     }
   }
-  // ---- 1. stage
+  // ---- 1. stage (position t holds logits row pred_row[t] when the loss is position-sorted)
+  const int prow = (pred_row && t0 + row16 < T) ? pred_row[t0 + row16] : t0 + row16;
   {
     const int t = t0 + row16;
     for (int r = 0; r < rg.n; ++r) {
       float* dst = tile + row16 * W + rg.lds_off[r];
-      const float* src = logits + (long long)t * ld + rg.beg[r];
+      const float* src = logits + (long long)prow * ld + rg.beg[r];
       if (rg.vec) {
         for (int c4 = l16; c4 < rg.len[r] / 4; c4 += 16)
           *reinterpret_cast<float4*>(dst + 4 * c4) = t < T ? *reinterpret_cast<const float4*>(src + 4 * c4)
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
     if (t < T) {
       for (int r = 0; r < rg.n; ++r) {
         const float* src = tile + row16 * W + rg.lds_off[r];
-        TDL* dst = dlogits + (long long)t * ld + rg.beg[r];
+        TDL* dst = dlogits + (long long)prow * ld + rg.beg[r];
         if (rg.vec) {
           for (int c8 = l16; c8 < rg.len[r] / 8; c8 += 16) {
             const float4 a = *reinterpret_cast<const float4*>(src + 8 * c8);
@@ -203,22 +208,30 @@ constexpr int MSE_TOK = 16;   // tokens per workgroup (4 per wave)
 template <typename TDL, bool VEC>
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, TDL* __restrict__ dpred,
                                                   int ld, LossKeys keys, const int* __restrict__ nvalid,
-                                                  float* __restrict__ sums, int T, int S, float inv_B) {
+                                                  float* __restrict__ sums, int T, int S, float inv_B,
+                                                  const int* __restrict__ pred_row, const int* __restrict__ true_row) {
   __shared__ float red[3][4];
   __shared__ float wt[MSE_TOK];
+  __shared__ int prow_s[MSE_TOK], trow_s[MSE_TOK];
   const mfp_loss_key k = keys.k[blockIdx.y];
   const int W = k.n_class;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* target = reinterpret_cast<const float*>(k.target);
   const int t0 = blockIdx.x * MSE_TOK;
-  if (threadIdx.x < MSE_TOK) wt[threadIdx.x] = t0 + (int)threadIdx.x < T ? token_weight(k, nvalid, t0 + threadIdx.x, S) : -1.f;
+  if (threadIdx.x < MSE_TOK) {
+    const int t = t0 + (int)threadIdx.x;
+    const int tt = (true_row && t < T) ? true_row[t] : t;
+    prow_s[threadIdx.x] = (pred_row && t < T) ? pred_row[t] : t;
+    trow_s[threadIdx.x] = tt;
+    wt[threadIdx.x] = t < T ? token_weight(k, nvalid, t, tt, S) : -1.f;
+  }
   __syncthreads();
   float acc_loss = 0.f, acc_score = 0.f, acc_den = 0.f;
   for (int tt = wave; tt < MSE_TOK; tt += 4) {
-    const int t = t0 + tt;
     const float w = wt[tt];
     if (w < 0.f) break;
-    const long long base = (long long)t * ld + k.col_off;
+    const long long base = (long long)prow_s[tt] * ld + k.col_off;
+    const long long tbase = (long long)trow_s[tt] * W;
     if (w == 0.f) {
       if (dpred) {
         if (VEC) {
@@ -242,8 +255,8 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
         float p[8], y[8], d[8];
         *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(pred + base + c);
         *reinterpret_cast<float4*>(p + 4) = *reinterpret_cast<const float4*>(pred + base + c + 4);
-        *reinterpret_cast<float4*>(y) = *reinterpret_cast<const float4*>(target + (long long)t * W + c);
-        *reinterpret_cast<float4*>(y + 4) = *reinterpret_cast<const float4*>(target + (long long)t * W + c + 4);
+        *reinterpret_cast<float4*>(y) = *reinterpret_cast<const float4*>(target + tbase + c);
+        *reinterpret_cast<float4*>(y + 4) = *reinterpret_cast<const float4*>(target + tbase + c + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           d[e] = p[e] - y[e];
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
       }
     } else {
       for (int j = lane; j < W; j += 64) {
-        const float p = pred[base + j], y = target[(long long)t * W + j];
+        const float p = pred[base + j], y = target[tbase + j];
         const float d = p - y;
         sd += d * d; sy += y * y; sp += p * p; syp += y * p;
         if (dpred) cdt_traits<TDL>::store(dpred + base + j, 2.f * d * inv_B);
@@ -291,11 +304,109 @@ __global__ void zero_sums_kernel(float* __restrict__ sums, int n) {
   if (i < n) sums[i] = 0.f;
 }
 
+// Position-sorted loss (reference models/tensor_utils.py:14-44): one workgroup per document.
+//   priority(s) = sum_k v_k(s) 100^(4-k) + [s >= nvalid] 100^5,  v_k = label or first-index argmax
+//   slot(s)     = #{j : p_j < p_s  or  (p_j == p_s and j < s)}          (stable ascending order)
+//   row_map[b*S + slot(s)] = b*S + s     (identity for documents whose flag is 0)
+// logits mode: one wave per position, lanes over the classes of each of the five heads.
+struct SortSrc {
+  const int* label[5];
+  int label_stride[5];
+  int col_off[5], n_class[5];
+};
+
+constexpr int SORT_MAX_S = 1024;
+
+__global__ __launch_bounds__(256) void sort_positions_kernel(SortSrc src, const float* __restrict__ logits, int ld,
+                                                             const int* __restrict__ nvalid,
+                                                             const unsigned char* __restrict__ flag,
+                                                             int* __restrict__ row_map, int S) {
+  __shared__ long long prio[SORT_MAX_S];
+  const int b = blockIdx.x;
+  const int base = b * S;
+  if (!flag[b]) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) row_map[base + s] = base + s;
+    return;
+  }
+  const int nv = nvalid[b];
+  if (logits == nullptr) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+      long long p = 0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) p = p * 100 + src.label[k][(long long)(base + s) * src.label_stride[k]];
+      prio[s] = p + (s >= nv ? 10000000000LL : 0LL);
+    }
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int s = wave; s < S; s += nwave) {
+      const float* row = logits + (long long)(base + s) * ld;
+      long long p = 0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        float m = -INFINITY;
+        int am = 0x7fffffff;
+        for (int j = lane; j < src.n_class[k]; j += 64) {
+          const float v = row[src.col_off[k] + j];
+          if (v > m) { m = v; am = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float om = __shfl_xor(m, o, 64);
+          const int oa = __shfl_xor(am, o, 64);
+          if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        }
+        if (am == 0x7fffffff) am = 0;   // a row of NaNs: argmax 0, as a serial first-maximum walk
+        p = p * 100 + am;
+      }
+      if (lane == 0) prio[s] = p + (s >= nv ? 10000000000LL : 0LL);
+    }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const long long p = prio[s];
+    int slot = 0;
+    for (int j = 0; j < S; ++j) {
+      const long long q = prio[j];
+      slot += (q < p || (q == p && j < s)) ? 1 : 0;
+    }
+    row_map[base + slot] = base + s;
+  }
+}
+
 }  // namespace
+
+extern "C" int mfp_sort_positions(const int32_t* const* labels, const int32_t* label_stride, const float* logits,
+                                  int32_t ld, const int32_t* col_off, const int32_t* n_class, const int32_t* nvalid,
+                                  const uint8_t* flag, int32_t* row_map, int32_t B, int32_t S, mfp_stream_t stream) {
+  MFP_CHECK_ARG(nvalid && flag && row_map && B > 0 && S > 0 && S <= SORT_MAX_S);
+  MFP_CHECK_ARG((labels && label_stride) || (logits && col_off && n_class && ld > 0));
+  SortSrc src;
+  for (int k = 0; k < 5; ++k) {
+    src.label[k] = nullptr; src.label_stride[k] = 0; src.col_off[k] = 0; src.n_class[k] = 0;
+    if (logits) {
+      MFP_CHECK_ARG(n_class[k] > 0 && n_class[k] < 100 && col_off[k] >= 0 && col_off[k] + n_class[k] <= ld);
+      src.col_off[k] = col_off[k]; src.n_class[k] = n_class[k];
+    } else {
+      MFP_CHECK_ARG(labels[k] && label_stride[k] > 0);
+      src.label[k] = labels[k]; src.label_stride[k] = label_stride[k];
+    }
+  }
+  hipLaunchKernelGGL(sort_positions_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, logits, ld,
+                     nvalid, flag, row_map, S);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
 
 extern "C" int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
                                 int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
                                 int32_t dl_dtype, mfp_stream_t stream) {
+  return mfp_loss_fwd_bwd_sorted(logits, dlogits, ld, keys, nkeys, nvalid, sums, B, S, dl_dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int mfp_loss_fwd_bwd_sorted(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
+                                       int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
+                                       int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row,
+                                       mfp_stream_t stream) {
   MFP_CHECK_ARG(logits && keys && nvalid && sums);
   MFP_CHECK_ARG(nkeys > 0 && nkeys <= MFP_MAX_LOSS_KEYS && B > 0 && S > 0 && ld > 0);
   MFP_CHECK_ARG(dl_dtype == MFP_F32 || dl_dtype == MFP_BF16);
@@ -381,16 +492,16 @@ extern "C" int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, 
     }
     const int bx = (T + CE_TOK - 1) / CE_TOK;
     if (dl_dtype == MFP_F32)
-      hipLaunchKernelGGL(ce_tile_kernel<float>, dim3(bx), dim3(256), lds, st, logits, (float*)dlogits, ld, cat, rg, nvalid, sums, T, S, inv_B);
+      hipLaunchKernelGGL(ce_tile_kernel<float>, dim3(bx), dim3(256), lds, st, logits, (float*)dlogits, ld, cat, rg, nvalid, sums, T, S, inv_B, pred_row, true_row);
     else
-      hipLaunchKernelGGL(ce_tile_kernel<unsigned short>, dim3(bx), dim3(256), lds, st, logits, (unsigned short*)dlogits, ld, cat, rg, nvalid, sums, T, S, inv_B);
+      hipLaunchKernelGGL(ce_tile_kernel<unsigned short>, dim3(bx), dim3(256), lds, st, logits, (unsigned short*)dlogits, ld, cat, rg, nvalid, sums, T, S, inv_B, pred_row, true_row);
     MFP_CHECK_LAUNCH();
   }
   if (num.n > 0) {
     const int bx = (T + MSE_TOK - 1) / MSE_TOK;
     bool vec = ld % 8 == 0;
     for (int i = 0; i < num.n; ++i) vec = vec && num.k[i].col_off % 8 == 0 && num.k[i].n_class % 8 == 0;
-#define MSE_LAUNCH(TT, V) hipLaunchKernelGGL((mse_kernel<TT, V>), dim3(bx, num.n), dim3(256), 0, st, logits, (TT*)dlogits, ld, num, nvalid, sums, T, S, inv_B)
+#define MSE_LAUNCH(TT, V) hipLaunchKernelGGL((mse_kernel<TT, V>), dim3(bx, num.n), dim3(256), 0, st, logits, (TT*)dlogits, ld, num, nvalid, sums, T, S, inv_B, pred_row, true_row)
     if (dl_dtype == MFP_F32) { if (vec) MSE_LAUNCH(float, true); else MSE_LAUNCH(float, false); }
     else { if (vec) MSE_LAUNCH(unsigned short, true); else MSE_LAUNCH(unsigned short, false); }
 #undef MSE_LAUNCH

@@ -81,6 +81,10 @@ SIGNATURES = {
     "mfp_row_flags": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p]),
     "mfp_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
                                    c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mfp_loss_fwd_bwd_sorted": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
+                                          c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "mfp_sort_positions": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_void_p, c_int32, POINTER(c_int32),
+                                     POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_adam_num_chunks": (c_int64, [POINTER(c_int32), c_int32]),
     "mfp_adam_chunk_table": (c_int32, [POINTER(c_int32), c_int32, POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32), POINTER(c_int32)]),

@@ -34,6 +34,7 @@ class StepCtx:
         self.dh_c = None    # compute-dtype copy of the encoder output gradient (block 0's LN1 backward)
         self.onehot = None  # one-hot count matrix of the index columns (built during the forward pass)
         self.mid = None     # activation entering block L/2 (set by Blocks; see MFP.capture_train_step)
+        self.loss_sort = None   # RICO position-sorted loss: dict(flag, labels, heads, ignore_sort)
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
         self.nvalid = nvalid
         self.training = training
@@ -302,6 +303,19 @@ class DecoderFn(torch.autograd.Function):
         return dh, None
 
 
+def loss_row_maps(sort, logits, nvalid, B, S):
+    """(pred_row, true_row) of the position-sorted loss (reference metrics.py:180-211): targets are
+    ordered by their labels, predictions by their own argmax, both only for the flagged documents."""
+    if sort is None:
+        return None, None
+    pred_row = true_row = None
+    if sort.get("ignore_sort") != "gt":
+        true_row = ops.sort_positions(nvalid, sort["flag"], B, S, labels=sort["labels"])
+    if sort.get("ignore_sort") != "pred":
+        pred_row = ops.sort_positions(nvalid, sort["flag"], B, S, logits=logits, heads=sort["heads"])
+    return pred_row, true_row
+
+
 class DecoderLossFn(torch.autograd.Function):
     """Heads + fused LossLayer.  Returns ``(loss_total, sums[nkeys,3], logits)``; the backward
     assumes the conventional unit upstream gradient on ``loss_total``."""
@@ -314,7 +328,9 @@ class DecoderLossFn(torch.autograd.Function):
         h_c = ctx.to_cdt(h.contiguous())
         logits = _heads_fwd(ctx, h_c)
         dl = ctx.store.scratch("dlogits", logits.shape, ctx.cdt)   # zeroed once: pad columns stay 0
-        sums, dl = ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt, dlogits=dl)
+        pred_row, true_row = loss_row_maps(ctx.loss_sort, logits, ctx.nvalid, ctx.B, ctx.S)
+        sums, dl = ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt, dlogits=dl,
+                                    pred_row=pred_row, true_row=true_row)
         fctx.ctx, fctx.saved = ctx, (h_c, dl)
         fctx.mark_non_differentiable(sums, logits)
         return sums[:, 0].sum(), sums, logits

@@ -291,9 +291,12 @@ def row_flags(x: torch.Tensor, rowcode: torch.Tensor, special_idx: Optional[torc
 # ---------------------------------------------------------------------------------- losses
 def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tensor, B: int, S: int,
                  dl_dtype: Optional[torch.dtype], sums: Optional[torch.Tensor] = None,
-                 dlogits: Optional[torch.Tensor] = None):
+                 dlogits: Optional[torch.Tensor] = None, pred_row: Optional[torch.Tensor] = None,
+                 true_row: Optional[torch.Tensor] = None):
     """keys: dicts with col_off, n_feat, n_class, is_numerical, target, mask, cond_idx,
-    cond_stride, cond_bits.  Returns (sums [nkeys,3], dlogits or None)."""
+    cond_stride, cond_bits.  Returns (sums [nkeys,3], dlogits or None).  ``pred_row`` /
+    ``true_row`` (int32 [B*S] permutations from :func:`sort_positions`) select the RICO
+    position-sorted loss (reference metrics.py:180-211)."""
     lib = load()
     ld = logits.shape[1]
     arr = (LossKey * len(keys))()
@@ -311,9 +314,43 @@ def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tenso
     code = dt_code(dlogits.dtype) if dlogits is not None else MFP_F32
     nb = logits.numel() * (4 + (_esz(dlogits) if dlogits is not None else 0))
     with _timed("loss_kernels(ce+mse)", 0, nb):
-        check(lib.mfp_loss_fwd_bwd(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid), _ptr(sums),
-                                   B, S, code, _stream()), "mfp_loss_fwd_bwd")
+        if pred_row is None and true_row is None:
+            check(lib.mfp_loss_fwd_bwd(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid), _ptr(sums),
+                                       B, S, code, _stream()), "mfp_loss_fwd_bwd")
+        else:
+            for m in (pred_row, true_row):
+                assert m is None or (m.dtype == torch.int32 and m.numel() == B * S and m.is_contiguous())
+            check(lib.mfp_loss_fwd_bwd_sorted(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid),
+                                              _ptr(sums), B, S, code, _ptr(pred_row), _ptr(true_row), _stream()),
+                  "mfp_loss_fwd_bwd_sorted")
     return sums, dlogits
+
+
+def sort_positions(nvalid: torch.Tensor, flag: torch.Tensor, B: int, S: int, labels: Sequence[torch.Tensor] = None,
+                   logits: torch.Tensor = None, heads: Sequence = None, out: torch.Tensor = None) -> torch.Tensor:
+    """Row map of ``sort_inputs`` (reference tensor_utils.py:14-44) for the documents whose
+    ``flag`` (uint8 [B]) is set, identity elsewhere.  ``labels``: five int32 tensors [B*S, n]
+    (type, left, top, width, height; feature 0 is the sort key) -- or ``logits`` f32 [B*S, ld] with
+    ``heads`` = five (col_off, n_class) pairs (from_logits=True: first-index argmax)."""
+    lib = load()
+    assert flag.dtype == torch.uint8 and flag.numel() == B and nvalid.dtype == torch.int32
+    if out is None:
+        out = torch.empty(B * S, dtype=torch.int32, device=nvalid.device)
+    if logits is not None:
+        assert logits.dtype == torch.float32 and logits.is_contiguous() and len(heads) == 5
+        co = (ctypes.c_int32 * 5)(*[int(h[0]) for h in heads])
+        nc = (ctypes.c_int32 * 5)(*[int(h[1]) for h in heads])
+        check(lib.mfp_sort_positions(None, None, _ptr(logits), logits.shape[1], co, nc, _ptr(nvalid), _ptr(flag),
+                                     _ptr(out), B, S, _stream()), "mfp_sort_positions")
+    else:
+        assert len(labels) == 5
+        for t in labels:
+            assert t.dtype == torch.int32 and t.is_contiguous() and t.numel() % (B * S) == 0
+        ptrs = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in labels])
+        strides = (ctypes.c_int32 * 5)(*[t.numel() // (B * S) for t in labels])
+        check(lib.mfp_sort_positions(ptrs, strides, None, 0, None, None, _ptr(nvalid), _ptr(flag), _ptr(out),
+                                     B, S, _stream()), "mfp_sort_positions")
+    return out
 
 
 # ------------------------------------------------------------------------------- optimizer

@@ -11,7 +11,8 @@ Keras metric names / definitions are reproduced from it:
 
 ``BeautyLayer`` / ``LayoutMetricLayer`` / ``mae_from_logits`` are unused by train.py and eval.py
  and are not provided.  The RICO position-sorted variant (``sort_flag``,
-metrics.py:180-211) is a "next" row: accepted only when no flag is set.
+metrics.py:180-211) runs on the device too: ``mfp_sort_positions`` turns the two ``sort_inputs``
+calls into row maps that ``mfp_loss_fwd_bwd_sorted`` reads logits / targets through.
 """
 from typing import Dict, List, Union
 
@@ -53,6 +54,24 @@ def build_loss_keys(input_columns: Dict, head_cols: Dict, y_true: Dict, mfp_mask
                      cond_bits=sum(1 << i for i, f in enumerate(cond["mask"]) if f))
         keys.append(d)
     return keys
+
+
+SORT_KEYS = ["type", "left", "top", "width", "height"]   # reference models/tensor_utils.py:11
+
+
+def build_loss_sort(input_columns: Dict, head_cols: Dict, y_true: Dict, sort_flag: torch.Tensor,
+                    ignore_sort: str = None) -> dict:
+    """Descriptor of the position-sorted loss (reference metrics.py:180-211, tensor_utils.py:14-44)
+    for ``ops.sort_positions``: the documents whose ``sort_flag`` is set have targets ordered by
+    (type, left, top, width, height) and predictions ordered by the argmax of those heads."""
+    assert ignore_sort in ("gt", "pred", None)                      # metrics.py:181
+    heads = []
+    for key in SORT_KEYS:
+        assert key in y_true and input_columns[key]["input_dim"] < 100   # tensor_utils.py:19-21
+        heads.append((head_cols[key][0], input_columns[key]["input_dim"]))   # feature 0 of the head
+    flag = sort_flag.view(torch.uint8) if sort_flag.dtype == torch.bool else (sort_flag != 0).to(torch.uint8)
+    labels = [y_true[key].to(torch.int32).contiguous() for key in SORT_KEYS]
+    return dict(flag=flag.contiguous(), labels=labels, heads=heads, ignore_sort=ignore_sort)
 
 
 def metrics_from_sums(input_columns: Dict, sums: torch.Tensor):
@@ -99,14 +118,17 @@ class LossLayer:
     def __call__(self, inputs, training=False, sort_flag: Union[bool, torch.Tensor] = None,
                  ignore_sort: str = None):
         y_true, y_pred, mfp_masks = inputs
-        if torch.is_tensor(sort_flag) and bool(sort_flag.any()):
-            raise NotImplementedError("position-sorted RICO loss (metrics.py:180-211) is a 'next' row")
         first = next(iter(self._head_cols))
         B, S = y_true[first].shape[:2]
         logits = self._flat_logits(y_pred, B, S)
         nvalid = (y_true["length"].reshape(-1) + 1).to(torch.int32)
         keys = build_loss_keys(self._input_columns, self._head_cols, y_true, mfp_masks)
-        sums, _ = ops.loss_fwd_bwd(logits, keys, nvalid, B, S, None)
+        pred_row = true_row = None
+        if torch.is_tensor(sort_flag):                               # metrics.py:180-211
+            from mfp.hip.functions import loss_row_maps
+            sort = build_loss_sort(self._input_columns, self._head_cols, y_true, sort_flag, ignore_sort)
+            pred_row, true_row = loss_row_maps(sort, logits, nvalid, B, S)
+        sums, _ = ops.loss_fwd_bwd(logits, keys, nvalid, B, S, None, pred_row=pred_row, true_row=true_row)
         losses, scores, metrics = metrics_from_sums(self._input_columns, sums)
         self.losses = [sums[:, 0].sum()]
         self.metrics = metrics

@@ -19,7 +19,8 @@ from mfp.data.spec import get_attribute_groups, get_dataset_name
 from mfp.models.architecture.mask import get_seq_mask
 from mfp.models.masking import (apply_token, elem_masking, feat_masking, filter_padding,
                                 get_task_names, random_masking)
-from mfp.models.metrics import LossLayer, build_loss_keys, loss_key_names, metrics_from_sums
+from mfp.models.metrics import (LossLayer, build_loss_keys, build_loss_sort, loss_key_names,
+                                metrics_from_sums)
 from mfp.models.fast_masking import FusedMasker
 from mfp.models.model import Model
 from mfp.models.tensor_utils import shuffle_inputs, sort_inputs
@@ -263,19 +264,26 @@ class MFP:
                                            self.model.store.device)
         else:
             tasks = self.sample_tasks(B)
-        if self.sort_pos and self.task_names.index("pos") in self._active_tasks:
-            raise NotImplementedError("RICO position-sorted training loss is a 'next' row (SURVEY.md §8f-4)")
+        # RICO: documents drawn for the "pos" task are scored order-free (mfp.py:336-338)
+        sorted_loss = self.sort_pos and self.task_names.index("pos") in self._active_tasks
+
+        def loss_sort(targets):
+            if not sorted_loss:
+                return None
+            return build_loss_sort(self._all_input_columns, self.model.layout.head_cols, targets,
+                                   tasks == self.task_names.index("pos"))
         if self.fast_masking and self.input_dtype == "set":
             ctx = self.model.make_ctx(batch, True)
             idx_all, codes, xs, masks = self._masker(batch, tasks, ctx.nvalid, ctx.B, ctx.S, self.model.step_ptr)
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, batch, masks)
-            loss, sums, _ = self.model.forward_loss(None, keys, training=True, premasked=(idx_all, codes, xs), ctx=ctx)
+            loss, sums, _ = self.model.forward_loss(None, keys, training=True, premasked=(idx_all, codes, xs), ctx=ctx,
+                                                    loss_sort=loss_sort(batch))
         else:
             targets, modified_inputs, masks = preprocess_for_train(
                 batch, self.input_columns, tasks, is_autoreg=self.is_autoreg, input_dtype=self.input_dtype,
                 active_tasks=self._active_tasks)
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, targets, masks)
-            loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True)
+            loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True, loss_sort=loss_sort(targets))
         return loss, sums, ctx
 
     def _join_sides(self):
@@ -379,7 +387,10 @@ class MFP:
             targets, modified_inputs, masks = preprocess_for_train(
                 batch, self.input_columns, tasks, input_dtype=self.input_dtype, active_tasks=self._active_tasks)
             outputs = self.model(modified_inputs, training=False)
-            self.loss_layer((targets, outputs, masks), False)
+            if self.sort_pos:                                            # mfp.py:336-338
+                self.loss_layer((targets, outputs, masks), False, tasks == self.task_names.index("pos"))
+            else:
+                self.loss_layer((targets, outputs, masks), False)
             keys = loss_key_names(self._all_input_columns)
             m = self.loss_layer.metrics
             return torch.stack([torch.stack([m[k + "_loss"], m[k + "_score"], m[k + "_score"] * 0 + 1])

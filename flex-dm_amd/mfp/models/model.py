@@ -66,7 +66,8 @@ class Model:
         h, ctx = self.hidden(inputs, training)
         return self.decoder(h, ctx)
 
-    def forward_loss(self, inputs: Dict, loss_keys, training: bool = True, premasked=None, ctx=None):
+    def forward_loss(self, inputs: Dict, loss_keys, training: bool = True, premasked=None, ctx=None,
+                     loss_sort=None):
         """Train-step path: heads + LossLayer fused.  Returns (loss_total, sums, outputs).
         ``premasked`` = (idx_all, codes, xs) from the fused masking kernel replaces ``inputs``."""
         if premasked is not None:
@@ -75,6 +76,7 @@ class Model:
         else:
             h, ctx = self.hidden(inputs, training)
         B, S, D = h.shape
+        ctx.loss_sort = loss_sort
         loss, sums, logits = DecoderLossFn.apply(h.reshape(B * S, D), ctx, loss_keys)
         outputs = split_logits(logits, self.layout, self.input_columns, B, S)
         outputs["_flat_logits"] = logits

@@ -184,6 +184,28 @@ int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, const mfp_l
                      int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
                      int32_t dl_dtype, mfp_stream_t stream);
 
+/* RICO position-sorted loss (reference models/metrics.py:180-211, mfp.py:336-338): position t of
+ * the loss reads logits row pred_row[t] (and writes that row of dlogits) and target / condition
+ * row true_row[t]; the mfp mask and nvalid stay positional (metrics.py:251,263).  Either map may be
+ * NULL (identity).  Each map must be a permutation of [0, T) so that every dlogits row is written. */
+int mfp_loss_fwd_bwd_sorted(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys /*host*/,
+                            int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
+                            int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row,
+                            mfp_stream_t stream);
+
+/* sort_inputs (reference models/tensor_utils.py:14-44) as a row map.  Per document b with flag[b]:
+ *   priority(s) = sum_k v_k(s) * 100^(4-k) + [s >= nvalid[b]] * 100^5   (k over type, left, top,
+ *   width, height), ascending stable order; row_map[b*S + r] = b*S + (position holding rank r).
+ * Documents with flag[b] == 0 get the identity.  Two sources for v_k:
+ *   labels mode (logits == NULL): labels[k] (host array of 5 device pointers) int32, element
+ *     (b*S+s)*label_stride[k];
+ *   logits mode (from_logits=True, :26-27): first-index argmax of logits[(b*S+s)*ld + col_off[k]
+ *     .. + n_class[k]) (n_class < 100, :21). */
+int mfp_sort_positions(const int32_t* const* labels /*host[5]*/, const int32_t* label_stride /*host[5]*/,
+                       const float* logits, int32_t ld, const int32_t* col_off /*host[5]*/,
+                       const int32_t* n_class /*host[5]*/, const int32_t* nvalid, const uint8_t* flag,
+                       int32_t* row_map, int32_t B, int32_t S, mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- optimizer
  * Keras Adam + per-variable clipnorm + L2 regularisers (train.py:71-77; utils.py:8-22), fused
  * over flat f32 buffers w,g,m,v that hold nseg variables back to back.  The buffers are cut

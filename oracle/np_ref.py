@@ -260,11 +260,86 @@ def continuous_metric(y_true, y_pred):
     return loss, score
 
 
-def loss_layer(input_columns, y_true, y_pred, mfp_masks, maxlen=None):
-    """LossLayer.call, models/metrics.py:213-299 (non-sort path, predict_context=False).
+SORT_KEYS = ["type", "left", "top", "width", "height"]   # models/tensor_utils.py:11
+
+
+def sort_inputs(inputs, input_columns, from_logits=False, maxlen=None):
+    """sort_inputs, models/tensor_utils.py:14-44: reorder every sequence tensor of ``inputs`` by
+    the lexicographic key (type, left, top, width, height), padding positions last.
+
+    [TF-EXT] ``tf.argsort`` (ascending, stable=False) is ``top_k`` of the negated values, which
+    lists equal values lowest index first, i.e. the order of a stable sort; ``tf.argmax``
+    returns the first maximal index.
+    """
+    CONST = 100                                                                    # :15
+    data = {}
+    for key, col in input_columns.items():                                         # :24-28
+        if key not in inputs:
+            continue
+        v = np.asarray(inputs[key])
+        if col["is_sequence"] and col["type"] == "categorical":
+            if from_logits:
+                v = v.argmax(axis=-1)
+            v = v.astype(np.int64)
+        data[key] = v
+    for key in SORT_KEYS:
+        assert input_columns[key]["input_dim"] < CONST                             # :21
+    S = data[SORT_KEYS[0]].shape[1]
+    invalid = ~get_seq_mask(inputs["length"], maxlen or S)                         # :30
+    priority = np.zeros(data[SORT_KEYS[0]].shape[:2], np.int64)
+    for key in SORT_KEYS:                                                          # :32-33
+        priority = priority * CONST + data[key][..., 0]
+    priority = priority + invalid.astype(np.int64) * CONST ** len(SORT_KEYS)       # :34
+    indices = np.argsort(priority, axis=-1, kind="stable")                         # :35
+    out = {}
+    for key, val in inputs.items():                                                # :37-43
+        val = np.asarray(val)
+        if key in input_columns and input_columns[key]["is_sequence"]:
+            idx = indices.reshape(indices.shape + (1,) * (val.ndim - 2))
+            out[key] = np.take_along_axis(val, idx, axis=1)
+        else:
+            out[key] = val
+    return out
+
+
+def sorted_loss_inputs(input_columns, y_true, y_pred, sort_flag, ignore_sort=None, maxlen=None):
+    """The ``sort_flag`` prologue of LossLayer.call, models/metrics.py:180-211: documents whose
+    flag is set have targets and predictions re-ordered independently (targets by their labels,
+    predictions by their own argmax), the others are left as they are.  ``mfp_masks`` are NOT
+    re-ordered (:251 uses them as they came in)."""
+    assert ignore_sort in ("gt", "pred", None)                                     # :181
+    cols = valid_columns(input_columns)
+    t_sort = y_true if ignore_sort == "gt" else sort_inputs(y_true, cols, maxlen=maxlen)
+    y_pred = dict(y_pred)
+    y_pred["length"] = y_true["length"]                                            # :188
+    p_sort = y_pred if ignore_sort == "pred" else sort_inputs(y_pred, cols, from_logits=True, maxlen=maxlen)
+    flag = np.asarray(sort_flag).astype(bool)
+    yt, yp = {}, {}
+    for key in y_true.keys():                                                      # :196-211
+        col = input_columns[key]
+        if col.get("demo_only", False):
+            continue
+        if col["is_sequence"]:
+            f = flag[:, None, None]
+            yt[key] = np.where(f, np.asarray(t_sort[key]), np.asarray(y_true[key]))
+            if col["type"] == "categorical":
+                f = f[:, None]
+            yp[key] = np.where(f, np.asarray(p_sort[key]), np.asarray(y_pred[key]))
+        else:
+            yt[key] = y_true[key]
+            if key in y_pred:
+                yp[key] = y_pred[key]
+    return yt, yp
+
+
+def loss_layer(input_columns, y_true, y_pred, mfp_masks, maxlen=None, sort_flag=None, ignore_sort=None):
+    """LossLayer.call, models/metrics.py:172-299 (predict_context=False); ``sort_flag`` (B,) bool
+    selects the RICO position-sorted variant (:180-211).
 
     Returns ``(loss_total, losses{key}, scores{key_score_num/_den}, metrics{...})``.
     """
+    if sort_flag is not None:
+        y_true, y_pred = sorted_loss_inputs(input_columns, y_true, y_pred, sort_flag, ignore_sort, maxlen)
     seq_mask = get_seq_mask(y_true["length"], maxlen)
     losses, scores, metrics = {}, {}, {}
     score_total = 0.0

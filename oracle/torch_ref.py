@@ -167,8 +167,64 @@ def continuous_metric(y_true, y_pred):
     return loss, -0.5 * cos + 0.5
 
 
-def loss_layer(input_columns, y_true, y_pred, mfp_masks, maxlen=None):
-    """LossLayer.call, models/metrics.py:213-299 (non-sort path)."""
+SORT_KEYS = ["type", "left", "top", "width", "height"]   # models/tensor_utils.py:11
+
+
+def sort_indices(inputs, input_columns, from_logits=False, maxlen=None):
+    """The permutation of sort_inputs (models/tensor_utils.py:15-35), written rank-wise instead of
+    with an argsort: position i goes to slot #{j : p_j < p_i or (p_j == p_i and j < i)}."""
+    S = inputs[SORT_KEYS[0]].shape[1]
+    prio = torch.zeros(inputs[SORT_KEYS[0]].shape[:2], dtype=torch.int64)
+    for key in SORT_KEYS:
+        v = inputs[key]
+        v = v.argmax(dim=-1) if from_logits else v
+        prio = prio * 100 + v[..., 0].to(torch.int64)
+    prio = prio + (~get_seq_mask(inputs["length"], maxlen or S)).to(torch.int64) * 100 ** len(SORT_KEYS)
+    pos = torch.arange(S)
+    before = (prio[:, None, :] < prio[:, :, None]) | ((prio[:, None, :] == prio[:, :, None]) & (pos[None, None, :] < pos[None, :, None]))
+    rank = before.sum(dim=-1)                       # slot of position i
+    return torch.argsort(rank, dim=-1)              # position held by slot r (rank is a permutation)
+
+
+def sorted_loss_inputs(input_columns, y_true, y_pred, sort_flag, ignore_sort=None, maxlen=None):
+    """LossLayer.call's sort prologue, models/metrics.py:180-211 (differentiable in y_pred: the
+    gather passes gradients back to the rows it picked)."""
+    flag = torch.as_tensor(sort_flag).to(torch.bool)
+    S = y_true[SORT_KEYS[0]].shape[1]
+    ident = torch.arange(S)[None, :].expand(flag.shape[0], S)
+    it = ident if ignore_sort == "gt" else sort_indices(y_true, input_columns, False, maxlen)
+    yp_len = dict(y_pred)
+    yp_len["length"] = y_true["length"]
+    ip = ident if ignore_sort == "pred" else sort_indices({k: v.detach() if torch.is_tensor(v) else v for k, v in yp_len.items()},
+                                                          input_columns, True, maxlen)
+    it = torch.where(flag[:, None], it, ident)
+    ip = torch.where(flag[:, None], ip, ident)
+
+    def take(val, idx):
+        idx = idx.reshape(idx.shape + (1,) * (val.dim() - 2)).expand(-1, -1, *val.shape[2:])
+        return torch.gather(val, 1, idx)
+
+    yt, yp = {}, {}
+    for key, col in input_columns.items():
+        if col.get("demo_only", False):
+            continue
+        if col["is_sequence"]:
+            yt[key] = take(y_true[key], it)
+            yp[key] = take(y_pred[key][:, :S], ip)
+        else:
+            if key in y_true:
+                yt[key] = y_true[key]
+            if key in y_pred:
+                yp[key] = y_pred[key]
+    yt["length"] = y_true["length"]
+    return yt, yp
+
+
+def loss_layer(input_columns, y_true, y_pred, mfp_masks, maxlen=None, sort_flag=None, ignore_sort=None):
+    """LossLayer.call, models/metrics.py:172-299; ``sort_flag`` (B,) selects the RICO
+    position-sorted variant (:180-211)."""
+    if sort_flag is not None:
+        y_true, y_pred = sorted_loss_inputs(input_columns, y_true, y_pred, sort_flag, ignore_sort, maxlen)
     seq_mask = get_seq_mask(y_true["length"], maxlen)
     losses, scores, metrics = {}, {}, {}
     score_total = 0.0
@@ -292,13 +348,13 @@ class TrainState:
 
 
 def loss_and_grads(state: TrainState, input_columns, targets, modified_inputs, masks,
-                   num_blocks, rate=0.0, keep_masks=None, maxlen=None):
+                   num_blocks, rate=0.0, keep_masks=None, maxlen=None, sort_flag=None):
     """Keras Model.train_step with no compiled loss: total = sum(model.losses)
     = LossLayer add_loss (metrics.py:297) + every L2 regulariser (utils.py:8-22)."""
     for w in state.p.values():
         w.grad = None
     out = model_fwd(state.p, input_columns, modified_inputs, num_blocks, rate, keep_masks, maxlen)
-    loss_total, losses, scores, metrics = loss_layer(input_columns, targets, out, masks, maxlen)
+    loss_total, losses, scores, metrics = loss_layer(input_columns, targets, out, masks, maxlen, sort_flag=sort_flag)
     reg = l2_loss(state.p, state.l2)
     total = loss_total + reg
     total.backward()

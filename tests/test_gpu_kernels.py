@@ -392,6 +392,112 @@ def test_losses_vs_oracle(dl_dtype):
     assert (dl[:, col:] == 0).all()
 
 
+# ------------------------------------------------------------- RICO position-sorted loss
+def _flat_layout(ic, keys):
+    col, layout = 0, {}
+    for k in keys:
+        c = ic[k]
+        n = c["shape"][-1] * c["input_dim"] if c["type"] == "categorical" else c["shape"][-1]
+        layout[k] = (col, n)
+        col += (n + 7) // 8 * 8
+    return layout, col
+
+
+@pytest.mark.parametrize("dataset,B,S", [("rico", 6, 20), ("crello", 4, 33), ("rico", 3, 300)])
+def test_sort_positions_vs_oracle(dataset, B, S):
+    """mfp_sort_positions == argsort of tensor_utils.py:14-44, from labels and from logits, with
+    ties (stable), ragged lengths and unflagged documents (identity)."""
+    ops = _ops()
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    ic = make_input_columns(dataset)
+    batch = synthetic_batch(ic, B, S, seed=2, ragged=True)
+    for k in np_ref.SORT_KEYS:          # ties: positions 1 and 3 equal position 0 on every sort key
+        batch[k][:, 1] = batch[k][:, 0]
+        batch[k][:, min(3, S - 1)] = batch[k][:, 0]
+    keys = [k for k, c in ic.items() if c.get("is_sequence") and not c.get("demo_only")]
+    layout, U = _flat_layout(ic, keys)
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(B * S, U, generator=g)
+    logits[1] = logits[0]
+    logits[S + 2] = logits[S]
+    logits[5, layout["left"][0]:layout["left"][0] + 4] = logits[5, layout["left"][0]:layout["left"][0] + 64].max() + 1  # argmax tie -> first
+    flag = torch.ones(B, dtype=torch.bool)
+    flag[1] = False
+    nvalid = (batch["length"].reshape(-1) + 1).to(torch.int32)
+    ident = torch.arange(S)[None].expand(B, S)
+    want_t = torch.where(flag[:, None], torch_ref.sort_indices(batch, ic, False, S), ident)
+    pred = {k: logits[:, layout[k][0]:layout[k][0] + ic[k]["input_dim"]].reshape(B, S, 1, -1) for k in np_ref.SORT_KEYS}
+    pred["length"] = batch["length"]
+    want_p = torch.where(flag[:, None], torch_ref.sort_indices(pred, ic, True, S), ident)
+    # cross-check the rank formulation against the numpy argsort restatement
+    np_sorted = np_ref.sort_inputs({k: v.numpy() for k, v in batch.items()}, np_ref.valid_columns(ic), maxlen=S)
+    assert np.array_equal(np_sorted["left"], np.take_along_axis(batch["left"].numpy(),
+                                                                  torch_ref.sort_indices(batch, ic, False, S).numpy()[:, :, None], 1))
+    base = (torch.arange(B) * S)[:, None]
+    fl = flag.to(torch.uint8).to(DEV)
+    labels = [batch[k].to(torch.int32).to(DEV).contiguous() for k in np_ref.SORT_KEYS]
+    got_t = ops.sort_positions(nvalid.to(DEV), fl, B, S, labels=labels).cpu().view(B, S)
+    heads = [(layout[k][0], ic[k]["input_dim"]) for k in np_ref.SORT_KEYS]
+    got_p = ops.sort_positions(nvalid.to(DEV), fl, B, S, logits=logits.to(DEV), heads=heads).cpu().view(B, S)
+    assert torch.equal(got_t.long(), want_t + base)
+    assert torch.equal(got_p.long(), want_p + base)
+
+
+@pytest.mark.parametrize("dataset", ["rico", "crello"])
+@pytest.mark.parametrize("ignore", [None, "gt", "pred"])
+@pytest.mark.parametrize("dl_dtype", [torch.float32, torch.bfloat16])
+def test_sorted_losses_vs_oracle(dataset, ignore, dl_dtype):
+    """LossLayer with sort_flag (metrics.py:180-211): per-key sums and d(loss)/d(logits) -- the
+    gradient lands on the ORIGINAL logits rows -- against the torch restatement."""
+    ops = _ops()
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.hip.functions import loss_row_maps
+    from mfp.models.metrics import build_loss_keys, build_loss_sort
+    ic = make_input_columns(dataset)
+    B, S = 5, 16
+    batch = synthetic_batch(ic, B, S, seed=6, ragged=True)
+    keys = [k for k, c in ic.items() if c.get("is_sequence") and not c.get("demo_only")]
+    layout, U = _flat_layout(ic, keys)
+    g = torch.Generator().manual_seed(10)
+    logits = torch.randn(B * S, U, generator=g) * 3
+    pred, masks = {}, {}
+    for k in keys:
+        c = ic[k]
+        o, n = layout[k]
+        sl = logits[:, o:o + n].reshape(B, S, -1)
+        pred[k] = (sl.reshape(B, S, c["shape"][-1], c["input_dim"]) if c["type"] == "categorical" else sl
+                   ).double().requires_grad_(True)
+        masks[k] = torch.rand(B, S, generator=g) < 0.6
+    flag = torch.tensor([True, True, False, True, False])
+    y64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    loss_total, losses, scores, _ = torch_ref.loss_layer(ic, y64, pred, masks, S, sort_flag=flag, ignore_sort=ignore)
+    loss_total.backward()
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    yt = dev(batch)
+    descr = build_loss_keys(ic, layout, yt, dev(masks))
+    nvalid = (batch["length"].reshape(-1) + 1).to(torch.int32).to(DEV)
+    lg = logits.to(DEV)
+    sort = build_loss_sort(ic, layout, yt, flag.to(DEV), ignore)
+    pred_row, true_row = loss_row_maps(sort, lg, nvalid, B, S)
+    assert (pred_row is None) == (ignore == "pred") and (true_row is None) == (ignore == "gt")
+    sums, dl = ops.loss_fwd_bwd(lg, descr, nvalid, B, S, dl_dtype, pred_row=pred_row, true_row=true_row)
+    sums = sums.cpu().double()
+    plain = ops.loss_fwd_bwd(lg, descr, nvalid, B, S, None)[0].cpu().double()
+    assert not torch.allclose(plain[:, 0], sums[:, 0])      # the sort does change the loss
+    for i, k in enumerate(keys):
+        assert abs(sums[i, 0].item() - float(losses[k])) < 1e-4 * max(1.0, abs(float(losses[k]))), k
+        assert abs(sums[i, 1].item() - float(scores[k + "_score_num"])) < 1e-4, k
+        assert abs(sums[i, 2].item() - float(scores[k + "_score_den"])) < 1e-6, k
+        o, n = layout[k]
+        want = pred[k].grad.reshape(B * S, n)
+        if dl_dtype == torch.float32:
+            assert_close(dl[:, o:o + n], want, 1e-6, 1e-4, "dlogits " + k)
+        else:
+            assert_close(dl[:, o:o + n], want, 1e-4, 1e-2, "dlogits bf16 " + k)
+
+
 # ------------------------------------------------------------------------------- optimizer
 def test_adam_keras_vs_oracle():
     ops = _ops()

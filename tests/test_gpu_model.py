@@ -163,6 +163,76 @@ def test_dropout_training_runs_and_is_seeded():
     assert abs(float(loss0) - outs[0][0]) > 1e-6
 
 
+def test_position_sorted_loss_parity_fp32_rico():
+    """RICO "pos" task (mfp.py:336-338): the documents flagged for it are scored order-free
+    (metrics.py:180-211).  Whole model fwd + bwd vs the oracle, with the flag on most documents."""
+    from mfp.models.metrics import build_loss_keys, build_loss_sort
+    B, S, D, L = 8, 32, 128, 2
+    ic, params, batch, modified, masks, np_ref, torch_ref, keys = _setup("rico", B, S, D, L, seed=2)
+    flag = torch.tensor([True, True, False, True, True, False, True, True])
+    state = torch_ref.TrainState(params, l2=None, clipnorm=1.0, lr=1e-2, dtype=torch.float64)
+    cast = lambda d: {k: (v.to(torch.float64) if v.is_floating_point() else v) for k, v in d.items()}
+    info, grads = torch_ref.loss_and_grads(state, ic, cast(batch), cast(modified), masks, L, maxlen=S, sort_flag=flag)
+    plain, _ = torch_ref.loss_and_grads(state, ic, cast(batch), cast(modified), masks, L, maxlen=S)
+    assert abs(float(plain["data_loss"]) - float(info["data_loss"])) > 1e-3     # the sort matters here
+    model = _model(ic, params, D, L, "fp32")
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    yt = dev(batch)
+    lkeys = build_loss_keys(ic, model.layout.head_cols, yt, dev(masks))
+    sort = build_loss_sort(ic, model.layout.head_cols, yt, flag.to(DEV))
+    loss, sums, outputs = model.forward_loss(dev(modified), lkeys, training=True, loss_sort=sort)
+    loss.backward()
+    torch.cuda.synchronize()
+    sums = sums.cpu().double()
+    for i, k in enumerate(keys):
+        want = float(info["losses"][k])
+        assert abs(sums[i, 0].item() - want) <= 1e-4 * max(1.0, abs(want)), (k, sums[i, 0].item(), want)
+        assert abs(sums[i, 1].item() - float(info["scores"][k + "_score_num"])) < 1e-3, k
+        assert abs(sums[i, 2].item() - float(info["scores"][k + "_score_den"])) < 1e-6, k
+    gd = model.store.grads_state_dict()
+    gmax = max(w.abs().max().item() for w in grads.values())
+    for name, want in grads.items():
+        err = (gd[name].double() - want).abs().max().item()
+        assert err <= 2e-4 * want.abs().max().item() + 5e-5 * gmax, (name, err)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_mfp_rico_pos_task_trains(dtype):
+    """RICO with the pos task active: eager steps, graph replay and the Keras-style test step all go
+    through the sorted loss, and LossLayer called directly with a sort flag matches the oracle."""
+    from oracle import torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("rico")
+    B, S = 16, 24
+    batch = synthetic_batch(ic, B, S, seed=0, ragged=True, device=DEV)
+    model = MFP(ic, num_blocks=2, latent_dim=128, dropout=0.1, l2=1e-2, masking_method="elem_pos_attr",
+                dtype=dtype, device=DEV)
+    assert model.sort_pos
+    model.compile(learning_rate=1e-3)
+    first = float(model.train_step(batch)[:, 0].sum())
+    model.capture_train_step(batch, warmup=1)
+    for _ in range(60):
+        sums = model.train_step(batch)
+    torch.cuda.synchronize()
+    last = float(sums[:, 0].sum())
+    assert np.isfinite(first) and np.isfinite(last) and last < first, (first, last)
+    ev = model.test_step(batch)
+    assert torch.isfinite(ev).all()
+    # LossLayer API with an explicit flag (metrics.py:172-178)
+    out = model(batch, training=False)
+    cpu = lambda d: {k: v.detach().cpu() for k, v in d.items() if torch.is_tensor(v)}
+    g = torch.Generator().manual_seed(0)
+    masks = {k: (torch.rand(B, S, generator=g) < 0.5) for k in model.loss_layer._head_cols}
+    flag = torch.rand(B, generator=g) < 0.5
+    logits = {k: out[k] for k in model.loss_layer._head_cols}
+    scores = model.loss_layer((batch, dict(logits), {k: v.to(DEV) for k, v in masks.items()}), False, flag.to(DEV))[0]
+    want = torch_ref.loss_layer(ic, cpu(batch), {k: v.double() for k, v in cpu(logits).items()}, masks, S, sort_flag=flag)
+    for k in model.loss_layer._head_cols:
+        assert abs(float(scores[k + "_score_num"]) - float(want[2][k + "_score_num"])) < 1e-3, k
+        assert abs(float(model.loss_layer.metrics[k + "_loss"]) - float(want[1][k])) <= 1e-4 * max(1.0, float(want[1][k])), k
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_mfp_train_step_eager_and_graph(dtype):
     from mfp.data.spec import make_input_columns, synthetic_batch

@@ -202,3 +202,75 @@ def test_golden_fixtures(name):
     torch_ref.apply_gradients(state, grads)
     for k in params:
         np.testing.assert_allclose(state.p[k].detach().numpy(), z["adam1:" + k], rtol=2e-6, atol=1e-8)
+
+
+# ------------------------------------------------------------------ RICO position-sorted loss
+def test_sort_inputs_known_answer():
+    """tensor_utils.py:14-44 on a hand-made document: key order (type, left, top, width, height),
+    ties keep their order, padding positions go last."""
+    ic = _ic("rico")
+    S = 6
+    col = lambda *v: np.array(v, np.int64).reshape(1, S, 1)
+    inputs = {"length": np.array([[3]]),            # 4 valid positions
+              "type": col(2, 1, 2, 1, 0, 0), "left": col(5, 9, 5, 9, 0, 0), "top": col(1, 0, 0, 0, 0, 0),
+              "width": col(0, 3, 7, 3, 0, 0), "height": col(0, 0, 0, 0, 0, 0)}
+    inputs["clickable"] = col(10, 11, 12, 13, 14, 15)
+    out = np_ref.sort_inputs(inputs, {k: ic[k] for k in inputs if k != "length"} | {"length": ic["length"]})
+    # priorities: p0 = (2,5,1,0,0) p1 = (1,9,0,3,0) p2 = (2,5,0,7,0) p3 = p1 -> order 1,3,2,0 then padding 4,5
+    assert out["clickable"].reshape(-1).tolist() == [11, 13, 12, 10, 14, 15]
+    assert out["type"].reshape(-1).tolist() == [1, 1, 2, 2, 0, 0]
+    t = {k: torch.as_tensor(v) for k, v in inputs.items()}
+    assert torch_ref.sort_indices(t, ic).reshape(-1).tolist() == [1, 3, 2, 0, 4, 5]
+
+
+def test_sorted_loss_restatements_agree_and_are_order_free():
+    ic = _ic("rico")
+    B, S, D, L = 4, 9, 16, 1
+    params = np_ref.init_params(ic, D, L, seed=-7)
+    batch = _batch(ic, B, S, seed=3)
+    nb = {k: v.numpy() for k, v in batch.items()}
+    out = np_ref.model_fwd(params, ic, nb, L, maxlen=S)
+    out_t = {k: torch.as_tensor(v) for k, v in out.items()}
+    g = torch.Generator().manual_seed(0)
+    masks = {k: torch.rand(B, S, generator=g) < 0.6 for k in out}
+    nm = {k: v.numpy() for k, v in masks.items()}
+    flag = np.array([True, False, True, True])
+    for ignore in (None, "gt", "pred"):
+        lt, losses, scores, _ = np_ref.loss_layer(ic, nb, out, nm, S, sort_flag=flag, ignore_sort=ignore)
+        lt2, losses2, scores2, _ = torch_ref.loss_layer(ic, batch, out_t, masks, S, sort_flag=torch.as_tensor(flag),
+                                                        ignore_sort=ignore)
+        assert abs(lt - float(lt2)) < 1e-9 * abs(lt)
+        for k in losses:
+            assert abs(losses[k] - float(losses2[k])) < 1e-9 * max(1.0, abs(losses[k]))
+            assert abs(scores[k + "_score_num"] - float(scores2[k + "_score_num"])) < 1e-9
+    # no flag set == the plain loss
+    lt0 = np_ref.loss_layer(ic, nb, out, nm, S)[0]
+    assert np_ref.loss_layer(ic, nb, out, nm, S, sort_flag=np.zeros(B, bool))[0] == lt0
+    # order-free: predictions that are a within-document shuffle of the (one-hot) targets score
+    # perfectly under the sorted loss, and badly under the positional one
+    rng = np.random.default_rng(0)
+    seqkeys = [k for k, c in ic.items() if c.get("is_sequence") and not c.get("demo_only")]
+    perm = np.stack([np.concatenate([rng.permutation(int(n) + 1), np.arange(int(n) + 1, S)])
+                     for n in nb["length"].reshape(-1)])
+    pred = {}
+    for k in seqkeys:
+        y = np.take_along_axis(nb[k], perm[:, :, None], axis=1)
+        pred[k] = 30.0 * np.eye(ic[k]["input_dim"])[y]            # (B, S, N, C) confident logits
+    full = {k: np.ones((B, S), bool) for k in seqkeys}
+    _, _, sc_sorted, _ = np_ref.loss_layer(ic, nb, pred, full, S, sort_flag=np.ones(B, bool))
+    _, _, sc_plain, _ = np_ref.loss_layer(ic, nb, pred, full, S)
+    # elements that tie on the five sort keys may still swap their other attributes
+    for k in ["type", "left", "top", "width", "height"]:
+        assert sc_sorted[k + "_score_num"] == sc_sorted[k + "_score_den"]
+    assert sc_plain["left_score_num"] < sc_plain["left_score_den"]
+
+
+def test_host_sort_inputs_matches_oracle():
+    from mfp.models.tensor_utils import sort_inputs
+    ic = _ic("rico")
+    batch = _batch(ic, 5, 8, seed=11)
+    cols = np_ref.valid_columns(ic)
+    want = np_ref.sort_inputs({k: v.numpy() for k, v in batch.items()}, cols, maxlen=8)
+    got = sort_inputs(batch, cols)
+    for k, v in want.items():
+        np.testing.assert_array_equal(got[k].numpy(), v)
