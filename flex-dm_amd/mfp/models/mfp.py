@@ -467,12 +467,20 @@ class MFP:
         if dp.rank() == 0:
             save_file(dict(self.model.store.state_dict()), path + ".safetensors")
 
-    def load_weights(self, path: str):
+    def load_weights(self, path: str, name_map: Optional[Dict[str, str]] = None):
+        """``model.load_weights(path)`` (train.py:67-69, eval.py:169-172): ``path`` is either a
+        checkpoint written by :meth:`save_weights` (``<path>.safetensors``) or the prefix of a
+        TensorFlow checkpoint of the reference (``<path>.index`` + ``<path>.data-*``), read
+        without TensorFlow by ``mfp.data.tf_checkpoint``."""
+        if os.path.exists(path + ".index"):
+            from mfp.data.tf_checkpoint import read_state_dict
+            expected = {k: tuple(v.shape) for k, v in self.model.store.state_dict().items()}
+            self.model.store.load_state_dict(read_state_dict(path, expected, name_map))
+            return self
         from safetensors.torch import load_file
         p = path if path.endswith(".safetensors") else path + ".safetensors"
         if not os.path.exists(p):
-            raise FileNotFoundError(
-                "%s not found (TF-checkpoint import is a 'next' row, SURVEY.md §8f-2)" % p)
+            raise FileNotFoundError("neither %s nor %s.index exists" % (p, path))
         self.model.store.load_state_dict(load_file(p))
         return self
 

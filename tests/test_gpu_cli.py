@@ -58,3 +58,39 @@ def test_train_cli_on_tfrecord_directory(tmp_path, capsys):
     out = capsys.readouterr().out
     assert "total_score" in out
     assert os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))
+
+
+def test_weights_from_tensorflow_checkpoint(tmp_path, capsys):
+    """--weights / load_weights on a TensorFlow checkpoint prefix (train.py:67-69): the bundle is
+    read without TensorFlow and every variable lands where the Keras object graph says."""
+    import numpy as np
+    import torch
+    from mfp.data import tf_checkpoint as tfc
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.main import main
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("rico")
+    src = MFP(ic, num_blocks=2, latent_dim=128, dtype="fp32", device="cuda:0", seed=5)
+    state = src.model.store.state_dict()
+    prefix = str(tmp_path / "pretrained" / "best.ckpt")
+    tfc.write_bundle(prefix, {tfc.checkpoint_key(k): v.numpy() for k, v in state.items()}, snappy=True)
+    dst = MFP(ic, num_blocks=2, latent_dim=128, dtype="bf16", device="cuda:0", seed=6)
+    assert not torch.equal(dst.model.store.state_dict()["decoder/decoder_type/kernel"], state["decoder/decoder_type/kernel"])
+    dst.load_weights(prefix)
+    for k, v in dst.model.store.state_dict().items():
+        assert torch.equal(v, state[k]), k
+    # same predictions from both models (the bf16 shadow weights were refreshed by the load)
+    batch = synthetic_batch(ic, 4, 16, seed=1, ragged=True, device="cuda:0")
+    dst32 = MFP(ic, num_blocks=2, latent_dim=128, dtype="fp32", device="cuda:0", seed=7).load_weights(prefix)
+    a = src.model(batch, training=False)
+    b = dst32.model(batch, training=False)
+    for k in ("type", "left", "icon"):
+        assert torch.equal(a[k], b[k]), k
+    wrong = MFP(ic, num_blocks=1, latent_dim=128, dtype="fp32", device="cuda:0")
+    with pytest.raises(ValueError, match="unmatched"):
+        wrong.load_weights(prefix)
+    job = str(tmp_path / "job4")
+    main(["--dataset_name", "rico", "--data_dir", "synthetic:16:16", "--job-dir", job, "--latent_dim", "128",
+          "--num_blocks", "2", "--batch_size", "8", "--num_epochs", "1", "--validation_freq", "1",
+          "--masking_method", "random", "--dtype", "fp32", "--verbose", "0", "--weights", prefix])
+    assert "total_score" in capsys.readouterr().out
