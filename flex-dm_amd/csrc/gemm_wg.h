@@ -15,7 +15,13 @@
 // Grid: 1-D over (k-chunk, tile) with all tiles of a chunk on one XCD (see gemm.hip).
 #pragma once
 
-template <int XD>
+constexpr int WG_MAX_KCHUNK = 4096;   // tokens per split-K chunk a ROWSKIP_A launch may have (row codes in LDS)
+
+// ROWSKIP: rows of A whose row code is non-zero count as zero rows (MFP_GEMM_ROWSKIP_A).  The codes of
+// the workgroup's whole k-chunk are staged in LDS up front: a per-tile global byte load would sit in
+// front of the operand loads it gates, and since vmcnt retires in order every step would then wait
+// for ALL tiles in flight (measured: 1.6 us per k-tile instead of 0.4).
+template <int XD, bool ROWSKIP>
 __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 128, BK = 64, PAD = 8, LDS_S = BM + PAD;   // bf16 elements per LDS row
   constexpr int TILE_E = BK * LDS_S;                                       // elements per operand tile
@@ -26,9 +32,23 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
   static_assert(BM * CS_LD * 4 <= 2 * STAGE_B, "output stage aliases the two operand stages");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ float colsum_s[16][BM];   // memory waves: per row-group column sums of A
+  __shared__ unsigned char rc_s[ROWSKIP ? WG_MAX_KCHUNK : 16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
+#ifdef MFP_GEMM_TRACE
+  int trace_i = 0;
+#define WG_STAMP() do { if (tid == 0 && trace_i < 24) p.trace[(long long)blockIdx.x * 24 + trace_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WG_STAMP() do {} while (0)
+#endif
+#ifdef MFP_GEMM_TRACE
+  int mtrace_i = 0;   // memory wave 0: phases of k-tiles 4..7 (s_memtime, core clocks)
+#define WG_MSTAMP(t) do { if (tid == 256 && (t) >= 4 && (t) < 8 && mtrace_i < 24) p.trace[(long long)(gridDim.x + blockIdx.x) * 24 + mtrace_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_MSTAMP(t) do {} while (0)
+#endif
+  WG_STAMP();
   const int tiles = p.tiles_m * p.tiles_n, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int kz = (j / tiles) * 8 + xcd, bid = j % tiles;          // splitk % 8 == 0 (host)
   const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
@@ -37,6 +57,10 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   const bool do_colsum = (p.flags & MFP_GEMM_COLSUM_A) && tn == 0;
   f32x4 acc[4][4];
+  if (ROWSKIP) {
+    for (int i = tid; i < p.kchunk; i += 512) rc_s[i] = kbeg + i < p.K ? p.rowcode[kbeg + i] : 0;
+    __syncthreads();
+  }
 
   if (wave < 4) {
     // ======================================================================== MATH waves
@@ -46,6 +70,7 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();   // prologue barrier (stage 0 filled)
+    WG_STAMP();
     for (int t = 0; t < nk; ++t) {
       const unsigned short* As = reinterpret_cast<const unsigned short*>(smem_raw + (t & 1) * STAGE_B);
       const unsigned short* Bs = As + TILE_E;
@@ -74,6 +99,7 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
       }
       __syncthreads();
+      if ((t & 3) == 3) WG_STAMP();
     }
     // ---- partial tile -> LDS (rows m, 16 contiguous columns per lane), stored by all waves below
     float* Cs = reinterpret_cast<float*>(smem_raw);
@@ -95,9 +121,6 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
     const unsigned int voa0 = (unsigned int)((krow0 * p.lda + m0 + ccol) * 2);
     const unsigned int vob0 = (unsigned int)((krow0 * p.ldb + n0 + ccol) * 2);
     const int ls0 = (krow0 * LDS_S + ccol) * 2;
-    const bool rowskip_a = (p.flags & MFP_GEMM_ROWSKIP_A) != 0;
-    const unsigned char* rcp = rowskip_a ? p.rowcode : reinterpret_cast<const unsigned char*>(p.A);
-    const unsigned int rsmask = rowskip_a ? 0xFFu : 0u;
     u32x4 ra[XD][CH], rb[XD][CH];
     float csum[8];
 #pragma unroll
@@ -110,7 +133,7 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
       for (int c = 0; c < CH; ++c) {
         const int k = k0 + krow0 + 16 * c;
         const unsigned int kbad = ~(unsigned int)(live & ((k - kend) >> 31));
-        const unsigned int skip = (rcp[min(max(k, 0), p.K - 1)] & rsmask) ? 0xFFFFFFFFu : 0u;
+        const unsigned int skip = (ROWSKIP && rc_s[min(k - kbeg, p.kchunk - 1)]) ? 0xFFFFFFFFu : 0u;
         ra[set][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
             rsa, (voa0 + (unsigned int)(16 * c * p.lda * 2)) | abad | kbad | skip, soa, 0));
         rb[set][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -141,9 +164,13 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
     // step t: tile t+1 registers -> LDS stage (t+1)&1, tile t+1+XD global -> registers
     auto step = [&](auto tc, int t) {
       constexpr int xi = (decltype(tc)::value + 1) % XD;
+      WG_MSTAMP(t);
       lstore(xi, (t + 1) & 1);
+      WG_MSTAMP(t);
       gload(xi, t + 1 + XD);
+      WG_MSTAMP(t);
       __syncthreads();
+      WG_MSTAMP(t);
     };
     static_assert(XD == 4, "step loop unrolled by XD");
     int t = 0;
@@ -161,7 +188,9 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
       for (int e = 0; e < 8; ++e) colsum_s[krow0][ccol + e] = csum[e];
     }
   }
+  WG_STAMP();
   __syncthreads();   // partial tile (and column sums) are in LDS
+  WG_STAMP();
   // ---- all 8 waves: partial tile -> ws[kz][M][N] as whole rows (128 f32 = 32 lanes x 16 B)
   {
     const float* Cs = reinterpret_cast<const float*>(smem_raw);
@@ -181,18 +210,24 @@ __global__ __launch_bounds__(512) void gemm_wg_kernel(GemmParams p) {
       p.ws_col[(long long)kz * p.M + m0 + tid] = s;
     }
   }
+#ifdef MFP_GEMM_TRACE
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+  WG_STAMP();
 }
 
 inline bool wg_eligible(const mfp_gemm_args* a, int splitk) {
+  if ((a->flags & MFP_GEMM_ROWSKIP_A) && (a->K + splitk - 1) / splitk > WG_MAX_KCHUNK) return false;
   return !a->a_kmajor && !a->b_kmajor && a->in_dtype == MFP_BF16 && splitk >= 8 && splitk % 8 == 0 &&
          a->M % 8 == 0 && a->N % 8 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0;
 }
 
-inline int launch_wg(const GemmParams& p0, int M, int N, int splitk, hipStream_t st) {
+template <bool ROWSKIP>
+inline int launch_wg_t(const GemmParams& p0, int M, int N, int splitk, hipStream_t st) {
   constexpr int lds = 2 * (2 * 64 * 136 * 2);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wg_kernel<4>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wg_kernel<4, ROWSKIP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_gemm: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
@@ -204,6 +239,10 @@ inline int launch_wg(const GemmParams& p0, int M, int N, int splitk, hipStream_t
   p.tiles_m = (M + 127) / 128;
   p.tiles_n = (N + 127) / 128;
   p.kz_xcd = 1;
-  hipLaunchKernelGGL(gemm_wg_kernel<4>, dim3(p.tiles_m * p.tiles_n * splitk), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((gemm_wg_kernel<4, ROWSKIP>), dim3(p.tiles_m * p.tiles_n * splitk), dim3(512), lds, st, p);
   return MFP_OK;
+}
+
+inline int launch_wg(const GemmParams& p0, int M, int N, int splitk, hipStream_t st) {
+  return (p0.flags & MFP_GEMM_ROWSKIP_A) ? launch_wg_t<true>(p0, M, N, splitk, st) : launch_wg_t<false>(p0, M, N, splitk, st);
 }

@@ -87,8 +87,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
   constexpr int WROWS = BN / 2, WCH = WROWS * CPR / 512;
   static_assert((WROWS * CPR) % 512 == 0 && WROWS * ROWB <= 2 * XSTAGE + 2 * OSTAGE, "weight staging image");
   // row -> li of the lane that reads it (its swizzle key): row = colq(b, q) + e with li = 4q + e
-  auto w_stage = [&](int r) {
-    u32x4 v[WCH];
+  // Both staging rounds' global loads are issued up front (second round trip hidden behind the
+  // first round's LDS write / fragment reads); registers are free here: fragments are not live yet.
+  auto w_load = [&](int r, u32x4 (&v)[WCH]) {
 #pragma unroll
     for (int c = 0; c < WCH; ++c) {
       const int ch = tid + c * 512, row = ch / CPR, pc = ch % CPR, rl = row % WBN;
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
       const unsigned int vo = n < p.N ? (unsigned int)((n * p.ldb + (pc ^ key) * 8) * 2) : OOB;
       v[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, 0, 0));
     }
+  };
+  auto w_store = [&](const u32x4 (&v)[WCH]) {
 #pragma unroll
     for (int c = 0; c < WCH; ++c) {
       const int ch = tid + c * 512;
@@ -113,9 +116,14 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     // weight row feeding MFMA row i = 4q + e of quad b is column colq(b, q) + e (transposed MFMA:
     // the output lane (li, lg) then holds C[row li][colq(b, lg) + 0..3]).
     bf16x8 wf[NQ][KS];
+    u32x4 wv[2][WCH];
+    w_load(0, wv[0]);
+    w_load(1, wv[1]);
+    WS_STAMP();
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      w_stage(r);
+      w_store(wv[r]);
+      WS_STAMP();
       __syncthreads();
       if ((wave >> 1) == r) {
 #pragma unroll
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
         }
       }
       __syncthreads();
+      WS_STAMP();
     }
     f32x4 bias4[NQ];
 #pragma unroll
@@ -295,14 +304,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
       rcbits[set] = bits;
     };
 
-    // ---- prologue
+    // ---- prologue: the weight image is what the first MFMA waits for, so it goes ahead of the X tiles
+    {
+      u32x4 wv[2][WCH];
+      w_load(0, wv[0]);
+      w_load(1, wv[1]);
 #pragma unroll
-    for (int i = 0; i < XD; ++i) gload(xa[i], i);
+      for (int i = 0; i < XD; ++i) gload(xa[i], i);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {       // weight staging rounds (barriers mirror the math waves)
-      w_stage(r);
-      __syncthreads();
-      __syncthreads();
+      for (int r = 0; r < 2; ++r) {       // weight staging rounds (barriers mirror the math waves)
+        w_store(wv[r]);
+        __syncthreads();
+        __syncthreads();
+      }
     }
     if (EPI != WS_EPI_PLAIN) xload(0, 0);
     lstore(xa[0], 0);

@@ -7,6 +7,7 @@ library and never computes anything itself.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -160,12 +161,15 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
     return out
 
 
+_WG_TARGET = int(os.environ.get("MFP_WG_TARGET", "256"))   # workgroups a wgrad launch aims for
+
+
 def wgrad_splitk(T: int, M: int, N: int) -> int:
     """Split the token contraction so that the 128x128 output tiles x splits give about one
     persistent workgroup per CU (the streaming wgrad kernel keeps 8 waves and ~80 KB of LDS per
     workgroup: one per CU), in multiples of 8 (a k-chunk's tiles then share an XCD)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    sk = max(1, 256 // max(tiles, 1))
+    sk = max(1, _WG_TARGET // max(tiles, 1))
     if sk >= 8:
         sk = sk // 8 * 8
     while sk > 1 and T // sk < 256:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_gemm.sh <outdir>   (separate --pmc passes, kernel-trace only: gpurun rule)
+# usage: PROF_SCRIPT=x.py KFILTER=name tools/pmc_kernel.sh <outdir>   (separate --pmc passes, kernel-trace only: gpurun rule)
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $OUT
 i=0
@@ -7,7 +7,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/tools/prof_one_attn.py > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/tools/${PROF_SCRIPT:-prof_one_wg.py} > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
