@@ -87,29 +87,58 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 #pragma unroll
   for (int j = 0; j < NVEC * 4; ++j) { dg[j] = 0.f; db[j] = 0.f; dc[j] = 0.f; }
   const int row0 = blockIdx.x * LN_BWD_ROWS;
-  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
-    const int row = row0 + rr;
-    if (row >= T) break;
-    const float mu = mean[row], rs = rstd[row];
-    const unsigned int rowh = drop_row(dkey, (unsigned int)row);
+  // A wave walks its rows with the NEXT row's operands already in flight: a row is a chain
+  // load -> two wave reductions -> store, and a wave that waits out a full memory round trip per row
+  // leaves the kernel latency-bound (measured 3.3 TB/s in the step).
+  struct RowIn {
+    float4 xv[NVEC], rv[NVEC];
+    float4 dvf[NVEC];    // f32 dy ...
+    u32x2 dvh[NVEC];     // ... or four packed bf16 (only the member matching TDY is ever touched; a single
+                         // punned member was miscompiled by hipcc 7.2: upper half treated as dead)
+    float mu, rs;
+  };
+  auto load_row = [&](int row, RowIn& in) {
     const float* xr = x + (long long)row * D;
     const TDY* dyr = dy + (long long)row * D;
+    const float* drr = dres ? dres + (long long)row * D : nullptr;
+    in.mu = mean[row];
+    in.rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c >= D) continue;
+      in.xv[i] = *reinterpret_cast<const float4*>(xr + c);
+      if constexpr (sizeof(TDY) == 4) {
+        in.dvf[i] = *reinterpret_cast<const float4*>(dyr + c);
+      } else {
+        in.dvh[i] = *reinterpret_cast<const u32x2*>(dyr + c);
+      }
+      if (drr) in.rv[i] = *reinterpret_cast<const float4*>(drr + c);
+    }
+  };
+  float4 gam[NVEC];
+#pragma unroll
+  for (int i = 0; i < NVEC; ++i) {
+    const int c = lane * 4 + i * 256;
+    gam[i] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto process = [&](const RowIn& cur, int row) {
+    const float mu = cur.mu, rs = cur.rs;
+    const unsigned int rowh = drop_row(dkey, (unsigned int)row);
     float xh[NVEC * 4], gy[NVEC * 4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int c = lane * 4 + i * 256, j = 4 * i;
       if (c >= D) { xh[j] = xh[j + 1] = xh[j + 2] = xh[j + 3] = 0.f; gy[j] = gy[j + 1] = gy[j + 2] = gy[j + 3] = 0.f; continue; }
-      float4 xv = *reinterpret_cast<const float4*>(xr + c);
-      float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 xv = cur.xv[i], g = gam[i];
       float d0, d1, d2, d3;
       if constexpr (sizeof(TDY) == 4) {
-        float4 t = *reinterpret_cast<const float4*>(dyr + c);
-        d0 = t.x; d1 = t.y; d2 = t.z; d3 = t.w;
+        d0 = cur.dvf[i].x; d1 = cur.dvf[i].y; d2 = cur.dvf[i].z; d3 = cur.dvf[i].w;
       } else {
-        u32x2 t = *reinterpret_cast<const u32x2*>(dyr + c);
-        d0 = bf16_to_f32((unsigned short)(t[0] & 0xffff)); d1 = bf16_to_f32((unsigned short)(t[0] >> 16));
-        d2 = bf16_to_f32((unsigned short)(t[1] & 0xffff)); d3 = bf16_to_f32((unsigned short)(t[1] >> 16));
+        const unsigned int t0 = cur.dvh[i][0], t1 = cur.dvh[i][1];
+        d0 = bf16_to_f32((unsigned short)(t0 & 0xffff)); d1 = bf16_to_f32((unsigned short)(t0 >> 16));
+        d2 = bf16_to_f32((unsigned short)(t1 & 0xffff)); d3 = bf16_to_f32((unsigned short)(t1 >> 16));
       }
       xh[j] = (xv.x - mu) * rs; xh[j + 1] = (xv.y - mu) * rs;
       xh[j + 2] = (xv.z - mu) * rs; xh[j + 3] = (xv.w - mu) * rs;
@@ -122,7 +151,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
     float* dxr = dx + (long long)row * D;
-    const float* drr = dres ? dres + (long long)row * D : nullptr;
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int c = lane * 4 + i * 256, j = 4 * i;
@@ -132,8 +160,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
       o.y = rs * (gy[j + 1] - s1 - xh[j + 1] * s2);
       o.z = rs * (gy[j + 2] - s1 - xh[j + 2] * s2);
       o.w = rs * (gy[j + 3] - s1 - xh[j + 3] * s2);
-      if (drr) {
-        float4 r = *reinterpret_cast<const float4*>(drr + c);
+      if (dres) {
+        const float4 r = cur.rv[i];
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
       *reinterpret_cast<float4*>(dxr + c) = o;
@@ -155,6 +183,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         }
         dc[j] += o.x; dc[j + 1] += o.y; dc[j + 2] += o.z; dc[j + 3] += o.w;
       }
+    }
+  };
+  // two named buffers, rows handled in pairs: no copies between the in-flight and the current row
+  RowIn bufA, bufB;
+  const int rlast = min(LN_BWD_ROWS, T - row0);     // rows of this workgroup
+  if (wave < rlast) load_row(row0 + wave, bufA);
+  for (int rr = wave; rr < rlast; rr += 8) {
+    const bool hasB = rr + 4 < rlast;
+    if (hasB) load_row(row0 + rr + 4, bufB);
+    process(bufA, row0 + rr);
+    if (hasB) {
+      if (rr + 8 < rlast) load_row(row0 + rr + 8, bufA);
+      process(bufB, row0 + rr + 4);
     }
   }
   // cross-wave reduction of the dgamma/dbeta(/colsum) partials
