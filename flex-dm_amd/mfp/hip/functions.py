@@ -112,8 +112,11 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
                      out=st.tables_padded(st.g), splitk=ops.wgrad_splitk(T, L.table_rows_pad, D))
         if onehot:   # stream 2: the one-hot operand was built there during the forward pass (in order)
             ctx.on_side(wgrad_tables, dh_c, idx_all, which=2)
-        for j, k in enumerate(L.num_keys):
+        n_num = len(L.num_keys)
+        for j, k in enumerate(L.num_keys[:-1]):
             ctx.on_side(lambda j=j, k=k: wgrad_dense(j, k), dh_c, xs[j], codes[j], which=j % 2)
+        if n_num:   # the main stream has nothing else left: the last product runs there, without a fork
+            wgrad_dense(n_num - 1, L.num_keys[-1])
     if not onehot:
         ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
     ctx.join_side()   # last node of the backward pass: every weight gradient is complete after this
