@@ -160,9 +160,24 @@ def main():
     model.compile(learning_rate=1e-4, clipnorm=1.0)
     dp.broadcast_parameters(model.model.store.w)
     model.model.store.refresh_shadow()
-    if not args.no_graph:
-        model.capture_train_step(batch, warmup=2)
-        batch = model.static_batch   # the graph's input buffers: inputs are already resident there
+    graphed = not args.no_graph
+    if graphed:
+        try:
+            model.capture_train_step(batch, warmup=2)
+            batch = model.static_batch   # the graph's input buffers: inputs are already resident there
+        except RuntimeError as e:   # a failed capture must not cost the whole run: step eagerly, say so
+            if world == 1:
+                raise
+            print("bench.py: hipGraph capture failed on rank %d (%s); stepping eagerly" % (rank, e), file=sys.stderr)
+            graphed = False
+            model._graph = None
+            torch.cuda.synchronize()
+        if world > 1:   # every rank must step the same way (the graphed path all-reduces in two buckets)
+            flag = torch.tensor([1 if graphed else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not bool(flag.item()) and graphed:
+                graphed = False
+                model._graph = None
 
     def barrier():
         if world > 1:
@@ -206,7 +221,7 @@ def main():
                                % ("IMP" if args.masking_method == "random" else "EXP", args.masking_method, D_MODEL,
                                   NUM_BLOCKS, S, B),
                    "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
-                   "launch": "eager" if args.no_graph else "hipGraph replay",
+                   "launch": "hipGraph replay" if graphed else "eager",
                    "params": L.numel, "train_flop_per_element": fpe},
         "final_loss": metrics["loss"],
         "params_in_sync": in_sync,

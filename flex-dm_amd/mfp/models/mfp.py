@@ -331,6 +331,9 @@ class MFP:
         g2 = g3 = None
         split = self.model.layout.bucket_split()
         grad = self.model.store.g
+        # thread-local capture checks: with a process group alive its watchdog thread polls events,
+        # which a "global"-mode capture would treat as an illegal call and abort
+        mode = "thread_local" if multi else "global"
         if not multi:
             with torch.cuda.graph(g1):
                 static_sums = self._forward_backward(static)
@@ -339,7 +342,7 @@ class MFP:
             # N > 1: the backward pass is cut at the input of block L/2.  Graph 1 = forward + upper
             # half of the backward; its gradients [split, end) (upper blocks + heads) are all-reduced
             # ASYNCHRONOUSLY while graph 2 runs the lower half; then [0, split); graph 3 = Adam.
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode=mode):
                 loss, static_sums, ctx = self._forward(static)
                 cut = ctx.mid if (ctx is not None and split > 0) else None
                 if cut is not None:
@@ -349,11 +352,11 @@ class MFP:
                 self._join_sides()
             if cut is not None:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g1.pool()):
+                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
                     cut.backward(dcut)
                     self._join_sides()
             g3 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g3, pool=g1.pool()):
+            with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode=mode):
                 self.optimizer.step(grad_scale=1.0 / dp.world_size())
 
         def replay(batch):
