@@ -244,6 +244,8 @@ class TFCheckpointReader:
 
 # ----------------------------------------------------------------------- key grammar -> names
 _RULES = [
+    # PositionEmbedding holds its table in an attribute called "embeddings" (transformer.py:17)
+    (re.compile(r"^encoder/input_layer/(const)/embeddings/(embeddings)$"), r"encoder/input_\1/\2"),
     (re.compile(r"^encoder/input_layer/([^/]+)/(embeddings|kernel|bias)$"), r"encoder/input_\1/\2"),
     (re.compile(r"^blocks/seq2seq/(seq2seq_\d+)/mlp/layer_with_weights-(\d+)/(kernel|bias)$"), r"blocks/\1/mlp/dense_\2/\3"),
     (re.compile(r"^blocks/seq2seq/(seq2seq_\d+)/(attn/[^/]+/(?:kernel|bias)|norm[12]/(?:gamma|beta))$"), r"blocks/\1/\2"),
@@ -287,7 +289,9 @@ def canonical_name(key: str) -> Optional[str]:
 def checkpoint_key(name: str, outer: bool = True) -> str:
     """Inverse of :func:`canonical_name` (fixtures / documentation)."""
     m = re.match(r"^encoder/input_(.+)/(embeddings|kernel|bias)$", name)
-    if m:
+    if name == "encoder/input_const/embeddings":
+        path = "encoder/input_layer/const/embeddings/embeddings"
+    elif m:
         path = "encoder/input_layer/%s/%s" % m.groups()
     else:
         m = re.match(r"^blocks/(seq2seq_\d+)/mlp/dense_(\d+)/(kernel|bias)$", name)

@@ -122,6 +122,42 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     ctx.join_side()   # last node of the backward pass: every weight gradient is complete after this
 
 
+class PosConstFn(torch.autograd.Function):
+    """``seq += Dropout(PositionEmbedding(range(S)))`` (reference encoder.py:241-242,
+    transformer.py:5-30): the learned position token of the non-"set" input types.  An ablation
+    path: the existing mask-and-scale kernel (``mfp_dropout_bwd``, stream 0 of the step) applies the
+    dropout in both directions, the row gather / batch sum around it is plumbing."""
+
+    POS_RNG_STREAM = 0   # the blocks use streams 2i+1, 2i+2
+
+    @staticmethod
+    def forward(fctx, h, anchor, ctx: StepCtx):
+        st = ctx.store
+        B, S, D = h.shape
+        table = st.weight("encoder/input_const/embeddings")[:S]
+        fctx.ctx, fctx.shape = ctx, (B, S, D)
+        if ctx.p > 0.0:
+            tiled = table.repeat(B, 1).contiguous()
+            dummy = torch.empty(D, dtype=torch.float32, device=h.device)
+            tiled = ops.dropout_bwd(tiled, torch.float32, dummy, ctx.p, ctx.seed, PosConstFn.POS_RNG_STREAM, ctx.step_ptr)
+            return h + tiled.view(B, S, D)
+        return h + table.unsqueeze(0)
+
+    @staticmethod
+    def backward(fctx, dout):
+        ctx = fctx.ctx
+        B, S, D = fctx.shape
+        g = ctx.store.grad("encoder/input_const/embeddings")
+        d = dout.contiguous()
+        if ctx.p > 0.0:
+            dummy = torch.empty(D, dtype=torch.float32, device=d.device)
+            d = ops.dropout_bwd(d.view(B * S, D), torch.float32, dummy, ctx.p, ctx.seed, PosConstFn.POS_RNG_STREAM,
+                                ctx.step_ptr).view(B, S, D)
+        g.zero_()
+        g[:S] = d.sum(dim=0)
+        return dout, None, None
+
+
 class EncoderFn(torch.autograd.Function):
     """Encoder on a dict of (already masked) attribute tensors, as the reference's call takes."""
 

@@ -1,16 +1,16 @@
 """Encoder: per-attribute embedding + sum fusion (reference architecture/encoder.py:14-265).
 
-Only the hot-path configuration is implemented: ``fusion="add"``, ``context=None``,
-``input_dtype="set"``, no element-wise noise (encoder.py:72-92,147-199,260-265); the ablation
-paths (flat/concat/none fusion, context tokens, position tokens) are out of scope
- and raise ``NotImplementedError``.
+Implemented: ``fusion="add"``, ``context=None``, no element-wise noise
+(encoder.py:72-92,147-199,260-265), with ``input_dtype="set"`` (the hot path) or
+``"shuffled_set"`` (adds the learned position token ``input_const``, encoder.py:47-55,241-242).
+The other ablation paths (flat/concat/none fusion, context tokens) raise ``NotImplementedError``.
 """
 from typing import Dict, Union
 
 import torch
 
 from mfp.data.spec import get_valid_input_columns
-from mfp.hip.functions import EncoderFn, StepCtx
+from mfp.hip.functions import EncoderFn, PosConstFn, StepCtx
 from mfp.models.architecture.mask import get_seq_mask
 
 CONTEXT_NAMES = [None, "id", "canvas", "length", "canvas_add"]
@@ -22,9 +22,10 @@ class Encoder:
                  latent_dim: int = 128, dropout: float = 0.1, l2: float = None, **kwargs):
         assert context in CONTEXT_NAMES
         assert fusion in ["add", "concat", "flat", "none"]
-        if context is not None or input_dtype != "set" or use_elemwise_noise or fusion != "add":
+        if context is not None or input_dtype not in ("set", "shuffled_set") or use_elemwise_noise or fusion != "add":
             raise NotImplementedError(
-                "only context=None, input_dtype='set', fusion='add' is on the accelerated MFP path")
+                "only context=None, input_dtype in {'set', 'shuffled_set'}, fusion='add' are provided")
+        self.use_pos_token = input_dtype != "set"            # encoder.py:41
         self.input_columns = input_columns
         self.valid_input_columns = get_valid_input_columns(input_columns, False)
         self.context, self.fusion, self.latent_dim = context, fusion, latent_dim
@@ -36,5 +37,9 @@ class Encoder:
         seq_mask = get_seq_mask(inputs["length"], maxlen=S)
         cat_inputs = [inputs[k] for k in L.cat_keys]
         num_inputs = [inputs[k] for k in L.num_keys]
-        h = EncoderFn.apply(self.store.anchor, ctx, cat_inputs, num_inputs)
-        return h.view(ctx.B, S, L.D), seq_mask
+        h = EncoderFn.apply(self.store.anchor, ctx, cat_inputs, num_inputs).view(ctx.B, S, L.D)
+        if self.use_pos_token:                               # encoder.py:241-242
+            if S > L.pos_rows:
+                raise ValueError("sequence length %d exceeds the %d rows of the position table" % (S, L.pos_rows))
+            h = PosConstFn.apply(h, self.store.anchor, ctx)
+        return h, seq_mask

@@ -34,7 +34,7 @@ class Model:
         self.arch_type = "oneshot"
         self.input_columns = input_columns
         self.dropout, self.seed = dropout, seed
-        self.layout = ModelLayout(input_columns, latent_dim, num_blocks)
+        self.layout = ModelLayout(input_columns, latent_dim, num_blocks, input_dtype)
         self.store = ParamStore(self.layout, device, DTYPES[dtype], l2=l2, seed=seed)
         self.blocks = Blocks(self.store, num_blocks=num_blocks, block_type=block_type,
                              latent_dim=latent_dim, dropout=dropout, l2=l2)

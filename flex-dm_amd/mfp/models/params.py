@@ -40,7 +40,7 @@ class Segment:
 class ModelLayout:
     """Static description of the flat buffer for one (input_columns, D, L) configuration."""
 
-    def __init__(self, input_columns: Dict, latent_dim: int, num_blocks: int):
+    def __init__(self, input_columns: Dict, latent_dim: int, num_blocks: int, input_dtype: str = "set"):
         D = latent_dim
         assert D % NUM_HEADS == 0, "embedding dimension = %d should be divisible by number of heads = %d" % (
             D, NUM_HEADS)  # ValueError text of transformer.py:48-52
@@ -83,6 +83,12 @@ class ModelLayout:
             assert width % 8 == 0
             self._add("encoder/input_%s/kernel" % k, (D, width), True, True)
             self._add("encoder/input_%s/bias" % k, (D,), True, False)
+        # position token of the non-"set" input types (encoder.py:47-55: PositionEmbedding "input_const",
+        # maxlen = input_dim of the length column -> maxlen + 1 rows)
+        self.pos_rows = 0
+        if input_dtype != "set":
+            self.pos_rows = int(input_columns["length"]["input_dim"]) + 1
+            self._add("encoder/input_const/embeddings", (self.pos_rows, D), True, False)
 
         # ---- transformer blocks
         for i in range(num_blocks):

@@ -4,7 +4,6 @@ Only what the hot path's callers reach: ``sort_inputs`` (RICO position-sorted lo
 tensor_utils.py:14-44), ``shuffle_inputs`` (:47-78), ``reorganize_indices`` (:81-108) and the
 dict split/merge helpers (:111-129).
 """
-import random
 from typing import Dict, List, Union
 
 import torch
@@ -52,16 +51,17 @@ def sort_inputs(inputs: Dict, input_columns: Dict, from_logits: bool = False):
 
 
 def shuffle_inputs(inputs: Dict):
+    """Random order of the valid elements of every document, padding left in place (reference
+    tensor_utils.py:47-78 walks the batch in Python with ``random.shuffle``; here the permutation
+    is an argsort of uniform keys on the device -- same distribution, no host sync, so the step
+    stays capturable in a hipGraph)."""
     assert "length" in inputs and "left" in inputs
     B, S = inputs["left"].shape[:2]
-    data = []
-    length = inputs["length"].reshape(-1).tolist()
-    for i in range(B):
-        N = int(length[i]) + 1
-        x = list(range(N))
-        random.shuffle(x)
-        data.append(x + list(range(N, S)))
-    indices = torch.tensor(data, device=inputs["left"].device)
+    dev = inputs["left"].device
+    valid = get_seq_mask(inputs["length"], maxlen=S)
+    keys = torch.rand((B, S), device=dev)
+    keys = torch.where(valid, keys, 2.0 + torch.arange(S, device=dev, dtype=torch.float32)[None, :])
+    indices = torch.argsort(keys, dim=1)
     new_inputs = {}
     for key, val in inputs.items():
         if val.dim() >= 2 and val.shape[1] == S:

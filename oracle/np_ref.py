@@ -55,7 +55,8 @@ def valid_columns(input_columns: Dict) -> Dict:
     return out
 
 
-def param_shapes(input_columns: Dict, latent_dim: int, num_blocks: int) -> Dict[str, Tuple[int, ...]]:
+def param_shapes(input_columns: Dict, latent_dim: int, num_blocks: int,
+                 input_dtype: str = "set") -> Dict[str, Tuple[int, ...]]:
     """Variables created by Encoder/Blocks/Decoder, in creation order.
 
     encoder.py:72-92 (Embedding(C+2, D) per categorical; Embedding(2, D) + Dense(D) per
@@ -72,6 +73,8 @@ def param_shapes(input_columns: Dict, latent_dim: int, num_blocks: int) -> Dict[
             shapes["encoder/input_%s_special/embeddings" % key] = (2, D)
             shapes["encoder/input_%s/kernel" % key] = (col["shape"][-1], D)
             shapes["encoder/input_%s/bias" % key] = (D,)
+    if input_dtype != "set":   # encoder.py:47-55: PositionEmbedding(maxlen = length.input_dim) -> maxlen + 1 rows
+        shapes["encoder/input_const/embeddings"] = (int(input_columns["length"]["input_dim"]) + 1, D)
     for i in range(num_blocks):
         p = "blocks/seq2seq_%d/" % i
         for name in ("dense_query", "dense_key", "dense_value", "combine_heads"):
@@ -98,14 +101,14 @@ def is_regularized(name: str) -> bool:
     return not (name.endswith("/gamma") or name.endswith("/beta"))
 
 
-def init_params(input_columns: Dict, latent_dim: int, num_blocks: int, seed: int = 0
+def init_params(input_columns: Dict, latent_dim: int, num_blocks: int, seed: int = 0, input_dtype: str = "set"
                 ) -> Dict[str, np.ndarray]:
     """[TF-EXT] Keras default initialisers: Dense glorot_uniform / zeros bias; Embedding
     U(-0.05, 0.05); LN gamma 1, beta 0.  (Biases are drawn small-random instead of zero when
     ``seed`` is negative so that tests exercise the bias paths.)"""
     rng = np.random.default_rng(abs(seed))
     params = {}
-    for name, shape in param_shapes(input_columns, latent_dim, num_blocks).items():
+    for name, shape in param_shapes(input_columns, latent_dim, num_blocks, input_dtype).items():
         if name.endswith("/embeddings"):
             w = rng.uniform(-0.05, 0.05, size=shape)
         elif name.endswith("/kernel"):
@@ -171,6 +174,9 @@ def encoder_fwd(params, input_columns, inputs, maxlen=None):
             x = np.where(is_masked[..., None], special[0], x)     # :174
             x = np.where(is_unused[..., None], special[1], x)     # :175 (unused wins)
         seq = seq + x                                             # :195-197
+    if "encoder/input_const/embeddings" in params:                # :241-242, transformer.py:24-30 (dropout 0)
+        S = seq.shape[1]
+        seq = seq + params["encoder/input_const/embeddings"].astype(F64)[np.arange(S)][None]
     return seq, seq_mask
 
 

@@ -84,6 +84,9 @@ def encoder_fwd(p, input_columns, inputs, maxlen=None):
     seq = 0.0
     for d in data_s:
         seq = seq + d
+    if "encoder/input_const/embeddings" in p:    # encoder.py:241-242 (PositionEmbedding, dropout rate 0)
+        positions = torch.arange(seq.shape[1])
+        seq = seq + p["encoder/input_const/embeddings"][positions][None, :, :]
     return seq, seq_mask
 
 

@@ -348,3 +348,47 @@ def test_split_backward_equals_single_backward():
     torch.cuda.synchronize()
     assert torch.allclose(sums, ref_sums, rtol=1e-5, atol=1e-5)   # loss sums: float atomics across workgroups
     assert torch.equal(g, ref)
+
+
+def test_shuffled_set_position_token_parity_and_training():
+    """--input_dtype shuffled_set (args.py:83-87): position token ``input_const`` (encoder.py:47-55,
+    241-242) -- forward / backward parity incl. the table's gradient at dropout 0, then training
+    steps with dropout through eager and graph replay."""
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.metrics import build_loss_keys
+    from mfp.models.mfp import MFP
+    from mfp.models.model import Model
+    B, S, D, L = 6, 20, 128, 2
+    ic, _, batch, modified, masks, *_ = _setup("rico", B, S, D, L, seed=4)
+    params = np_ref.init_params(ic, D, L, seed=-9, input_dtype="shuffled_set")
+    state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S)
+    model = Model(ic, num_blocks=L, latent_dim=D, dropout=0.0, dtype="fp32", device=DEV, input_dtype="shuffled_set")
+    model.store.load_state_dict(params)
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    keys = build_loss_keys(ic, model.layout.head_cols, dev(batch), dev(masks))
+    loss, sums, outputs = model.forward_loss(dev(modified), keys, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(info["data_loss"])) <= 1e-4 * max(1.0, float(info["data_loss"]))
+    gd = model.store.grads_state_dict()
+    gmax = max(w.abs().max().item() for w in grads.values())
+    for name in ("encoder/input_const/embeddings", "encoder/input_left/embeddings", "blocks/seq2seq_0/attn/dense_query/kernel"):
+        err = (gd[name].double() - grads[name]).abs().max().item()
+        assert err <= 2e-4 * grads[name].abs().max().item() + 5e-5 * gmax, (name, err)
+    assert (gd["encoder/input_const/embeddings"][S:] == 0).all()    # rows past the sequence get no gradient
+    # training through the reference-shaped API, with dropout on the token
+    mfp = MFP(ic, num_blocks=2, latent_dim=128, dropout=0.1, l2=1e-2, masking_method="random", dtype="bf16",
+              device=DEV, input_dtype="shuffled_set")
+    mfp.compile(learning_rate=1e-3)
+    dbatch = synthetic_batch(ic, 16, 24, seed=0, ragged=True, device=DEV)
+    w0 = mfp.model.store.weight("encoder/input_const/embeddings").clone()
+    first = float(mfp.train_step(dbatch)[:, 0].sum())
+    mfp.capture_train_step(dbatch, warmup=1)
+    for _ in range(40):
+        sums = mfp.train_step(dbatch)
+    torch.cuda.synchronize()
+    assert np.isfinite(first) and float(sums[:, 0].sum()) < first
+    w1 = mfp.model.store.weight("encoder/input_const/embeddings")
+    assert not torch.equal(w0[:24], w1[:24])
+    assert torch.isfinite(mfp.test_step(dbatch)).all()

@@ -274,3 +274,20 @@ def test_host_sort_inputs_matches_oracle():
     got = sort_inputs(batch, cols)
     for k, v in want.items():
         np.testing.assert_array_equal(got[k].numpy(), v)
+
+
+def test_position_token_of_shuffled_set():
+    """input_dtype != "set" adds PositionEmbedding(range(S)) to every element (encoder.py:241-242)."""
+    ic = _ic("rico")
+    B, S, D, L = 2, 6, 16, 1
+    params = np_ref.init_params(ic, D, L, seed=-2, input_dtype="shuffled_set")
+    assert params["encoder/input_const/embeddings"].shape == (ic["length"]["input_dim"] + 1, D)
+    batch = _batch(ic, B, S, seed=2)
+    nb = {k: v.numpy() for k, v in batch.items()}
+    plain = {k: v for k, v in params.items() if k != "encoder/input_const/embeddings"}
+    h0, _ = np_ref.encoder_fwd(plain, ic, nb, S)
+    h1, _ = np_ref.encoder_fwd(params, ic, nb, S)
+    np.testing.assert_allclose(h1 - h0, np.broadcast_to(params["encoder/input_const/embeddings"][:S].astype(np.float64), (B, S, D)), atol=1e-12)
+    p = torch_ref.to_torch(params, torch.float64)
+    ht, _ = torch_ref.encoder_fwd(p, ic, batch, S)
+    np.testing.assert_allclose(ht.detach().numpy(), h1, rtol=1e-10, atol=1e-12)

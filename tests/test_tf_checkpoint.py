@@ -116,3 +116,7 @@ def test_name_map_override_and_entry_fields(tmp_path):
     np.testing.assert_array_equal(got["encoder/input_x/kernel"], a)
     assert tfc.canonical_name("model/encoder/input_layer/a..b.Sc/kernel" + tfc._SUFFIX) == "encoder/input_a.b/c/kernel"
     assert tfc.canonical_name("_CHECKPOINTABLE_OBJECT_GRAPH") is None
+    # PositionEmbedding of the shuffled_set input type keeps its table in an attribute "embeddings"
+    k = "model/encoder/input_layer/const/embeddings/embeddings" + tfc._SUFFIX
+    assert tfc.canonical_name(k) == "encoder/input_const/embeddings"
+    assert tfc.checkpoint_key("encoder/input_const/embeddings") == k
