@@ -7,6 +7,10 @@
 
 namespace {
 
+// Two dependent round trips per token instead of 2 * NCOL: all index loads are issued first
+// (a token's D/4 threads read the same words: one broadcast transaction each), then all table rows
+// (L2-resident: the tables are < 1 MB), then the sum.  MAXC is the compile-time column bound.
+template <int MAXC>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ idx,
                                                         const int* __restrict__ rowoff,
                                                         const float* __restrict__ tables,
@@ -15,16 +19,23 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ 
   const int dv = D >> 2;
   long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = (long long)T * dv;
+  int off[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) off[j] = j < NCOL ? rowoff[j] : 0;
   for (; gid < total; gid += (long long)gridDim.x * blockDim.x) {
     const int t = (int)(gid / dv), c = (int)(gid % dv) * 4;
     const int* it = idx + (long long)t * NCOL;
+    int r[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) r[j] = j < NCOL ? it[j] : -1;
+    float4 v[MAXC];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j)
+      v[j] = r[j] >= 0 ? *reinterpret_cast<const float4*>(tables + (long long)(off[j] + r[j]) * D + c)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < NCOL; ++j) {
-      const int r = it[j];
-      if (r < 0) continue;
-      float4 v = *reinterpret_cast<const float4*>(tables + (long long)(rowoff[j] + r) * D + c);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }   // column order: as before
     *reinterpret_cast<float4*>(out + (long long)t * D + c) = acc;
   }
 }
@@ -149,8 +160,13 @@ extern "C" int mfp_embed_pool_fwd(const int32_t* idx, const int32_t* rowoff, con
   long long total = (long long)T * (D / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     idx, rowoff, tables, out, T, NCOL, D);
+  MFP_CHECK_ARG(NCOL <= 32);
+  if (NCOL <= 16)
+    hipLaunchKernelGGL(embed_fwd_kernel<16>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       idx, rowoff, tables, out, T, NCOL, D);
+  else
+    hipLaunchKernelGGL(embed_fwd_kernel<32>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       idx, rowoff, tables, out, T, NCOL, D);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
