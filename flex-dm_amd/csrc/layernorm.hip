@@ -283,3 +283,23 @@ extern "C" int mfp_reduce_partials(const float* part, float* out0, float* out1, 
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
+
+extern "C" int mfp_reduce_partials_batch(const mfp_reduce_job* jobs, int32_t njobs, mfp_stream_t stream) {
+  MFP_CHECK_ARG(jobs && njobs > 0 && njobs <= MFP_MAX_REDUCE_JOBS);
+  ReduceJobs rj;
+  long long maxn = 0;
+  for (int i = 0; i < MFP_MAX_REDUCE_JOBS; ++i) {
+    const mfp_reduce_job& j = jobs[i < njobs ? i : 0];
+    if (i < njobs) {
+      MFP_CHECK_ARG(j.part && j.out0 && j.P > 0 && j.N > 0 && j.N <= 8192 && j.pstride >= j.N && j.split1 >= 0 && j.split2 >= j.split1);
+      MFP_CHECK_ARG((j.split1 >= j.N || j.out1) && (j.split2 >= j.N || j.out2));
+      if (j.N > maxn) maxn = j.N;
+    }
+    rj.part[i] = j.part; rj.out0[i] = j.out0; rj.out1[i] = j.out1; rj.out2[i] = j.out2;
+    rj.split1[i] = j.split1; rj.split2[i] = j.split2; rj.N[i] = j.N; rj.pstride[i] = j.pstride; rj.P[i] = j.P;
+  }
+  hipLaunchKernelGGL(reduce_rows_multi_kernel<8>, dim3((unsigned)((maxn + 7) / 8), (unsigned)njobs), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), rj);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

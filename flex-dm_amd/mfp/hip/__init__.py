@@ -42,6 +42,13 @@ class GemmArgs(Structure):
     ]
 
 
+class ReduceJob(Structure):
+    _fields_ = [
+        ("part", c_void_p), ("out0", c_void_p), ("out1", c_void_p), ("out2", c_void_p),
+        ("split1", c_int64), ("split2", c_int64), ("N", c_int64), ("pstride", c_int64), ("P", c_int32),
+    ]
+
+
 class LossKey(Structure):
     _fields_ = [
         ("col_off", c_int32), ("n_feat", c_int32), ("n_class", c_int32), ("is_numerical", c_int32),
@@ -72,6 +79,7 @@ SIGNATURES = {
     "mfp_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mfp_layernorm_bwd_partial_rows": (c_int32, [c_int32]),
     "mfp_reduce_partials": (c_int32, [c_void_p] * 4 + [c_int64, c_int64, c_int32, c_int64, c_int64, c_void_p]),
+    "mfp_reduce_partials_batch": (c_int32, [POINTER(ReduceJob), c_int32, c_void_p]),
     "mfp_attention_fwd": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "mfp_attention_bwd": (c_int32, [c_void_p] * 6 + [c_int32] * 5 + [c_void_p]),
     "mfp_embed_pool_fwd": (c_int32, [c_void_p] * 4 + [c_int32] * 4 + [c_void_p]),

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -34,6 +36,8 @@ class StepCtx:
         self.dh_c = None    # compute-dtype copy of the encoder output gradient (block 0's LN1 backward)
         self.onehot = None  # one-hot count matrix of the index columns (built during the forward pass)
         self.mid = None     # activation entering block L/2 (set by Blocks; see MFP.capture_train_step)
+        # pending LayerNorm parameter-gradient reductions (flush_ln_jobs); None = reduce in line
+        self.ln_jobs = [] if os.environ.get("MFP_LN_BATCH_REDUCE", "1") == "1" else None
         self.loss_sort = None   # RICO position-sorted loss: dict(flag, labels, heads, ignore_sort)
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
         self.nvalid = nvalid
@@ -58,6 +62,13 @@ class StepCtx:
             fn()
         for t in tensors:   # their memory must not be recycled by main-stream allocations too early
             t.record_stream(side)
+
+    def flush_ln_jobs(self):
+        """Sum the LayerNorm gamma / beta (/ fused bias) gradient partials of every layer handled so
+        far in one launch.  Called where the gradients are needed: at the end of the backward pass and,
+        in the data-parallel split step, before the upper bucket is all-reduced."""
+        if self.ln_jobs:
+            ops.reduce_partials_batch(self.ln_jobs)
 
     def join_side(self):
         for side in self.sides:
@@ -115,10 +126,12 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
         n_num = len(L.num_keys)
         for j, k in enumerate(L.num_keys[:-1]):
             ctx.on_side(lambda j=j, k=k: wgrad_dense(j, k), dh_c, xs[j], codes[j], which=j % 2)
+        ctx.flush_ln_jobs()   # every LayerNorm layer's parameter-gradient partials: one launch, here in the tail
         if n_num:   # the main stream has nothing else left: the last product runs there, without a fork
             wgrad_dense(n_num - 1, L.num_keys[-1])
     if not onehot:
         ops.embed_pool_bwd(idx_all, st.rowoff, dh, st.tables(st.g))
+    ctx.flush_ln_jobs()   # (no-op when already flushed above)
     ctx.join_side()   # last node of the backward pass: every weight gradient is complete after this
 
 
@@ -264,7 +277,7 @@ class BlockFn(torch.autograd.Function):
         dx1, d_o1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
                                       st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
                                       drop=(st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
-                                            ctx.step_ptr))
+                                            ctx.step_ptr), jobs=ctx.ln_jobs)
         # ---- attention: x1 = x + drop(a Wo + bo)
         wt = st.cwt(p + "attn/combine_heads/kernel")
         da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True,
@@ -286,7 +299,7 @@ class BlockFn(torch.autograd.Function):
             dx, nxt = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
                                         st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"),
                                         drop=(st.grad(pp + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * (i - 1) + 2,
-                                              ctx.step_ptr))
+                                              ctx.step_ptr), jobs=ctx.ln_jobs)
             ctx.handoff[i - 1] = nxt
         else:
             if cdt == torch.bfloat16:
@@ -294,10 +307,11 @@ class BlockFn(torch.autograd.Function):
                 # encoder's weight-gradient products read (saves the cast pass at the end of the step)
                 dx, ctx.dh_c = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
                                                  st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"),
-                                                 drop=(st.scratch("ln_dummy_colsum", (D,), torch.float32), 0.0, 0, 0, None))
+                                                 drop=(st.scratch("ln_dummy_colsum", (D,), torch.float32), 0.0, 0, 0, None),
+                                                 jobs=ctx.ln_jobs)
             else:
                 dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
-                                       st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"))
+                                       st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), jobs=ctx.ln_jobs)
         fctx.saved = None
         return dx, None, None
 

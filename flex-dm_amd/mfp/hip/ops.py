@@ -194,11 +194,14 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,
-                  dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None, defer=None):
+                  dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None, defer=None,
+                  jobs: Optional[list] = None):
     """``drop`` = (colsum_out [D], p, seed, offset, step_ptr): also return the dropout-masked,
     compute-dtype copy of dx for the consuming Dense backward (fused mfp_dropout_bwd).
     ``defer(fn, *tensors)``: the parameter-gradient reduction (dgamma, dbeta, colsum -- only the
-    optimizer needs them) is handed to ``defer`` (StepCtx.on_side) instead of running in line."""
+    optimizer needs them) is handed to ``defer`` (StepCtx.on_side) instead of running in line.
+    ``jobs``: instead, append the reduction to this list for ONE batched launch at the end of the
+    backward pass (:func:`reduce_partials_batch`)."""
     lib = load()
     T, D = x.shape
     if dx is None:
@@ -207,15 +210,20 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma
     colsum, p_, seed_, off_, sp_ = drop if drop is not None else (None, 0.0, 0, 0, None)
     nbytes = lib.mfp_layernorm_bwd_workspace_bytes(T, D)
     # deferred reduction: the partials must outlive this call -> their own buffer, not the shared one
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if defer is not None else workspace(nbytes, x.device)
+    own_ws = defer is not None or jobs is not None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if own_ws else workspace(nbytes, x.device)
     nb = T * D * (_esz(dy) + 4 + (4 if dres is not None else 0) + 4 + (_esz(dy) if drop is not None else 0))
     with _timed("ln_bwd_kernel", 0, nb):
         check(lib.mfp_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
-                                    _ptr(dx), _ptr(None if defer is not None else dgamma),
-                                    _ptr(None if defer is not None else dbeta), ws.data_ptr(), ws.numel(), T, D,
+                                    _ptr(dx), _ptr(None if own_ws else dgamma),
+                                    _ptr(None if own_ws else dbeta), ws.data_ptr(), ws.numel(), T, D,
                                     dt_code(dy.dtype), _ptr(ddrop), _ptr(colsum), float(p_), int(seed_), int(off_),
                                     _ptr(sp_), _stream()), "mfp_layernorm_bwd")
-    if defer is not None:
+    if jobs is not None:
+        P = lib.mfp_layernorm_bwd_partial_rows(T)
+        jobs.append(dict(part=ws, out0=dgamma, out1=dbeta, out2=colsum, split1=D, split2=2 * D, P=P,
+                         N=3 * D if drop is not None else 2 * D, pstride=3 * D))
+    elif defer is not None:
         P = lib.mfp_layernorm_bwd_partial_rows(T)
         n = 3 * D if drop is not None else 2 * D
 
@@ -224,6 +232,23 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma
                                           3 * D, _stream()), "mfp_reduce_partials")
         defer(finish, ws)
     return (dx, ddrop) if drop is not None else dx
+
+
+def reduce_partials_batch(jobs: list) -> None:
+    """One launch for every pending partial reduction (dicts from ``layernorm_bwd(jobs=...)``); the
+    list is emptied.  More than MFP_MAX_REDUCE_JOBS entries go out in several launches."""
+    lib = load()
+    from . import ReduceJob
+    while jobs:
+        chunk, rest = jobs[:16], jobs[16:]
+        arr = (ReduceJob * len(chunk))()
+        for i, j in enumerate(chunk):
+            arr[i].part, arr[i].out0, arr[i].out1, arr[i].out2 = (j["part"].data_ptr(), _ptr(j["out0"]), _ptr(j["out1"]),
+                                                                   _ptr(j["out2"]))
+            arr[i].split1, arr[i].split2, arr[i].N, arr[i].pstride, arr[i].P = j["split1"], j["split2"], j["N"], j["pstride"], j["P"]
+        with _timed("reduce_partials_batch", 0, sum(j["P"] * j["N"] * 4 for j in chunk)):
+            check(lib.mfp_reduce_partials_batch(arr, len(chunk), _stream()), "mfp_reduce_partials_batch")
+        jobs[:] = rest
 
 
 # ------------------------------------------------------------------------------- attention

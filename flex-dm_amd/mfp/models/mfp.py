@@ -347,6 +347,7 @@ class MFP:
                 cut = ctx.mid if (ctx is not None and split > 0) else None
                 if cut is not None:
                     dcut = torch.autograd.grad(loss, cut)[0]
+                    ctx.flush_ln_jobs()   # upper blocks' LayerNorm gradients must be final before their all-reduce
                 else:
                     loss.backward()
                 self._join_sides()

@@ -118,6 +118,17 @@ size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D);
 int32_t mfp_layernorm_bwd_partial_rows(int32_t T);
 int mfp_reduce_partials(const float* part, float* out0, float* out1, float* out2, int64_t split1,
                         int64_t split2, int32_t P, int64_t N, int64_t pstride, mfp_stream_t stream);
+/* The same reduction for up to MFP_MAX_REDUCE_JOBS independent partial buffers in one launch (the
+ * partials of every LayerNorm layer of the step, summed once at the end of the backward pass;
+ * same summation order per output as mfp_reduce_partials, N <= 8192 per job). */
+#define MFP_MAX_REDUCE_JOBS 16
+typedef struct mfp_reduce_job {
+  const float* part;
+  float* out0; float* out1; float* out2;
+  int64_t split1, split2, N, pstride;
+  int32_t P;
+} mfp_reduce_job;
+int mfp_reduce_partials_batch(const mfp_reduce_job* jobs /*host*/, int32_t njobs, mfp_stream_t stream);
 
 /* --------------------------------------------------------------------------- attention
  * MultiHeadSelfAttention.attention (transformer.py:60-76) fused: softmax(QK^T/sqrt(hd) +

@@ -337,6 +337,7 @@ def test_split_backward_equals_single_backward():
     loss, sums, ctx = model._forward(batch)
     assert ctx.mid is not None
     dcut = torch.autograd.grad(loss, ctx.mid)[0]
+    ctx.flush_ln_jobs()          # as capture_train_step does before the upper bucket's all-reduce
     model._join_sides()
     torch.cuda.synchronize()
     # upper bucket complete; the lower one is still (almost) untouched -- only the bias gradient that
