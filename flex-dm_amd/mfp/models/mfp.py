@@ -286,13 +286,21 @@ class MFP:
             loss, sums, _ = self.model.forward_loss(modified_inputs, keys, training=True, loss_sort=loss_sort(targets))
         return loss, sums, ctx
 
+    def _unit_grad(self, loss: torch.Tensor) -> torch.Tensor:
+        """The root gradient as a resident tensor: autograd would otherwise launch a fill kernel for
+        ones_like(loss) on the critical path of every step."""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype:
+            one = self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return one
+
     def _join_sides(self):
         for side in self.model.side_streams:   # weight gradients run on the side streams
             torch.cuda.current_stream().wait_stream(side)
 
     def _forward_backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         loss, sums, _ = self._forward(batch)
-        loss.backward()
+        loss.backward(self._unit_grad(loss))
         self._join_sides()
         return sums
 
@@ -346,10 +354,10 @@ class MFP:
                 loss, static_sums, ctx = self._forward(static)
                 cut = ctx.mid if (ctx is not None and split > 0) else None
                 if cut is not None:
-                    dcut = torch.autograd.grad(loss, cut)[0]
+                    dcut = torch.autograd.grad(loss, cut, grad_outputs=self._unit_grad(loss))[0]
                     ctx.flush_ln_jobs()   # upper blocks' LayerNorm gradients must be final before their all-reduce
                 else:
-                    loss.backward()
+                    loss.backward(self._unit_grad(loss))
                 self._join_sides()
             if cut is not None:
                 g2 = torch.cuda.CUDAGraph()
