@@ -365,15 +365,23 @@ class _TFRecordDataset:
         return recs
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        # shuffle -> repeat -> batch (reference spec.py:244-248): batching runs over the REPEATED
+        # record stream, so with repeat=True a batch straddles pass boundaries and every batch is
+        # full; only a non-repeated pass ends with a short batch
         recs = self._records()
         self._count = len(recs)
-        while True:
+        pending: List[bytes] = []
+        while recs:
             order = self._rng.permutation(len(recs)) if self._shuffle else np.arange(len(recs))
-            for i in range(0, len(recs), self._bs):
-                yield parse_examples([recs[j] for j in order[i:i + self._bs]], self._schema, self._device,
-                                     seq_len=self._seq_len)
+            for j in order:
+                pending.append(recs[j])
+                if len(pending) == self._bs:
+                    yield parse_examples(pending, self._schema, self._device, seq_len=self._seq_len)
+                    pending = []
             if not self._repeat:
-                return
+                break
+        if pending:
+            yield parse_examples(pending, self._schema, self._device, seq_len=self._seq_len)
 
     def __len__(self):
         if self._count is None:

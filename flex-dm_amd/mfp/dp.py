@@ -40,6 +40,13 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def rank_seed(seed: int) -> int:
+    """Seed of this rank's counter-based random streams (task draw, masking, dropout): every rank
+    must draw independently for its documents, otherwise only B/N of the global batch's draws are
+    independent.  Rank 0 keeps ``seed``; the parameter-initialisation seed is NOT rank-dependent."""
+    return (int(seed) + 0x9E3779B1 * rank()) & 0x7FFFFFFFFFFFFFFF
+
+
 def allreduce_gradients(flat_grad: torch.Tensor, async_op: bool = False):
     """Sum the flat gradient over ranks in place.  The 1/N factor is folded into the optimizer
     (``AdamKeras.step(grad_scale=1/N)``) so no extra pass over the buffer is needed."""
@@ -65,15 +72,45 @@ def broadcast_parameters(flat_w: torch.Tensor, src: int = 0):
         dist.broadcast(flat_w, src=src)
 
 
-def shard_batch(batch: dict, r: Optional[int] = None, n: Optional[int] = None) -> dict:
-    """Rank r's slice of a global batch (axis 0), equal shards."""
+def shard_bounds(B: int, r: int, n: int):
+    """[lo, hi) of rank r's documents when B documents are dealt to n ranks as evenly as possible
+    (the first B % n ranks hold one more; a rank's shard may be empty when B < n)."""
+    q, rem = divmod(B, n)
+    lo = r * q + min(r, rem)
+    return lo, lo + q + (1 if r < rem else 0)
+
+
+def shard_batch(batch: dict, r: Optional[int] = None, n: Optional[int] = None, even: bool = True) -> dict:
+    """Rank r's slice of a global batch (axis 0).  ``even=True`` (training: the averaged gradient
+    equals the global-batch gradient only for equal shards) insists on B % n == 0; ``even=False``
+    (evaluation: sums are all-reduced with the document counts) deals a ragged batch out unevenly."""
     r = rank() if r is None else r
     n = world_size() if n is None else n
     if n == 1:
         return batch
     out = {}
     for k, v in batch.items():
-        B = v.shape[0]
-        assert B % n == 0, "global batch %d not divisible by world size %d" % (B, n)
-        out[k] = v[r * (B // n):(r + 1) * (B // n)]
+        B = len(v)
+        if even:
+            assert B % n == 0, ("global batch of %d documents is not divisible by the %d data-parallel ranks "
+                                "(choose --batch_size as a multiple of the world size)" % (B, n))
+        lo, hi = shard_bounds(B, r, n)
+        out[k] = v[lo:hi]
     return out
+
+
+def allreduce_eval_sums(sums: Optional[torch.Tensor], b_local: int, nkeys: int, device) -> torch.Tensor:
+    """Evaluation sums of one global batch from the per-rank shards: ``sums [nkeys][3]`` holds the
+    shard's (mean-over-documents loss, score numerator, score denominator) or is None for an empty
+    shard.  Returns the same triple for the GLOBAL batch (loss = mean over all its documents)."""
+    pack = torch.zeros(nkeys * 3 + 1, dtype=torch.float64, device=device)
+    if sums is not None and b_local > 0:
+        s = sums.to(torch.float64).clone()
+        s[:, 0] *= b_local                      # mean over the shard -> sum over its documents
+        pack[:-1] = s.reshape(-1)
+        pack[-1] = b_local
+    if world_size() > 1:
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+    out = pack[:-1].reshape(nkeys, 3).clone()
+    out[:, 0] /= pack[-1].clamp(min=1.0)
+    return out.to(torch.float32)

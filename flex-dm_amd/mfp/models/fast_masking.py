@@ -7,6 +7,7 @@ from typing import Dict, List
 
 import torch
 
+from mfp import dp
 from mfp.data.spec import get_attribute_groups
 from mfp.hip import ops
 
@@ -16,7 +17,7 @@ MASK_SEED_SALT = 0x9E3779B97F4A7C15
 class FusedMasker:
     def __init__(self, input_columns: Dict, layout, store, seed: int):
         self.layout, self.store = layout, store
-        self.seed = (int(seed) ^ MASK_SEED_SALT) & 0xFFFFFFFFFFFFFFFF
+        self._seed = int(seed)
         groups = get_attribute_groups(input_columns.keys())
         group_of = {k: gi for gi, keys in enumerate(groups.values()) for k in keys}
         self.cols: List[dict] = []
@@ -34,6 +35,11 @@ class FusedMasker:
                 cond = c["loss_condition"]
                 d.update(cond_key=cond["key"], cond_bits=sum(1 << i for i, f in enumerate(cond["mask"]) if f))
             self.cols.append(d)
+
+    @property
+    def seed(self) -> int:
+        """Evaluated per call: the process group may be initialised after the model is built."""
+        return (dp.rank_seed(self._seed) ^ MASK_SEED_SALT) & 0xFFFFFFFFFFFFFFFF
 
     def __call__(self, batch: Dict[str, torch.Tensor], tasks: torch.Tensor, nvalid: torch.Tensor, B: int, S: int,
                  step_ptr):

@@ -93,7 +93,11 @@ def metrics_from_sums(input_columns: Dict, sums: torch.Tensor):
 
 class LossLayer:
     def __init__(self, input_columns: Dict, name: str = "loss_layer", predict_context: bool = False,
-                 **kwargs):
+                 model_layout=None, **kwargs):
+        """``model_layout`` (new, optional): the ``ModelLayout`` of the model whose outputs this layer
+        scores.  The model's concatenated logits buffer ``_flat_logits`` pads every head to a multiple
+        of 8 columns; it is only consumed in place when the layout that produced it is known --
+        otherwise the per-key logits of ``y_pred`` are re-concatenated (unpadded)."""
         if predict_context:
             raise NotImplementedError("predict_context is off the MFP hot path")
         self.name = name
@@ -101,35 +105,44 @@ class LossLayer:
         self._valid_input_columns = get_valid_input_columns(input_columns)
         self.losses: List[torch.Tensor] = []
         self.metrics: Dict[str, torch.Tensor] = {}
+        self.sums = None
         col, self._head_cols = 0, {}
         for k, c in self._valid_input_columns.items():
             units = c["shape"][-1] * c["input_dim"] if c["type"] == "categorical" else c["shape"][-1]
             self._head_cols[k] = (col, units)
             col += units
         self._U = col
+        self._model_head_cols, self._model_ld = None, None
+        if model_layout is not None:
+            assert list(model_layout.head_cols) == list(self._head_cols)
+            self._model_head_cols, self._model_ld = dict(model_layout.head_cols), model_layout.Upad
 
-    def _flat_logits(self, y_pred: Dict, B: int, S: int) -> torch.Tensor:
+    def _flat_logits(self, y_pred: Dict, B: int, S: int):
+        """-> (logits [B*S][ld] f32, head_cols).  The model's own buffer is used in place only
+        together with the model's (8-aligned) column offsets."""
         flat = y_pred.get("_flat_logits")
-        if flat is not None and flat.shape[0] == B * S:
-            return flat
+        if (flat is not None and self._model_head_cols is not None and flat.shape[0] == B * S
+                and flat.shape[1] == self._model_ld):
+            return flat, self._model_head_cols
         parts = [y_pred[k][:, :S].reshape(B * S, -1).to(torch.float32) for k in self._head_cols]
-        return torch.cat(parts, dim=1).contiguous()
+        return torch.cat(parts, dim=1).contiguous(), self._head_cols
 
     def __call__(self, inputs, training=False, sort_flag: Union[bool, torch.Tensor] = None,
                  ignore_sort: str = None):
         y_true, y_pred, mfp_masks = inputs
         first = next(iter(self._head_cols))
         B, S = y_true[first].shape[:2]
-        logits = self._flat_logits(y_pred, B, S)
+        logits, head_cols = self._flat_logits(y_pred, B, S)
         nvalid = (y_true["length"].reshape(-1) + 1).to(torch.int32)
-        keys = build_loss_keys(self._input_columns, self._head_cols, y_true, mfp_masks)
+        keys = build_loss_keys(self._input_columns, head_cols, y_true, mfp_masks)
         pred_row = true_row = None
         if torch.is_tensor(sort_flag):                               # metrics.py:180-211
             from mfp.hip.functions import loss_row_maps
-            sort = build_loss_sort(self._input_columns, self._head_cols, y_true, sort_flag, ignore_sort)
+            sort = build_loss_sort(self._input_columns, head_cols, y_true, sort_flag, ignore_sort)
             pred_row, true_row = loss_row_maps(sort, logits, nvalid, B, S)
         sums, _ = ops.loss_fwd_bwd(logits, keys, nvalid, B, S, None, pred_row=pred_row, true_row=true_row)
         losses, scores, metrics = metrics_from_sums(self._input_columns, sums)
         self.losses = [sums[:, 0].sum()]
         self.metrics = metrics
+        self.sums = sums
         return [scores]

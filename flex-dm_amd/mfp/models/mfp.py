@@ -192,7 +192,7 @@ class MFP:
         self.model = Model(input_columns=input_columns, num_blocks=num_blocks, block_type=block_type,
                            context=context, input_dtype=input_dtype,
                            use_elemwise_noise=use_elemwise_noise, **kwargs)
-        self.loss_layer = LossLayer(input_columns)
+        self.loss_layer = LossLayer(input_columns, model_layout=self.model.layout)
         self.task_names = get_task_names(input_columns)
         self.task_probs = get_task_probs(self.task_names, masking_method)
         self._active_tasks = [i for i, p in enumerate(self.task_probs) if p > 0.0]
@@ -369,6 +369,13 @@ class MFP:
                 self.optimizer.step(grad_scale=1.0 / dp.world_size())
 
         def replay(batch):
+            if any(k in static and tuple(v.shape) != tuple(static[k].shape) for k, v in batch.items()):
+                # a batch of another shape (ragged last batch, variable S without --seq_len) cannot go
+                # through the captured graph: step it eagerly (same kernels, same semantics)
+                sums = self._forward_backward(batch)
+                self._apply()
+                self.last_sums = sums
+                return sums
             for k, v in batch.items():
                 if k in static and v.data_ptr() != static[k].data_ptr():
                     static[k].copy_(v, non_blocking=True)
@@ -392,7 +399,9 @@ class MFP:
         return replay
 
     def test_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """Keras test_step: MFP.call(training=False) still re-masks (is_demo False)."""
+        """Keras test_step: MFP.call(training=False) still re-masks (is_demo False).  Returns the
+        LossLayer sums ``[nkeys][3]`` = (loss: mean over the batch's documents, score numerator,
+        score denominator) of this batch (metrics.py:265-288)."""
         with torch.no_grad():
             B = batch["left"].shape[0]
             tasks = self.sample_tasks(B)
@@ -403,10 +412,7 @@ class MFP:
                 self.loss_layer((targets, outputs, masks), False, tasks == self.task_names.index("pos"))
             else:
                 self.loss_layer((targets, outputs, masks), False)
-            keys = loss_key_names(self._all_input_columns)
-            m = self.loss_layer.metrics
-            return torch.stack([torch.stack([m[k + "_loss"], m[k + "_score"], m[k + "_score"] * 0 + 1])
-                                for k in keys])
+            return self.loss_layer.sums
 
     @property
     def metrics_names(self) -> List[str]:
@@ -458,12 +464,22 @@ class MFP:
         return history
 
     def evaluate(self, dataset, batch_size=None, steps=None, return_dict=False):
+        """Keras ``evaluate``: every metric is the mean over batches of its per-batch value
+        (``add_metric`` aggregation "mean").  Data-parallel: each rank scores its shard of the batch
+        and the sums are all-reduced with the document counts BEFORE normalising, so every rank
+        reports the metrics of the whole batch (ragged last batches are dealt out unevenly)."""
+        keys = loss_key_names(self._all_input_columns)
         acc, n = None, 0
         for i, batch in enumerate(dataset):
             if steps is not None and i >= steps:
                 break
-            s = self.test_step(dp.shard_batch(batch))
-            acc = s.clone() if acc is None else acc + s
+            shard = dp.shard_batch(batch, even=False)
+            b_local = int(shard["length"].shape[0])
+            s = self.test_step(shard) if b_local > 0 else None
+            s = dp.allreduce_eval_sums(s, b_local, len(keys), self.model.store.device)
+            _, _, m = metrics_from_sums(self._all_input_columns, s)
+            row = torch.stack([torch.stack([m[k + "_loss"], m[k + "_score"]]) for k in keys])
+            acc = row.clone() if acc is None else acc + row
             n += 1
         res = _metrics_from_eval(self._all_input_columns, acc, n)
         if return_dict:

@@ -9,6 +9,7 @@ from typing import Dict, Optional, Union
 
 import torch
 
+from mfp import dp
 from mfp.hip.functions import DecoderLossFn, EncoderPreFn, StepCtx
 from mfp.models.architecture.decoder import Decoder, split_logits
 from mfp.models.architecture.encoder import Encoder
@@ -52,7 +53,7 @@ class Model:
     def make_ctx(self, inputs: Dict, training: bool) -> StepCtx:
         B, S = inputs[self._first].shape[:2]
         nvalid = (inputs["length"].reshape(-1) + 1).to(torch.int32)
-        return StepCtx(self.store, B, S, nvalid, training, self.dropout, self.seed, self.step_ptr,
+        return StepCtx(self.store, B, S, nvalid, training, self.dropout, dp.rank_seed(self.seed), self.step_ptr,
                        self.side_streams if training and self.side_streams else None)
 
     def hidden(self, inputs: Dict, training: bool = False, ctx: Optional[StepCtx] = None):
