@@ -8,7 +8,8 @@ Differences from the reference, both documented in SURVEY.md section 3.3:
   ``random_masking`` does not accept: eval.py:59-65 vs masking.py:227-231 -> TypeError);
 * ``--task_mode elem|random`` works (the reference reads an undefined ``group_name``:
   eval.py:99 -> NameError); the task id sent with ``context="id"`` is that of the mode itself.
-The RICO position-sorted score (``sort_flag``) is a "next" row and raises NotImplementedError.
+The RICO position-sorted score (``sort_flag``, reference metrics.py:180-211) runs on the device
+(``mfp_sort_positions`` + ``mfp_loss_fwd_bwd_sorted``) like the train step's.
 """
 import argparse
 import csv

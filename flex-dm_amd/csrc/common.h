@@ -73,6 +73,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ----------------------------------------------------------------------------- per-device caches
+// hipFuncSetAttribute and the CU count are properties of (function, device): a process that drives
+// several devices must not reuse what it learnt on the first one.  Host-side caches are indexed by
+// the current device (slot 0 for ordinals beyond the table).
+#define MFP_MAX_DEVICES 64
+inline int mfp_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MFP_MAX_DEVICES) dev = 0;
+  return dev;
+}
+
 // ----------------------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG for dropout: the keep mask of element (row, col) of an [M,N] activation is
 // philox(key = seed, ctr = (row, col>>2, offset_lo, offset_hi))[col & 3] so that the GEMM epilogue

@@ -490,7 +490,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #include "gemm_wg.h"
 
 int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
-  static int ncu = 0;
+  static int ncu_of[MFP_MAX_DEVICES] = {};
+  int& ncu = ncu_of[mfp_device_slot()];
   if (ncu == 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -517,7 +518,8 @@ template <typename T, bool AK, bool BK_, int MT, int NQ, int NBUF>
 int launch_one(const GemmParams& p0, int M, int N, int splitk, hipStream_t st) {
   using L = GemmLds<T, AK, BK_, MT, NQ, NBUF>;
   constexpr size_t lds = L::BYTES;
-  static bool attr_set = false;  // benign cache: the attribute is a per-function constant
+  static bool attr_done[MFP_MAX_DEVICES] = {};  // benign cache: the attribute is a constant per (function, device)
+  bool& attr_set = attr_done[mfp_device_slot()];
   if (lds > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, AK, BK_, MT, NQ, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

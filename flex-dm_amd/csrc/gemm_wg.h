@@ -225,7 +225,8 @@ inline bool wg_eligible(const mfp_gemm_args* a, int splitk) {
 template <bool ROWSKIP>
 inline int launch_wg_t(const GemmParams& p0, int M, int N, int splitk, hipStream_t st) {
   constexpr int lds = 2 * (2 * 64 * 136 * 2);
-  static bool attr_set = false;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wg_kernel<4, ROWSKIP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);

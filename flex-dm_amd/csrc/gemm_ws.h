@@ -412,7 +412,8 @@ template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16, bool NARROW = fa
 int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
   constexpr int NQ = (KS == 8 ? 4 : (KS == 16 ? 2 : 1)) >> (NARROW ? 1 : 0), BN = 64 * NQ, XSTAGE = 16 * MT * 64 * KS, OSTAGE = 16 * MT * BN * (OUT_BF16 ? 2 : 4);
   constexpr int lds = 2 * XSTAGE + 2 * OSTAGE;
-  static bool attr_set = false;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
   if (lds > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16, NARROW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -42,7 +42,7 @@ _TRAIN_FLAGS = [
     ("--num_epochs", dict(default=500, type=int, help="Number of epochs to train.")),
     ("--learning_rate", dict(default=1e-4, type=float, help="Base learning rate.")),
     ("--enable_profile", dict(dest="enable_profile", action="store_true",
-                              help="Enable profiling (maps to a rocprofv3/torch.profiler range).")),
+                              help="Profile the 2nd train step: roctx range + torch.profiler trace under job_dir/logs.")),
     ("--validation_freq", dict(default=10, type=int, help="Validation frequency in terms of epochs.")),
 ]
 

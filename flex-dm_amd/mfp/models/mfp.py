@@ -433,6 +433,7 @@ class MFP:
             validation_freq=1, callbacks=None, verbose=2, use_graph: bool = False):
         callbacks = callbacks or []
         history = []
+        global_step = 0
         it = iter(dataset)
         for epoch in range(epochs):
             acc, n = None, 0
@@ -445,7 +446,14 @@ class MFP:
                 batch = dp.shard_batch(batch)
                 if use_graph and self._graph is None:
                     self.capture_train_step(batch)
+                for cb in callbacks:
+                    if hasattr(cb, "on_train_batch_begin"):
+                        cb.on_train_batch_begin(global_step)
                 sums = self.train_step(batch)
+                for cb in callbacks:
+                    if hasattr(cb, "on_train_batch_end"):
+                        cb.on_train_batch_end(global_step)
+                global_step += 1
                 acc = sums.clone() if acc is None else acc + sums
                 n += 1
             logs = self.metrics_dict(_mean_sums(acc, n))

@@ -1,4 +1,5 @@
-"""``__graft_entry__.smoke()``: one small train-step-shaped invocation of the HIP hot path on
+"""``__graft_entry__.smoke()`` (test infrastructure next to the entry point, not part of the product
+package -- it imports the oracle): one small train-step-shaped invocation of the HIP hot path on
 cuda:0, checked against the CPU oracle (forward logits, per-key losses, one gradient)."""
 import numpy as np
 import torch

@@ -75,6 +75,6 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "flex-dm_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith(".py") and f != "selfcheck.py":     # selfcheck = __graft_entry__.smoke()
+            if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dirpath, f)

@@ -98,3 +98,77 @@ def test_single_process_helpers_are_noops():
     assert dp.world_size() == 1 and dp.rank() == 0
     assert dp.allreduce_gradients(t) is None and torch.equal(dp.allreduce_sums(t.view(1, 3)), t.view(1, 3))
     assert dp.shard_batch({"a": t})["a"] is t
+
+
+def _eval_worker(rank, world, port, q, B):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "flex-dm_amd")]
+    from oracle import np_ref, torch_ref
+    from mfp import dp
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    dp.init_from_env("gloo")
+    ic = make_input_columns("rico")
+    S, D, L = 6, 16, 1
+    params = torch_ref.to_torch(np_ref.init_params(ic, D, L, seed=-7), torch.float64, requires_grad=False)
+    batch = synthetic_batch(ic, B, S, seed=9, ragged=True)
+    g = torch.Generator().manual_seed(3)
+    keys = [k for k, c in ic.items() if c.get("is_sequence")]
+    masks = {k: torch.rand(B, S, generator=g) < 0.6 for k in keys}
+    shard, mshard = dp.shard_batch(batch, even=False), dp.shard_batch(masks, even=False)
+    bl = shard["length"].shape[0]
+    sums = None
+    if bl > 0:
+        out = torch_ref.model_fwd(params, ic, shard, L, maxlen=S)
+        _, losses, scores, _ = torch_ref.loss_layer(ic, shard, out, mshard, S)
+        sums = torch.tensor([[float(losses[k]), float(scores[k + "_score_num"]), float(scores[k + "_score_den"])]
+                             for k in keys], dtype=torch.float64)
+    red = dp.allreduce_eval_sums(sums, bl, len(keys), "cpu")
+    seeds = dp.rank_seed(5)
+    if rank == 0:
+        q.put((red.numpy(), bl))
+    q.put(("seed", rank, seeds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 5), (3, 2)])
+def test_evaluation_sums_over_uneven_shards_equal_the_global_batch(world, B):
+    """evaluate() deals a ragged (last) batch out unevenly -- a shard may even be empty -- and
+    all-reduces loss sums with the document counts: every rank must end up with the metrics of the
+    whole batch (rank 0 used to report 1/N of the data)."""
+    from oracle import np_ref, torch_ref
+    from mfp import dp
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    assert [dp.shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
+    assert [dp.shard_bounds(2, r, 3) for r in range(3)] == [(0, 1), (1, 2), (2, 2)]
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q, B)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, seeds = None, {}
+    for _ in range(world + 1):
+        item = q.get(timeout=240)
+        if isinstance(item[0], str):
+            seeds[item[1]] = item[2]
+        else:
+            got = item[0]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert seeds[0] == 5 and len(set(seeds.values())) == world      # rank-dependent masking/dropout streams
+    ic = make_input_columns("rico")
+    S, D, L = 6, 16, 1
+    params = torch_ref.to_torch(np_ref.init_params(ic, D, L, seed=-7), torch.float64, requires_grad=False)
+    batch = synthetic_batch(ic, B, S, seed=9, ragged=True)
+    g = torch.Generator().manual_seed(3)
+    keys = [k for k, c in ic.items() if c.get("is_sequence")]
+    masks = {k: torch.rand(B, S, generator=g) < 0.6 for k in keys}
+    out = torch_ref.model_fwd(params, ic, batch, L, maxlen=S)
+    _, losses, scores, _ = torch_ref.loss_layer(ic, batch, out, masks, S)
+    for i, k in enumerate(keys):
+        assert abs(got[i, 0] - float(losses[k])) < 1e-5 * max(1.0, abs(float(losses[k]))), k
+        assert abs(got[i, 1] - float(scores[k + "_score_num"])) < 1e-5 and abs(got[i, 2] - float(scores[k + "_score_den"])) < 1e-6

@@ -40,8 +40,15 @@ def test_train_cli_crello_bf16_graph(tmp_path):
     job = str(tmp_path / "job2")
     main(["--dataset_name", "crello", "--data_dir", "synthetic:16:32", "--job-dir", job, "--latent_dim", "128",
           "--num_blocks", "1", "--batch_size", "16", "--num_epochs", "2", "--validation_freq", "2",
-          "--masking_method", "elem_pos_attr_img_txt", "--dtype", "bf16", "--use_graph", "--verbose", "0"])
+          "--masking_method", "elem_pos_attr_img_txt", "--dtype", "bf16", "--use_graph", "--verbose", "0",
+          "--enable_profile"])
     assert os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))
+    # --enable_profile = TensorBoard(profile_batch=2) of the reference (callbacks.py:44-48): the 2nd
+    # train step is traced; its kernel table must name kernels of the HIP library
+    table = os.path.join(job, "logs", "profile_step2.kernels.txt")
+    assert os.path.exists(table) and os.path.exists(os.path.join(job, "logs", "profile_step2.trace.json"))
+    txt = open(table).read()
+    assert "gemm" in txt or "attn" in txt, txt[:2000]
 
 
 def test_train_cli_on_tfrecord_directory(tmp_path, capsys):
@@ -50,10 +57,12 @@ def test_train_cli_on_tfrecord_directory(tmp_path, capsys):
     from mfp.data.spec import write_synthetic_tfrecords
     from mfp.main import main
     data = str(tmp_path / "crello")
-    write_synthetic_tfrecords(data, "crello", {"train": 24, "val": 8, "test": 8}, seq_len=9, seed=2)
+    # 27 train documents at batch 8: batches straddle the epoch boundary (shuffle -> repeat -> batch,
+    # spec.py:244-248) and are always full; the 11 val/test documents end with a short batch
+    write_synthetic_tfrecords(data, "crello", {"train": 27, "val": 11, "test": 11}, seq_len=9, seed=2)
     job = str(tmp_path / "job3")
     main(["--dataset_name", "crello", "--data_dir", data, "--job-dir", job, "--latent_dim", "128",
-          "--num_blocks", "1", "--batch_size", "8", "--num_epochs", "1", "--validation_freq", "1",
+          "--num_blocks", "1", "--batch_size", "8", "--num_epochs", "2", "--validation_freq", "1",
           "--masking_method", "random", "--dtype", "fp32", "--verbose", "0"])
     out = capsys.readouterr().out
     assert "total_score" in out

@@ -193,7 +193,7 @@ def test_gemm_dropout_matches_dropout_bwd():
     dropped = ops.gemm(A, W, M, N, K, a_kmajor=True, b_kmajor=False, dropout=(p, seed, off))
     colsum = torch.empty(N, device=DEV)
     via_bwd = ops.dropout_bwd(plain, torch.float32, colsum, p, seed, off)
-    assert torch.equal(dropped, via_bwd)  # identical Philox stream
+    assert torch.equal(dropped, via_bwd)  # identical counter-based stream (common.h: hash RNG keyed by seed, site, step, row, column)
     keep = (dropped != 0).float().mean().item()
     assert abs(keep - (1 - p)) < 0.01
     assert_close(colsum, via_bwd.double().sum(0).cpu(), 1e-2, 1e-5, "dropout colsum")
