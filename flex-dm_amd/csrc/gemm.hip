@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 #include "gemm_ws.h"
 #include "gemm_wg.h"
+#include "gemm_wgg.h"
 
 int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
   static int ncu_of[MFP_MAX_DEVICES] = {};
@@ -664,5 +665,103 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
                        splitk, (a->flags & MFP_GEMM_ACCUM) ? 1 : 0);
     MFP_CHECK_LAUNCH();
   }
+  return MFP_OK;
+}
+
+// ------------------------------------------------------------------ grouped weight gradients
+namespace {
+int wgg_tiles(const mfp_wgrad_job* jobs, int njobs) {
+  int t = 0;
+  for (int i = 0; i < njobs; ++i) t += ((jobs[i].M + 127) / 128) * ((jobs[i].N + 127) / 128);
+  return t;
+}
+int wgg_ncu() {
+  static int ncu_of[MFP_MAX_DEVICES] = {};
+  int& ncu = ncu_of[mfp_device_slot()];
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu = n;
+  }
+  return ncu;
+}
+}  // namespace
+
+extern "C" int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs, int32_t njobs) {
+  if (jobs == nullptr || njobs < 1) return 0;
+  return wgg_tiles(jobs, njobs);
+}
+
+// Split of the token dimension: a multiple of 8 (a k-slice's tiles share an XCD) that minimises
+// waves-of-workgroups x k-tiles-per-workgroup on this device, smallest split on ties (fewer partial
+// slabs); slices of at least 256 tokens, at most WG_MAX_KCHUNK when a job masks rows (codes in LDS).
+extern "C" int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K) {
+  if (jobs == nullptr || njobs < 1 || K < 1) return 8;
+  const int tiles = wgg_tiles(jobs, njobs), ncu = wgg_ncu();
+  bool rowskip = false;
+  for (int i = 0; i < njobs; ++i) rowskip |= jobs[i].rowcode != nullptr;
+  int best = 8;
+  long long best_cost = -1;
+  for (int sk = 8; sk <= 512; sk += 8) {
+    const int kchunk = (((K + 63) / 64 + sk - 1) / sk) * 64;      // tokens of the longest cyclic k-slice
+    if (sk > 8 && kchunk < 256) break;
+    if (rowskip && kchunk > WG_MAX_KCHUNK) continue;
+    const long long waves = ((long long)tiles * sk + ncu - 1) / ncu;
+    // measured (tools/bench_wgrad.py, block group at T = 32768): 1.1 us per k-tile + 11 us per workgroup
+    // (pipeline fill, 64 KB slab store, ticket, the last arriver's read of `sk` slabs)
+    const long long cost = waves * (kchunk / 64 + 10) + sk / 8;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sk; }
+  }
+  return best;
+}
+
+extern "C" size_t mfp_wgrad_group_workspace_bytes(const mfp_wgrad_job* jobs, int32_t njobs, int32_t splitk) {
+  if (jobs == nullptr || njobs < 1 || splitk < 1) return 0;
+  return (size_t)splitk * ((size_t)wgg_tiles(jobs, njobs) * (128 * 128 + 128) + WGG_ZPAD) * sizeof(float);
+}
+
+extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int32_t splitk,
+                               void* workspace, size_t workspace_bytes, uint32_t* tickets, mfp_stream_t stream) {
+  MFP_CHECK_ARG(jobs != nullptr && njobs >= 1 && njobs <= MFP_MAX_WGRAD_JOBS && K > 0);
+  MFP_CHECK_ARG(splitk >= 8 && splitk % 8 == 0 && tickets != nullptr && workspace != nullptr);
+  WggParams p;
+  int tile0 = 0;
+  bool rowskip = false;
+  for (int i = 0; i < njobs; ++i) {
+    const mfp_wgrad_job& j = jobs[i];
+    MFP_CHECK_ARG(j.A && j.B && j.C && j.M > 0 && j.N > 0);
+    MFP_CHECK_ARG(j.M % 8 == 0 && j.N % 8 == 0 && j.lda % 8 == 0 && j.ldb % 8 == 0 && j.ldc % 4 == 0);
+    MFP_CHECK_ARG(j.lda >= j.M && j.ldb >= j.N && j.ldc >= j.N);
+    MFP_CHECK_ARG(((uintptr_t)j.A % 16) == 0 && ((uintptr_t)j.B % 16) == 0 && ((uintptr_t)j.C % 16) == 0);
+    MFP_CHECK_ARG((long long)K * j.lda * 2 < 0x7FFFFFF0ll && (long long)K * j.ldb * 2 < 0x7FFFFFF0ll);   // 32-bit offsets
+    WggJob& d = p.job[i];
+    d.A = reinterpret_cast<const unsigned short*>(j.A);
+    d.B = reinterpret_cast<const unsigned short*>(j.B);
+    d.C = j.C; d.colsum = j.colsum; d.rowcode = j.rowcode;
+    d.M = j.M; d.N = j.N; d.lda = j.lda; d.ldb = j.ldb; d.ldc = j.ldc;
+    d.tiles_n = (j.N + 127) / 128;
+    d.tile0 = tile0; d.pad_ = 0;
+    tile0 += ((j.M + 127) / 128) * d.tiles_n;
+    rowskip |= j.rowcode != nullptr;
+  }
+  for (int i = njobs; i < WGG_MAX_JOBS; ++i) { p.job[i] = p.job[0]; p.job[i].tile0 = 0x7FFFFFFF; }
+  p.njobs = njobs; p.ntiles = tile0; p.K = K; p.splitk = splitk;
+  p.nk_max = ((K + 63) / 64 + splitk - 1) / splitk;
+  if (rowskip) MFP_CHECK_ARG(p.nk_max * 64 <= WG_MAX_KCHUNK);
+  const size_t need = mfp_wgrad_group_workspace_bytes(jobs, njobs, splitk);
+  if (workspace_bytes < need) {
+    mfp_set_error("mfp_wgrad_group: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return MFP_EWORKSPACE;
+  }
+  MFP_CHECK_ARG(((uintptr_t)workspace % 16) == 0);
+  p.ws = reinterpret_cast<float*>(workspace);
+  p.zstride = (long long)p.ntiles * 128 * 128 + WGG_ZPAD;
+  p.ws_col = p.ws + (size_t)splitk * p.zstride;
+  p.tickets = tickets;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = rowskip ? launch_wgg_t<true>(p, st) : launch_wgg_t<false>(p, st);
+  if (rc != MFP_OK) return rc;
+  MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -1,0 +1,293 @@
+// Grouped streaming weight-gradient GEMM with the split-K reduction INSIDE the launch (gfx950, bf16).
+//
+// One launch computes up to WGG_MAX_JOBS independent products C_j[M_j][N_j] = A_j[K][M_j]^T B_j[K][N_j]
+// over the same token dimension K -- the four weight gradients of a DeepSVG block (reference
+// architecture/transformer.py:85-98,163-169: dWq|k|v, dWo, dW1, dW2), or the heads / encoder /
+// embedding-table gradients (decoder.py:39-43, encoder.py:74-92,156-160) -- plus their bias
+// gradients (column sums of A).
+//
+// Why grouped: one product has 4-12 output tiles of 128 x 128, so filling 256 CUs needed a 21- to
+// 64-way split of the tokens, i.e. 8-16 k-tiles per workgroup wrapped in fixed costs (pipeline fill,
+// partial-tile store) and 265 MB of f32 partials per step that a second kernel re-read (r01:
+// gemm_wg_kernel 563 us + splitk_reduce_kernel 200 us per step).  The 32 tiles of a block's four
+// products fill the chip with an 8-way split: 64 k-tiles per workgroup, 8x fewer partial bytes.
+//
+// Reduction: every workgroup stores its partial tile as a 64 KB slab ws[kz][tile], publishes it
+// (agent-scope release) and draws a ticket for the tile; the workgroup that draws the last ticket
+// acquires, sums the slabs in FIXED order kz = 0 .. splitk-1 (data-parallel replicas stay bit-identical)
+// and writes the gradient.  Placement-independent (any distribution of a tile's chunks over XCDs /
+// CUs); the ticket word is reset by the last arriver, so the ticket array stays all-zero between
+// launches.  Main loop = gemm_wg.h (4 memory waves streaming k-tiles, 4 math waves on MFMA).
+//
+// Grid: 1-D, block b -> XCD b & 7; k-slice kz = (j / ntiles) * 8 + xcd, tile = j % ntiles (j = b >> 3):
+// all tiles of a k-slice run on one XCD, so each operand panel is fetched from HBM once and re-read
+// from that XCD's L2 by the tiles that share it.  A k-slice is CYCLIC -- k-tiles kz, kz + splitk,
+// kz + 2 splitk, ... of 64 tokens -- not a contiguous chunk: with contiguous chunks the 8 XCDs walk
+// addresses a power-of-two distance (chunk x row pitch = 2-4 MB) apart in lockstep and pile onto the
+// same HBM channels (measured: 1.7 us per k-tile, 1 TB/s for the whole chip, against 0.8 us with the
+// short chunks of the ungrouped launches); cyclic slices make the chip sweep the operands front to
+// back, neighbouring XCDs on neighbouring 32-64 KB blocks.
+#pragma once
+
+constexpr int WGG_MAX_JOBS = 8;
+#ifndef MFP_WGG_XD
+#define MFP_WGG_XD 4
+#endif
+constexpr int WGG_XD = MFP_WGG_XD;   // k-tiles in flight (registers) per memory wave
+constexpr int WGG_ZPAD = 2112;   // floats: the slabs of one tile sit (ntiles * 64 KB + 8.25 KB) apart
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void wgg_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    wgg_static_for<I + 1, N>(f);
+  }
+}
+
+struct WggJob {
+  const unsigned short* A;      // bf16 [K][lda], M columns
+  const unsigned short* B;      // bf16 [K][ldb], N columns
+  float* C;                     // f32 [M][ldc]
+  float* colsum;                // f32 [M] or nullptr
+  const unsigned char* rowcode; // u8 [K] or nullptr: rows of A with a non-zero code count as zero
+  int M, N, lda, ldb, ldc, tiles_n, tile0, pad_;
+};
+
+struct WggParams {
+  WggJob job[WGG_MAX_JOBS];
+  float* ws;                    // [splitk][zstride]: partial tiles [ntiles][128 * 128] (+ pad: slabs of one tile off a power-of-two stride)
+  float* ws_col;                // [splitk][ntiles][128] partial column sums
+  unsigned int* tickets;        // [ntiles], zero on entry, zero on exit
+  long long zstride;            // floats between the slabs of consecutive k-slices
+  int njobs, ntiles, K, nk_max, splitk;   // nk_max = k-tiles of the longest k-slice
+};
+
+template <int XD, bool ROWSKIP>
+__global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
+  constexpr int BM = 128, BN = 128, BK = 64, PAD = 8, LDS_S = BM + PAD;
+  constexpr int TILE_E = BK * LDS_S;
+  constexpr int STAGE_B = 2 * TILE_E * 2;
+  constexpr int CH = BK * (BM / 8) / 256;
+  constexpr int CS_LD = BN + 4;
+  static_assert(CH == 4, "64 x 128 tile = 1024 chunks over 256 memory threads");
+  static_assert(BM * CS_LD * 4 + 16 <= 2 * STAGE_B, "output stage + the last-arriver flag alias the two operand stages");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ float colsum_s[16][BM];
+  __shared__ unsigned char rc_s[ROWSKIP ? WG_MAX_KCHUNK : 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int kz = (j / p.ntiles) * 8 + xcd, tile = j % p.ntiles;          // splitk % 8 == 0 (host)
+  int ji = 0;
+  for (int q = 1; q < p.njobs; ++q) ji = tile >= p.job[q].tile0 ? q : ji;
+  const WggJob& jb = p.job[ji];
+  const int M = jb.M, N = jb.N, lda = jb.lda, ldb = jb.ldb;
+  const int bid = tile - jb.tile0;
+  const int tm = bid / jb.tiles_n, tn = bid % jb.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int nk = kz < ktiles ? (ktiles - kz + p.splitk - 1) / p.splitk : 0;      // k-tiles kz, kz + splitk, ...
+  const int kend = p.K;
+  const bool do_colsum = jb.colsum != nullptr && tn == 0;
+  const bool skip_rows = ROWSKIP && jb.rowcode != nullptr;
+  f32x4 acc[4][4];
+  if (ROWSKIP) {
+    for (int i = tid; i < p.nk_max * BK; i += 512) {      // row codes of this slice's tokens, k-tile by k-tile
+      const int k = ((i >> 6) * p.splitk + kz) * BK + (i & 63);
+      rc_s[i] = (skip_rows && k < p.K) ? jb.rowcode[k] : 0;
+    }
+    __syncthreads();
+  }
+
+  if (wave < 4) {
+    // ======================================================================== MATH waves
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();   // prologue barrier (stage 0 filled)
+    for (int t = 0; t < nk; ++t) {
+      const unsigned short* As = reinterpret_cast<const unsigned short*>(smem_raw + (t & 1) * STAGE_B);
+      const unsigned short* Bs = As + TILE_E;
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 xf[4], wf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const unsigned short* ptr = &As[(ks * 32 + lg * 8 + (li >> 2)) * LDS_S + wm * 64 + a * 16 + (li & 3) * 4];
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDS_S));
+          xf[a] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const unsigned short* ptr = &Bs[(ks * 32 + lg * 8 + (li >> 2)) * LDS_S + wn * 64 + (li & 3) * 16 + b * 4];
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDS_S));
+          wf[b] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        *reinterpret_cast<f32x4*>(&Cs[(wm * 64 + a * 16 + li) * CS_LD + wn * 64 + lg * 16 + b * 4]) = acc[a][b];
+  } else {
+    // ====================================================================== MEMORY waves
+    const int mt = tid - 256;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(jb.A), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(jb.B), 0, 0x7FFFFFFF, 0x00020000);
+    const int krow0 = mt >> 4, ccol = (mt & 15) * 8;
+    const unsigned int abad = m0 + ccol < M ? 0u : 0xFFFFFFFFu, bbad = n0 + ccol < N ? 0u : 0xFFFFFFFFu;
+    const unsigned int voa0 = (unsigned int)((krow0 * lda + m0 + ccol) * 2);
+    const unsigned int vob0 = (unsigned int)((krow0 * ldb + n0 + ccol) * 2);
+    const int ls0 = (krow0 * LDS_S + ccol) * 2;
+    u32x4 ra[XD][CH], rb[XD][CH];
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    auto gload = [&](int set, int t) {
+      const int k0 = (t * p.splitk + kz) * BK;
+      const int live = (t - nk) >> 31;                      // -1 while t < nk
+      const int soa = (k0 * lda * 2) & live, sob = (k0 * ldb * 2) & live;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int k = k0 + krow0 + 16 * c;
+        const unsigned int kbad = ~(unsigned int)(live & ((k - kend) >> 31));
+        const unsigned int skip = (ROWSKIP && rc_s[min(t, p.nk_max - 1) * BK + krow0 + 16 * c]) ? 0xFFFFFFFFu : 0u;
+        ra[set][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsa, (voa0 + (unsigned int)(16 * c * lda * 2)) | abad | kbad | skip, soa, 0));
+        rb[set][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsb, (vob0 + (unsigned int)(16 * c * ldb * 2)) | bbad | kbad, sob, 0));
+      }
+    };
+    auto lstore = [&](int set, int stage) {
+      unsigned char* st = smem_raw + stage * STAGE_B + ls0;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        *reinterpret_cast<u32x4*>(st + 16 * c * LDS_S * 2) = ra[set][c];
+        *reinterpret_cast<u32x4*>(st + TILE_E * 2 + 16 * c * LDS_S * 2) = rb[set][c];
+        if (do_colsum) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned int w = ra[set][c][e];
+            csum[2 * e] += bf16_to_f32((unsigned short)(w & 0xffffu));
+            csum[2 * e + 1] += bf16_to_f32((unsigned short)(w >> 16));
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < XD; ++i) gload(i, i);
+    lstore(0, 0);
+    gload(0, XD);
+    __syncthreads();   // prologue barrier
+    auto step = [&](auto tc, int t) {
+      constexpr int xi = (decltype(tc)::value + 1) % XD;
+      lstore(xi, (t + 1) & 1);
+      gload(xi, t + 1 + XD);
+      __syncthreads();
+    };
+    // the step loop is unrolled by XD: register set (t + 1) % XD must be a compile-time index
+    int t = 0;
+    for (; t + XD - 1 < nk; t += XD) wgg_static_for<0, XD>([&](auto ic) { step(ic, t + decltype(ic)::value); });
+    wgg_static_for<0, XD - 1>([&](auto ic) { if (t + decltype(ic)::value < nk) step(ic, t + decltype(ic)::value); });
+    if (do_colsum) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) colsum_s[krow0][ccol + e] = csum[e];
+    }
+  }
+  __syncthreads();   // partial tile (and column sums) are in LDS
+
+  // (no further static __shared__ object: statics of a size that is not a multiple of 16 would shift the
+  // dynamic region off its 16-byte alignment and ds_read_b64_tr_b16 would silently read the wrong bytes)
+  volatile int* last_s = reinterpret_cast<volatile int*>(smem_raw + BM * CS_LD * 4);
+  // ---- publish the partial tile: slab ws[kz][tile] (whole 128 x 128, 512 B rows), then a ticket
+  const int r0 = tid >> 5, c4 = (tid & 31) * 4;
+  {
+    const float* Cs = reinterpret_cast<const float*>(smem_raw);
+    float* slab = p.ws + kz * p.zstride + (long long)tile * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+      const int row = r0 + 16 * i;
+      *reinterpret_cast<f32x4*>(slab + row * BN + c4) = *reinterpret_cast<const f32x4*>(&Cs[row * CS_LD + c4]);
+    }
+    if (do_colsum && tid < BM) {
+      float s = 0.f;
+#pragma unroll
+      for (int gI = 0; gI < 16; ++gI) s += colsum_s[gI][tid];
+      p.ws_col[((long long)kz * p.ntiles + tile) * BM + tid] = s;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back must have left before the ticket is drawn
+    const unsigned int ticket = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == (unsigned int)(p.splitk - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+    }
+    *last_s = last;
+  }
+  __syncthreads();
+  if (!*last_s) return;
+
+  // ---- last arriver: C[m][n] = sum over kz (ascending) of the slabs; colsum likewise
+  {
+    const long long zstride = p.zstride;
+    const float* slab0 = p.ws + (long long)tile * (BM * BN);
+#pragma unroll 2
+    for (int i = 0; i < BM / 16; ++i) {
+      const int row = r0 + 16 * i;
+      const float* src = slab0 + row * BN + c4;
+      f32x4 s = *reinterpret_cast<const f32x4*>(src);
+      for (int z0 = 1; z0 < p.splitk; z0 += 7) {      // 7 slabs in flight, summed in ascending order
+        f32x4 v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+          v[u] = z0 + u < p.splitk ? *reinterpret_cast<const f32x4*>(src + (z0 + u) * zstride) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+          if (z0 + u < p.splitk) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; s[3] += v[u][3]; }
+      }
+      if (m0 + row < M && n0 + c4 < N)
+        *reinterpret_cast<f32x4*>(jb.C + (long long)(m0 + row) * jb.ldc + n0 + c4) = s;
+    }
+    if (do_colsum && tid < BM && m0 + tid < M) {
+      float s = 0.f;
+      for (int z = 0; z < p.splitk; ++z) s += p.ws_col[((long long)z * p.ntiles + tile) * BM + tid];
+      jb.colsum[m0 + tid] = s;
+    }
+  }
+}
+
+template <bool ROWSKIP>
+inline int launch_wgg_t(const WggParams& p, hipStream_t st) {
+  constexpr int lds = 2 * (2 * 64 * 136 * 2);
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgg_kernel<WGG_XD, ROWSKIP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_wgrad_group: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_wgg_kernel<WGG_XD, ROWSKIP>), dim3(p.ntiles * p.splitk), dim3(512), lds, st, p);
+  return MFP_OK;
+}

@@ -42,6 +42,13 @@ class GemmArgs(Structure):
     ]
 
 
+class WgradJob(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("colsum", c_void_p), ("rowcode", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
+    ]
+
+
 class ReduceJob(Structure):
     _fields_ = [
         ("part", c_void_p), ("out0", c_void_p), ("out1", c_void_p), ("out2", c_void_p),
@@ -73,6 +80,10 @@ SIGNATURES = {
     "mfp_version": (c_int32, []),
     "mfp_gemm": (c_int32, [POINTER(GemmArgs), c_void_p]),
     "mfp_gemm_workspace_bytes": (c_size_t, [POINTER(GemmArgs)]),
+    "mfp_wgrad_group_tiles": (c_int32, [POINTER(WgradJob), c_int32]),
+    "mfp_wgrad_group_splitk": (c_int32, [POINTER(WgradJob), c_int32, c_int32]),
+    "mfp_wgrad_group_workspace_bytes": (c_size_t, [POINTER(WgradJob), c_int32, c_int32]),
+    "mfp_wgrad_group": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mfp_layernorm_fwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_int32, c_void_p]),
     "mfp_layernorm_bwd": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                     c_float, c_uint64, c_uint64, c_void_p, c_void_p]),

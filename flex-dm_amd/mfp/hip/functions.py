@@ -21,6 +21,9 @@ import torch
 from . import ops
 
 NUM_HEADS = 8
+# bf16 path: the weight gradients of a block (of the heads, of the encoder) as ONE grouped launch with the
+# split-K reduction inside it (csrc/gemm_wgg.h); 0 = one mfp_gemm + reduce kernel per product (A/B switch)
+WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
 
 
 class StepCtx:
@@ -107,6 +110,22 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     if L.num_keys or onehot:
         dh_c = ctx.dh_c if (ctx.dh_c is not None and ctx.dh_c.shape == dh.shape) else ctx.to_cdt(dh)
         ctx.dh_c = None
+        if onehot and WGRAD_GROUP:
+            # the last products of the backward pass -- both encoder Dense gradients (+ biases) and the
+            # table gradient -- as ONE grouped launch on the main stream (nothing is left to overlap)
+            ctx.flush_ln_jobs()
+            if ctx.onehot is None:
+                ctx.onehot = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
+            elif len(ctx.sides) > 2:   # built on side stream 2 during the forward pass
+                torch.cuda.current_stream().wait_stream(ctx.sides[2])
+            jobs = [dict(A=dh_c, B=xs[j], out=st.grad("encoder/input_%s/kernel" % k), M=D, N=xs[j].shape[1],
+                         rowskip=codes[j], colsum=st.grad("encoder/input_%s/bias" % k))
+                    for j, k in enumerate(L.num_keys)]
+            jobs.append(dict(A=ctx.onehot, B=dh_c, out=st.tables_padded(st.g), M=L.table_rows_pad, N=D))
+            ops.wgrad_group(jobs, T)
+            ctx.onehot = None
+            ctx.join_side()
+            return
 
         # the last products of the backward pass: nothing on the main stream overlaps them any more,
         # so the independent ones go to different side streams and share the chip
@@ -264,12 +283,15 @@ class BlockFn(torch.autograd.Function):
         dh = ops.gemm(d_o2, wt if wt is not None else st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True,
                       b_kmajor=wt is not None, out_dtype=cdt, relu_bwd_aux=h)
 
+        grouped = WGRAD_GROUP and cdt == torch.bfloat16
+
         def wgrads_mlp():
             ops.gemm(d_o2, h, D, 2 * D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_1/kernel"),
                      splitk=sk(T, D, 2 * D))
             ops.gemm(dh, y2, 2 * D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_0/kernel"),
                      colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
-        ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
+        if not grouped:
+            ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
         wt = st.cwt(p + "mlp/dense_0/kernel")     # [D][2D]
         dy2 = ops.gemm(dh, wt if wt is not None else st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True,
                        b_kmajor=wt is not None, out_dtype=cdt)
@@ -290,7 +312,18 @@ class BlockFn(torch.autograd.Function):
             ops.gemm(dqkv, y1, 3 * D, D, T, a_kmajor=False, b_kmajor=False,
                      out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D),
                      colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D), splitk=sk(T, 3 * D, D))
-        ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
+        def wgrads_block():   # the four weight gradients (+ two bias gradients) of the block: one launch
+            ops.wgrad_group([
+                dict(A=dqkv, B=y1, out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D), M=3 * D, N=D,
+                     colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D)),
+                dict(A=dh, B=y2, out=st.grad(p + "mlp/dense_0/kernel"), M=2 * D, N=D,
+                     colsum=st.grad(p + "mlp/dense_0/bias")),
+                dict(A=d_o2, B=h, out=st.grad(p + "mlp/dense_1/kernel"), M=D, N=2 * D),
+                dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)], T)
+        if grouped:
+            ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1)
+        else:
+            ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
         wt = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
         dy1 = ops.gemm(dqkv, wt if wt is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
                        3 * D, a_kmajor=True, b_kmajor=wt is not None, out_dtype=cdt)
@@ -330,6 +363,10 @@ def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Ten
     first = next(iter(L.columns))
     T, D, U = ctx.T, L.D, L.Upad
     def wgrad_heads():
+        if WGRAD_GROUP and dl_c.dtype == torch.bfloat16:
+            ops.wgrad_group([dict(A=dl_c, B=h_c, out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
+                                  M=U, N=D, colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U))], T)
+            return
         ops.gemm(dl_c, h_c, U, D, T, a_kmajor=False, b_kmajor=False,
                  out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
                  colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U), splitk=ops.wgrad_splitk(T, U, D))

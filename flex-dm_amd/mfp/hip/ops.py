@@ -14,7 +14,7 @@ import torch
 
 from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_A, GEMM_DROPOUT, GEMM_RELU, GEMM_RELU_BWD,
                GEMM_RESIDUAL, GEMM_ROWSKIP, GEMM_ROWSKIP_A, MFP_BF16, MFP_F32, GemmArgs, LossKey,
-               MaskCol, check, load)
+               MaskCol, WgradJob, check, load)
 
 _DT = {torch.float32: MFP_F32, torch.bfloat16: MFP_BF16}
 
@@ -175,6 +175,52 @@ def wgrad_splitk(T: int, M: int, N: int) -> int:
     while sk > 1 and T // sk < 256:
         sk //= 2
     return sk
+
+
+# ---------------------------------------------------------------- grouped weight gradients
+_tickets: Dict[tuple, torch.Tensor] = {}
+WGRAD_MAX_TILES = 4096
+
+
+def _wgrad_tickets(device) -> torch.Tensor:
+    """Per (device, stream) ticket words of the in-launch split-K reduction: zero before the first
+    launch, left zero by every launch; launches on different streams may overlap, so each stream has
+    its own (like the workspaces)."""
+    key = (torch.device(device), torch.cuda.current_stream().cuda_stream)
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(WGRAD_MAX_TILES, dtype=torch.int32, device=device)
+    return t
+
+
+def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None) -> None:
+    """``out_j[M_j, N_j] = A_j[K, M_j]^T @ B_j[K, N_j]`` (+ ``colsum_j[M_j] = sum_k A_j``) for up to 8 jobs
+    in ONE launch -- see ``mfp_wgrad_group`` in include/mfp_hip.h.  jobs: dicts with A, B (bf16
+    [K, ld]), out (f32 [M, ldc] view), M, N and optionally colsum (f32 [M]), rowskip (u8 [K])."""
+    lib = load()
+    n = len(jobs)
+    arr = (WgradJob * n)()
+    flops = nbytes = 0
+    for i, j in enumerate(jobs):
+        A, B, out = j["A"], j["B"], j["out"]
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and out.dtype == torch.float32
+        assert A.shape[0] == K and B.shape[0] == K and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(-1) == 1
+        a = arr[i]
+        a.A, a.B, a.C = _ptr(A), _ptr(B), _ptr(out)
+        a.colsum, a.rowcode = _ptr(j.get("colsum")), _ptr(j.get("rowskip"))
+        a.M, a.N = j["M"], j["N"]
+        a.lda, a.ldb = A.stride(0), B.stride(0)
+        a.ldc = out.stride(0) if out.dim() == 2 else j["N"]
+        flops += 2 * K * a.M * a.N
+        nbytes += K * (a.M + a.N) * 2 + a.M * a.N * 4
+    dev = jobs[0]["A"].device
+    if splitk is None:
+        splitk = lib.mfp_wgrad_group_splitk(arr, n, K)
+    assert lib.mfp_wgrad_group_tiles(arr, n) <= WGRAD_MAX_TILES
+    ws = workspace(lib.mfp_wgrad_group_workspace_bytes(arr, n, splitk), dev)
+    with _timed("gemm_wgg_kernel", flops, nbytes):
+        check(lib.mfp_wgrad_group(arr, n, K, splitk, ws.data_ptr(), ws.numel(), _wgrad_tickets(dev).data_ptr(),
+                                  _stream()), "mfp_wgrad_group")
 
 
 # ------------------------------------------------------------------------------- LayerNorm

@@ -92,6 +92,35 @@ typedef struct mfp_gemm_args {
 int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);
 size_t mfp_gemm_workspace_bytes(const mfp_gemm_args* args /*host*/);
 
+/* ---------------------------------------------------------------- grouped weight gradients
+ * Up to MFP_MAX_WGRAD_JOBS products C_j[M_j][N_j] = A_j[K][M_j]^T B_j[K][N_j] over the SAME token
+ * dimension K in ONE launch, with the split-K reduction inside the launch (last arriver per output
+ * tile sums the partial slabs in a fixed order) -- the weight / bias gradients of the Dense layers
+ * of one DeepSVG block (transformer.py:85-98,163-169), of the decoder heads (decoder.py:39-43) or
+ * of the encoder (encoder.py:74-92,156-160: Dense kernels and, through the one-hot count matrix,
+ * the embedding tables).  bf16 operands, f32 results.
+ *   A bf16 [K][lda] (gradient side), B bf16 [K][ldb] (activation side), C f32 [M][ldc];
+ *   colsum f32 [M] or NULL: column sums of A (bias gradient); rowcode u8 [K] or NULL: rows of A
+ *   whose code is non-zero count as zero rows (encoder.py:174-175).
+ *   M, N, lda, ldb % 8 == 0; ldc % 4 == 0; splitk % 8 == 0 (mfp_wgrad_group_splitk picks it);
+ *   tickets: uint32 [>= mfp_wgrad_group_tiles()] owned by the caller, ALL ZERO before the first
+ *   launch that uses them; the launch leaves them zero.  Launches that may run concurrently (other
+ *   streams) need their own workspace and tickets. */
+#define MFP_MAX_WGRAD_JOBS 8
+typedef struct mfp_wgrad_job {
+  const void* A;
+  const void* B;
+  float* C;
+  float* colsum;
+  const uint8_t* rowcode;
+  int32_t M, N, lda, ldb, ldc;
+} mfp_wgrad_job;
+int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs /*host*/, int32_t njobs);
+int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K);
+size_t mfp_wgrad_group_workspace_bytes(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t splitk);
+int mfp_wgrad_group(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t splitk,
+                    void* workspace, size_t workspace_bytes, uint32_t* tickets, mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- LayerNorm
  * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
  * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.

@@ -652,3 +652,59 @@ def test_gemm_streaming_wgrad(M, N, T, sk):
     ops.gemm(A.to(DEV, torch.bfloat16), Bm.to(DEV, torch.bfloat16), M, N, T, a_kmajor=False, b_kmajor=False, out=out2,
              splitk=sk)
     assert_close(out2, A.double().t() @ Bm.double(), 2e-4 * math.sqrt(T), 1e-5, "streaming wgrad plain")
+
+
+@pytest.mark.parametrize("T,splitk", [(4096, None), (1100, 8), (32768, None), (8192, 16)])
+def test_wgrad_group(T, splitk):
+    """mfp_wgrad_group: several products over the same tokens in one launch with the split-K reduction
+    inside it (last arriver per tile sums the slabs).  Ragged tiles (M = 344, 1384, N = 72), ragged
+    last k-tiles, bias-gradient column sums, masked rows, strided operand views (A and B of one job are
+    column slices of wider matrices, as dqkv / the one-hot matrix are), outputs with ldc > N; against a
+    double reference.  Launched three times on the same ticket words: results must be BIT-identical
+    (fixed summation order, tickets left zero)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(T)
+    shapes = [(256, 512, True, False), (344, 256, False, False), (1384, 256, True, False), (136, 72, True, True),
+              (768, 256, True, False)]
+    if T > 8192:   # the timed token count: block-shaped jobs + the encoder tail (masked rows, ragged table tiles)
+        shapes = [(256, 512, True, True), (344, 256, False, False), (768, 256, True, False), (512, 256, True, False)]
+    wide_a = bf16_round(torch.randn(T, 2048, generator=g)).to(DEV, torch.bfloat16)
+    wide_b = bf16_round(torch.randn(T, 1024, generator=g)).to(DEV, torch.bfloat16)
+    code = (torch.rand(T, generator=g) < 0.25).to(torch.uint8).to(DEV)
+    jobs, want = [], []
+    ca = cb = 0
+    for M, N, cs, skip in shapes:
+        if ca + M > 2048:
+            ca = 0
+        if cb + N > 1024:
+            cb = 0
+        A, Bm = wide_a[:, ca:ca + M], wide_b[:, cb:cb + N]
+        ca, cb = ca + (M + 7) // 8 * 8, cb + N
+        out = torch.full((M, N + 8), 7.0, device=DEV)[:, :N]
+        j = dict(A=A, B=Bm, out=out, M=M, N=N)
+        keep = torch.ones(T, 1, dtype=torch.float64)
+        if cs:
+            j["colsum"] = torch.full((M,), 7.0, device=DEV)
+        if skip:
+            j["rowskip"] = code
+            keep = (code.cpu() == 0).double()[:, None]
+        jobs.append(j)
+        Ad = A.cpu().double() * keep
+        want.append((Ad.t() @ Bm.cpu().double(), Ad.sum(0)))
+    runs = []
+    for _ in range(3):
+        for j in jobs:
+            j["out"].fill_(7.0)
+        ops.wgrad_group(jobs, T, splitk)
+        torch.cuda.synchronize()
+        runs.append([(j["out"].clone(), j["colsum"].clone() if "colsum" in j else None) for j in jobs])
+    tol = 2e-4 * math.sqrt(T)
+    for j, (w, wc), (o, c) in zip(jobs, want, runs[0]):
+        assert_close(o, w, tol, 1e-5, "grouped wgrad %dx%d" % (j["M"], j["N"]))
+        if c is not None:
+            assert_close(c, wc, tol, 1e-5, "grouped bias gradient %d" % j["M"])
+        assert (j["out"]._base[:, j["N"]:] == 7.0).all()          # nothing written beyond N
+    for r in runs[1:]:
+        for (o0, c0), (o, c) in zip(runs[0], r):
+            assert torch.equal(o0, o) and (c0 is None or torch.equal(c0, c))
+    assert int(ops._wgrad_tickets(DEV).abs().sum()) == 0

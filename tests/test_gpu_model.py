@@ -489,3 +489,37 @@ def test_timed_shape_parity_vs_oracle(dtype, mix, B):
         assert rel <= BF16_LOSS_BUDGET, rel
         assert max(key_rel.values()) <= 3 * BF16_LOSS_BUDGET, key_rel
         assert worst_cos > 0.98
+
+
+def test_grouped_wgrad_equals_per_product_path():
+    """bf16 step at the timed widths: every parameter gradient from the grouped weight-gradient launches
+    (csrc/gemm_wgg.h: split-K reduction inside the launch) against the per-product mfp_gemm + reduce
+    path on the same batch, masks and dropout streams -- they differ only in f32 summation order."""
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.hip import functions
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    B, S = 64, 128
+    batch = synthetic_batch(ic, B, S, seed=3, ragged=True, device=DEV)
+    grads = []
+    old = functions.WGRAD_GROUP
+    try:
+        for grouped in (False, True):
+            functions.WGRAD_GROUP = grouped
+            model = MFP(ic, num_blocks=4, latent_dim=256, dropout=0.1, l2=1e-2, masking_method="random",
+                        dtype="bf16", device=DEV)
+            model.compile(learning_rate=1e-3)
+            model.model.store.g.fill_(float("nan"))
+            sums = model._forward_backward(batch)
+            torch.cuda.synchronize()
+            grads.append((model.model.store.grads_state_dict(), sums.clone()))
+    finally:
+        functions.WGRAD_GROUP = old
+    (g0, s0), (g1, s1) = grads
+    assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-5)
+    for name, a in g0.items():
+        b = g1[name]
+        assert torch.isfinite(b).all(), name
+        scale = a.abs().max().item()
+        err = (a - b).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-7, (name, err, scale)
