@@ -1,24 +1,37 @@
 #!/usr/bin/env python
 """Benchmark of the MFP train-step hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
 Metric (BASELINE.json): elements/sec of the train step (masking -> forward -> masked losses ->
-backward -> [RCCL all-reduce] -> clipnorm + L2 + Keras Adam) on Crello-shaped synthetic batches,
-seq_len=128, d_model=256, 4 blocks, B=256 documents per GPU (weak scaling), bf16 MFMA operands
-with f32 accumulation.  One "element" = one sequence slot of a document.  Inputs are resident in
-HBM before the timed region.  For N>1 the driver launches this file under
-``python -m torch.distributed.run`` (one rank per GPU, RCCL); run directly with --gpus N>1 it
-re-launches itself that way.  Rank 0 prints ONE JSON line.
+backward -> [RCCL all-reduce] -> clipnorm + L2 + Keras Adam) on Crello-shaped synthetic batches.
+One "element" = one sequence slot of a document.  Inputs are resident in HBM before the timed
+region.  For N>1 the driver launches this file under ``python -m torch.distributed.run`` (one rank
+per GPU, RCCL); run directly with --gpus N>1 it re-launches itself that way.  Rank 0 prints ONE
+JSON line.
+
+Configurations (BASELINE.json `configs`, SURVEY.md section 8 shorthand; documents per GPU are fixed as
+N grows = weak scaling):
+  c2 (default; the configuration the metric is quoted on)  Crello Ours-IMP: masking_method=random,
+     d_model 256, 4 blocks, seq_len 128, 256 documents/GPU, bf16 MFMA operands + f32 accumulation
+  c3  c2 with masking_method=elem_pos_attr_img_txt (Ours-EXP: all five task types active)
+  c4  c2 with 128 documents/GPU (global batch 1024 at --gpus 8)
+  c5  Crello Ours-EXP-FT shape: d_model 512, 8 blocks, seq_len 256, 64 documents/GPU
 
 Extra objects on the line (prompt section 4):
-  roofline     - dominant kernel (by summed duration over a step) measured with HIP events on
-                 the launch stream in instrumented eager steps of the same workload: algorithmic
-                 FLOPs (2*M*N*K per GEMM launch) / summed duration vs the 2.5 PFLOP/s dense bf16
-                 MFMA peak.  `step` gives the whole-step figure from SURVEY.md section 8d
-                 (17 320 960 algorithmic FLOP per element).
-  cpu_baseline - the oracle's eager torch-CPU restatement of the same train step (kind "port";
-                 the TensorFlow reference cannot run here) on a bounded sample, host cores.
+  roofline     - the kernel FAMILY with the largest summed duration in a step, measured with HIP events
+                 on the launch stream in instrumented eager steps of the same workload: algorithmic
+                 bytes (and FLOPs) per launch / average launch duration against the HBM (and MFMA) roof;
+                 `traffic` = PMC HBM bytes per launch of the same family (profiles/r02_pmc_traffic.json,
+                 collected by tools/pmc_step.sh over this same command); `encoder_block` = all kernels
+                 of the DeepSVG blocks (forward, backward, weight gradients) summed -- the quantity
+                 north_star's MFMA-utilisation target is stated on; `step` = whole-step MFMA fraction
+                 (17 320 960 algorithmic FLOP per element at c2).
+  cpu_baseline - the oracle's eager torch-CPU restatement of the same train step (kind "port"; the
+                 TensorFlow reference cannot run here) on a bounded sample, host cores.
+  bf16_loss_rel_dev - |loss(bf16 path) - loss(f32 path)| / loss(f32 path) on the first timed-size batch
+                 (same masks, same dropout streams); the f32 path is parity-tested against the f64
+                 oracle to 1e-5 at this shape (tests/test_gpu_model.py).
 """
 import argparse
 import json
@@ -31,9 +44,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "flex-dm_amd"))
 
-B_PER_GPU, SEQ_LEN, D_MODEL, NUM_BLOCKS = 256, 128, 256, 4
+CONFIGS = {
+    "c2": dict(name="Crello Ours-IMP", masking_method="random", D=256, L=4, S=128, B=256, dtype="bf16"),
+    "c3": dict(name="Crello Ours-EXP", masking_method="elem_pos_attr_img_txt", D=256, L=4, S=128, B=256, dtype="bf16"),
+    "c4": dict(name="Crello Ours-IMP (global batch 1024 at 8 GPUs)", masking_method="random", D=256, L=4, S=128, B=128,
+               dtype="bf16"),
+    "c5": dict(name="Crello Ours-EXP-FT shape", masking_method="elem_pos_attr_img_txt", D=512, L=8, S=256, B=64,
+               dtype="bf16"),
+}
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def train_flops_per_element(D, L, S, U, n_num):
@@ -41,35 +62,45 @@ def train_flops_per_element(D, L, S, U, n_num):
     return 3 * L * (16 * D * D + 4 * S * D) + 2 * (2 * n_num * 512 * D) + 3 * (2 * D * U)
 
 
+def block_flops_per_element(D, L, S):
+    """The DeepSVG blocks alone (forward + both gradients): 3*L*(16 D^2 + 4 S D)."""
+    return 3 * L * (16 * D * D + 4 * S * D)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="override the configuration's compute dtype")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--masking_method", default="random")
-    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="documents per GPU")
+    ap.add_argument("--masking_method", default=None, help="override the configuration's task mix")
+    ap.add_argument("--batch", type=int, default=None, help="documents per GPU (override)")
     return ap.parse_args()
 
 
-def pmc_traffic_per_launch(kernel):
-    """HBM bytes per launch of `kernel` from the L2 memory-side counters (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes over this same bench command, FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md; tools/pmc_step.sh writes the file).  None when not collected."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def family(kernel_name):
+    return kernel_name.split("<")[0].split("(")[0]
+
+
+def pmc_traffic(fam):
+    """(HBM bytes per launch, launches per step) of kernel family `fam` from the L2 memory-side counters
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command,
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md; tools/pmc_step.sh writes the
+    file).  Bytes and launches come from the SAME file: one denominator.  None when not collected."""
     try:
-        table = json.load(open(path))["kernels"]
+        table = json.load(open(PMC_FILE))["kernels"]
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
     tot, calls = 0.0, 0.0
     for k, v in table.items():
-        if k.startswith(kernel.split("<")[0]) and (kernel.startswith("gemm_w") or k == kernel):
+        if family(k) == fam:
             tot += (v["read_mb"] + v["write_mb"]) * 1e6
             calls += v["calls_per_step"]
-    return tot / calls if calls else None
+    return (tot / calls, calls) if calls else (None, None)
 
 
 def measured_peaks(device):
@@ -102,27 +133,72 @@ def measured_peaks(device):
     return out
 
 
-def cpu_baseline(ic, budget_s=12.0):
-    """Oracle (checker only) timed as the CPU baseline: same train step, eager torch-CPU f32."""
+def _cpu_steps(ic, D, L, S, B, budget_s, min_steps=2, max_steps=200):
     import torch
     from oracle import np_ref, torch_ref
     from mfp.data.spec import synthetic_batch
-    B = 16
-    params = np_ref.init_params(ic, D_MODEL, NUM_BLOCKS, seed=0)
+    params = np_ref.init_params(ic, D, L, seed=0)
     state = torch_ref.TrainState(params, lr=1e-4, l2=1e-2)
-    batch = synthetic_batch(ic, B, SEQ_LEN, seed=0)
+    batch = synthetic_batch(ic, B, S, seed=0)
     gen = torch.Generator().manual_seed(0)
-    torch_ref.train_step(state, ic, batch, NUM_BLOCKS, rate=0.1, gen=gen, maxlen=SEQ_LEN)  # warm-up
+    torch_ref.train_step(state, ic, batch, L, rate=0.1, gen=gen, maxlen=S)  # warm-up
     n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < budget_s and n < 200):
-        torch_ref.train_step(state, ic, batch, NUM_BLOCKS, rate=0.1, gen=gen, maxlen=SEQ_LEN)
+    while n < min_steps or (time.time() - t0 < budget_s and n < max_steps):
+        torch_ref.train_step(state, ic, batch, L, rate=0.1, gen=gen, maxlen=S)
         n += 1
     dt = time.time() - t0
-    return {"value": B * SEQ_LEN * n / dt, "unit": "elements/s", "cores": torch.get_num_threads(),
-            "kind": "port", "ms_per_step": 1e3 * dt / n,
-            "sample": "%d train steps of the eager torch-CPU f32 restatement (oracle/torch_ref.py), Crello "
-                      "D=%d L=%d S=%d, B=%d documents/step (B reduced from 256 to bound the sample), "
-                      "dropout 0.1, masking_method=random" % (n, D_MODEL, NUM_BLOCKS, SEQ_LEN, B)}
+    return B * S * n / dt, 1e3 * dt / n, n
+
+
+def cpu_baseline(ic, cfg):
+    """Oracle (checker only) timed as the CPU baseline: same train step, eager torch-CPU f32
+    (BASELINE.md section 2: the bench configuration at B=32, all host threads; the same on ONE thread;
+    and config c1 -- the reference's own CPU-runnable case -- on all threads).  ~25 s of CPU work."""
+    import torch
+    from mfp.data.spec import make_input_columns
+    D, L, S = cfg["D"], cfg["L"], cfg["S"]
+    threads = torch.get_num_threads()
+    B = 32 if D <= 256 else 8
+    v, ms, n = _cpu_steps(ic, D, L, S, B, budget_s=9.0)
+    out = {"value": v, "unit": "elements/s", "cores": threads, "kind": "port", "ms_per_step": ms,
+           "sample": "%d train steps of the eager torch-CPU f32 restatement (oracle/torch_ref.py), Crello "
+                     "D=%d L=%d S=%d, B=%d documents/step (B reduced from %d to bound the sample), "
+                     "dropout 0.1, masking_method=random" % (n, D, L, S, B, cfg["B"])}
+    try:
+        torch.set_num_threads(1)
+        v1, ms1, n1 = _cpu_steps(ic, D, L, S, 2, budget_s=6.0, min_steps=1)
+        out["one_thread"] = {"value": v1, "unit": "elements/s", "cores": 1, "ms_per_step": ms1,
+                             "sample": "%d steps, B=2 documents/step, same shape" % n1}
+    finally:
+        torch.set_num_threads(threads)
+    ric = make_input_columns("rico")
+    vc, msc, nc = _cpu_steps(ric, 128, 2, 32, 8, budget_s=4.0)
+    out["c1"] = {"value": vc, "unit": "elements/s", "cores": threads, "ms_per_step": msc,
+                 "sample": "%d steps of BASELINE config c1: RICO masking_method=random, 2 blocks, d_model=128, "
+                           "seq_len=32, batch=8" % nc}
+    return out
+
+
+def bf16_deviation(ic, cfg, batch, masking_method, device):
+    """Loss of the bf16 path against the f32 (exact-f32 MFMA) path on the same batch, masks and
+    dropout streams at step 0 (forward only)."""
+    import torch
+    from mfp.models.mfp import MFP
+    losses = {}
+    for dt in ("fp32", "bf16"):
+        m = MFP(ic, num_blocks=cfg["L"], latent_dim=cfg["D"], dropout=0.1, l2=1e-2, masking_method=masking_method,
+                dtype=dt, device=device, seed=0)
+        m.compile(learning_rate=1e-4, clipnorm=1.0)
+        with torch.no_grad():
+            _, sums, _ = m._forward(batch)
+        m._join_sides()
+        torch.cuda.synchronize()
+        losses[dt] = sums[:, 0].double().cpu()
+        del m
+    f, b = losses["fp32"], losses["bf16"]
+    tot = float(f.sum())
+    return {"bf16_loss_rel_dev": abs(float(b.sum()) - tot) / tot,
+            "bf16_worst_key_loss_rel_dev": float(((b - f).abs() / f.abs().clamp(min=1e-3 * tot)).max())}
 
 
 def main():
@@ -142,6 +218,13 @@ def main():
     from mfp.hip import ops
     from mfp.models.mfp import MFP
 
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    dtype = args.dtype or cfg["dtype"]
+    masking_method = args.masking_method or cfg["masking_method"]
+    D, NB, S, B = cfg["D"], cfg["L"], cfg["S"], cfg["B"]
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
@@ -153,10 +236,12 @@ def main():
     torch.manual_seed(1234 + rank)
 
     ic = make_input_columns("crello")
-    B, S = args.batch, SEQ_LEN
     batch = synthetic_batch(ic, B, S, seed=rank, ragged=False, device=device)
-    model = MFP(ic, num_blocks=NUM_BLOCKS, latent_dim=D_MODEL, dropout=0.1, l2=1e-2,
-                masking_method=args.masking_method, dtype=args.dtype, device=device, seed=0)
+    extra = {}
+    if dtype == "bf16" and rank == 0 and not args.no_roofline:
+        extra = bf16_deviation(ic, cfg, batch, masking_method, device)
+    model = MFP(ic, num_blocks=NB, latent_dim=D, dropout=0.1, l2=1e-2,
+                masking_method=masking_method, dtype=dtype, device=device, seed=0)
     model.compile(learning_rate=1e-4, clipnorm=1.0)
     dp.broadcast_parameters(model.model.store.w)
     model.model.store.refresh_shadow()
@@ -208,26 +293,26 @@ def main():
         in_sync = bool(torch.equal(lo, hi)) and bool(torch.isfinite(w).all())
 
     value = world * B * S * args.steps / elapsed
-    L = model.model.layout
-    fpe = train_flops_per_element(D_MODEL, NUM_BLOCKS, S, L.U, len(L.num_keys))
+    lay = model.model.layout
+    fpe = train_flops_per_element(D, NB, S, lay.U, len(lay.num_keys))
     step_tflops = value / world * fpe / 1e12   # per GPU
     out = {
         "metric": "elements_per_sec_train_step", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": "Crello Ours-%s train step (masking_method=%s): d_model=%d, %d DeepSVG blocks, "
-                               "seq_len=%d, %d documents/GPU, dropout 0.1, l2 1e-2, Adam lr 1e-4 clipnorm 1.0"
-                               % ("IMP" if args.masking_method == "random" else "EXP", args.masking_method, D_MODEL,
-                                  NUM_BLOCKS, S, B),
-                   "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
+        "vs_baseline": None, "dtype": "bf16" if dtype == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "%s (%s) train step, masking_method=%s: d_model=%d, %d DeepSVG blocks, seq_len=%d, "
+                               "%d documents/GPU, dropout 0.1, l2 1e-2, Adam lr 1e-4 clipnorm 1.0"
+                               % (cfg["name"], args.config, masking_method, D, NB, S, B),
+                   "name": args.config, "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay" if graphed else "eager",
-                   "params": L.numel, "train_flop_per_element": fpe},
+                   "params": lay.numel, "train_flop_per_element": fpe},
         "final_loss": metrics["loss"],
         "params_in_sync": in_sync,
     }
+    out.update(extra)
 
-    # ---------------- roofline of the dominant kernel: HIP events on the launch stream, eager steps
+    # ---------------- roofline of the dominant kernel family: HIP events on the launch stream, eager steps
     if not args.no_roofline and rank == 0:
         model._graph = None
         model.train_step(batch)
@@ -237,14 +322,16 @@ def main():
         for _ in range(nprof):
             model.train_step(batch)
         recs = ops.stop_profile()
-        agg = {}
-        for name, flops, nbytes, ms in recs:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        agg, blk = {}, [0.0, 0.0, 0.0]
+        for name, flops, nbytes, ms, scope in recs:
+            a = agg.setdefault(family(name), [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += flops; a[2] += nbytes; a[3] += ms
+            if scope == "block":
+                blk[0] += flops; blk[1] += nbytes; blk[2] += ms
         total_ms = sum(a[3] for a in agg.values())
         table = sorted(agg.items(), key=lambda kv: -kv[1][3])
         name, (cnt, flops, nbytes, ms) = table[0]
-        # every kernel of this path is a skinny product or an element stream: price the dominant one
+        # every kernel of this path is a skinny product or an element stream: price the dominant family
         # against BOTH roofs and report the one it is closer to (the binding roof)
         tf = flops / (ms * 1e-3) / 1e12
         gbs = nbytes / (ms * 1e-3) / 1e9
@@ -256,9 +343,23 @@ def main():
             roof = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": f_mfma, "hbm_frac": f_hbm}
         roof["algorithmic_bytes_per_launch"] = nbytes / cnt
-        roof["traffic"] = pmc_traffic_per_launch(name)
-        roof.update({"launches_per_step": cnt // nprof, "avg_launch_us": 1e3 * ms / cnt,
+        roof["launches_per_step"] = cnt / nprof
+        traffic, pmc_calls = pmc_traffic(name) if args.config == "c2" and dtype == "bf16" else (None, None)
+        roof["traffic"] = traffic
+        if traffic is not None:
+            roof["traffic_launches_per_step"] = pmc_calls   # must equal launches_per_step (same command)
+        block_fl = block_flops_per_element(D, NB, S) * B * S
+        roof.update({"avg_launch_us": 1e3 * ms / cnt,
                      "share_of_instrumented_kernel_time": ms / total_ms,
+                     "encoder_block": {
+                         "us_per_step": 1e3 * blk[2] / nprof,
+                         "mfma_frac": (block_fl / (blk[2] / nprof * 1e-3) / 1e12) / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                         "achieved_tflops": block_fl / (blk[2] / nprof * 1e-3) / 1e12,
+                         "hbm_frac": (blk[1] / nprof / (blk[2] / nprof * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                         "algorithmic_gb_per_step": blk[1] / nprof / 1e9,
+                         "note": "all kernels of the DeepSVG blocks (LN, QKV/O/FFN GEMMs, attention, their input and "
+                                 "weight gradients): sum of event-timed launch durations in eager steps (side-stream "
+                                 "weight gradients overlap the main chain, so the sum over-counts wall time)"},
                      "step": {"achieved": step_tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": step_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS},
                      "kernels_us_per_step": {k: round(1e3 * v[3] / nprof, 1) for k, v in table}})
@@ -272,7 +373,7 @@ def main():
             roof["measured_peaks"] = "unavailable: %s" % exc
         out["roofline"] = roof
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(ic)
+        out["cpu_baseline"] = cpu_baseline(ic, cfg)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -586,6 +586,17 @@ extern "C" size_t mfp_gemm_workspace_bytes(const mfp_gemm_args* a) {
   return ((size_t)sk * a->M * a->N + (size_t)sk * a->M) * sizeof(float);
 }
 
+static bool env_ws_off() { static const bool v = getenv("MFP_GEMM_NO_WS") != nullptr; return v; }   // benchmarking only
+static bool env_wg_off() { static const bool v = getenv("MFP_GEMM_NO_WG") != nullptr; return v; }   // benchmarking only
+
+extern "C" const char* mfp_gemm_kernel_family(const mfp_gemm_args* a) {
+  if (a == nullptr) return "";
+  const int splitk = a->splitk < 1 ? 1 : a->splitk;
+  if (!env_ws_off() && ws_eligible(a, splitk)) return "gemm_ws_kernel";
+  if (!env_wg_off() && uses_workspace(a) && wg_eligible(a, splitk)) return "gemm_wg_kernel";
+  return "gemm_kernel";
+}
+
 extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   MFP_CHECK_ARG(a != nullptr && a->A && a->B && a->C);
   MFP_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
@@ -642,16 +653,14 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   kchunk = ((kchunk + bk - 1) / bk) * bk;
   p.kchunk = kchunk;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static const bool ws_off = getenv("MFP_GEMM_NO_WS") != nullptr;   // benchmarking only
-  if (!ws_off && ws_eligible(a, splitk)) {
+  if (!env_ws_off() && ws_eligible(a, splitk)) {
     int rcw = launch_ws_any(a, p, st);
     if (rcw != MFP_OK) return rcw;
     MFP_CHECK_LAUNCH();
     return MFP_OK;
   }
-  static const bool wg_off = getenv("MFP_GEMM_NO_WG") != nullptr;   // benchmarking only
   int rc;
-  if (!wg_off && ws_path && wg_eligible(a, splitk)) rc = launch_wg(p, a->M, a->N, splitk, st);
+  if (!env_wg_off() && ws_path && wg_eligible(a, splitk)) rc = launch_wg(p, a->M, a->N, splitk, st);
   else rc = a->in_dtype == MFP_BF16 ? launch_gemm<unsigned short>(a, p, splitk, st)
                                     : launch_gemm<float>(a, p, splitk, st);
   if (rc != MFP_OK) return rc;

@@ -243,6 +243,16 @@ class EncoderPreFn(torch.autograd.Function):
 class BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(fctx, x, ctx: StepCtx, i: int):
+        with ops.scope("block"):
+            return BlockFn._forward(fctx, x, ctx, i)
+
+    @staticmethod
+    def backward(fctx, dx2):
+        with ops.scope("block"):
+            return BlockFn._backward(fctx, dx2)
+
+    @staticmethod
+    def _forward(fctx, x, ctx: StepCtx, i: int):
         st = ctx.store
         D = st.layout.D
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
@@ -266,7 +276,7 @@ class BlockFn(torch.autograd.Function):
         return x2
 
     @staticmethod
-    def backward(fctx, dx2):
+    def _backward(fctx, dx2):
         ctx, i = fctx.ctx, fctx.i
         st = ctx.store
         D = st.layout.D

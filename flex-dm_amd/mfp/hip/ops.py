@@ -43,6 +43,21 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 # bench.py's roofline leg: HIP events recorded on the launch stream around each library call
 # (torch.cuda.Event records on torch's current stream, which is the stream passed to the kernels).
 _prof = None
+_scope = [""]
+
+
+class scope:
+    """Tag the library calls made inside the ``with`` block (bench.py sums the kernels of the
+    encoder blocks separately: the quantity north_star's MFMA target is stated on)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _scope.append(self.name)
+
+    def __exit__(self, *exc):
+        _scope.pop()
 
 
 def start_profile():
@@ -51,16 +66,16 @@ def start_profile():
 
 
 def stop_profile():
-    """-> [(kernel name, algorithmic flops, algorithmic bytes, milliseconds)]"""
+    """-> [(kernel name, algorithmic flops, algorithmic bytes, milliseconds, scope)]"""
     global _prof
     recs, _prof = _prof or [], None
     torch.cuda.synchronize()
-    return [(n, f, b, e0.elapsed_time(e1)) for n, f, b, e0, e1 in recs]
+    return [(n, f, b, e0.elapsed_time(e1), sc) for n, f, b, sc, e0, e1 in recs]
 
 
 class _timed:
     def __init__(self, name, flops=0, nbytes=0):
-        self.args = (name, flops, nbytes)
+        self.args = (name, flops, nbytes, _scope[-1])
 
     def __enter__(self):
         if _prof is not None:
@@ -148,15 +163,16 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
     if nbytes:
         ws = workspace(nbytes, A.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    bf = A.dtype == torch.bfloat16
-    if bf and a_kmajor and b_kmajor and K in (256, 512) and splitk == 1:
-        name = "gemm_ws_kernel"          # weight-stationary Dense forward / dgrad (csrc/gemm_ws.h)
-    elif bf and not a_kmajor and not b_kmajor and splitk >= 8 and splitk % 8 == 0:
-        name = "gemm_wg_kernel"          # streaming weight gradient (csrc/gemm_wg.h) + split-K reduce
-    else:
-        name = "gemm_kernel<%s,%s,%s>" % ("bf16" if bf else "f32", "Ak" if a_kmajor else "Am",
-                                          "Bk" if b_kmajor else "Bn")
-    with _timed(name, 2 * M * N * K, (M * K + N * K) * _esz(A) + M * N * _esz(out)):
+    name = "gemm_kernel"
+    if _prof is not None:   # booked under the kernel family the library actually launches
+        name = lib.mfp_gemm_kernel_family(ctypes.byref(a)).decode()
+        if name == "gemm_kernel":
+            name = "gemm_kernel<%s,%s,%s>" % ("bf16" if A.dtype == torch.bfloat16 else "f32", "Ak" if a_kmajor else "Am",
+                                              "Bk" if b_kmajor else "Bn")
+    # algorithmic bytes: both operands once, the result once, plus the epilogue operands it reads
+    nbytes = (M * K + N * K) * _esz(A) + M * N * _esz(out)
+    nbytes += M * N * 4 * ((residual is not None) + bool(accum)) + (M * N * _esz(relu_bwd_aux) if relu_bwd_aux is not None else 0)
+    with _timed(name, 2 * M * N * K, nbytes):
         check(lib.mfp_gemm(ctypes.byref(a), _stream()), "mfp_gemm")
     return out
 

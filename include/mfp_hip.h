@@ -91,6 +91,10 @@ typedef struct mfp_gemm_args {
 
 int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);
 size_t mfp_gemm_workspace_bytes(const mfp_gemm_args* args /*host*/);
+/* Which kernel family mfp_gemm will launch for these arguments -- "gemm_ws_kernel" (weight-
+ * stationary, warp-specialised), "gemm_wg_kernel" (streaming weight gradient + split-K reduce) or
+ * "gemm_kernel" (LDS-tiled) -- so that measurements are booked under the kernel that ran. */
+const char* mfp_gemm_kernel_family(const mfp_gemm_args* args /*host*/);
 
 /* ---------------------------------------------------------------- grouped weight gradients
  * Up to MFP_MAX_WGRAD_JOBS products C_j[M_j][N_j] = A_j[K][M_j]^T B_j[K][N_j] over the SAME token

@@ -400,8 +400,8 @@ def test_shuffled_set_position_token_parity_and_training():
 # shape (S=128, D=256, 4 blocks) against the f64 oracle.  The bf16 path (the one bench.py times)
 # rounds every MFMA operand to 8 mantissa bits; its loss deviation is MEASURED here, recorded under
 # gpurun_out/parity_timed_shape.json, and bounded by BF16_LOSS_BUDGET.
-F32_LOSS_TOL = 1e-3
-BF16_LOSS_BUDGET = 2e-3
+F32_LOSS_TOL = 1e-5      # measured 5e-8 (gpurun_out/parity_timed_shape.json, r02)
+BF16_LOSS_BUDGET = 1e-3  # north_star's bound, on the TOTAL loss; measured 4e-4 (c2 mix) / 6e-4 (c3 mix)
 
 
 def _timed_shape_case(mix, B, S=128, D=256, L=4):
@@ -439,6 +439,26 @@ def _timed_shape_case(mix, B, S=128, D=256, L=4):
     return ic, params, batch, modified, masks, torch_ref, loss_key_names(ic)
 
 
+def _bf16_grad_report(gd, grads):
+    """Gradients of a run against the oracle's.  Returns (worst cosine over the SIGNIFICANT variables
+    -- max |g| >= 1e-3 of the largest gradient entry of the step --, worst ratio of a variable's rms
+    error to its budget 0.2 rms(g) + 5e-5 gmax).  The budget's absolute term matters for variables
+    whose true gradient is a small residual of large terms: at initialisation attention is near-uniform
+    and the token representations of the upper blocks nearly coincide, so dWq / dWk there are 1e-4 of
+    the step's largest gradients and carry the bf16 rounding of the stored q|k|v at full size (c5 shape:
+    cosine 0.67 at relative magnitude 6e-5); the f32 path has none of it (cosine 1 - 5e-10)."""
+    gmax = max(float(w.abs().max()) for w in grads.values())
+    worst_cos, worst_excess = 1.0, 0.0
+    for name, w in grads.items():
+        got, w = gd[name].double().reshape(-1), w.reshape(-1)
+        n = got.numel() ** 0.5
+        err, ref = float((got - w).norm()) / n, float(w.norm()) / n
+        worst_excess = max(worst_excess, err / (0.2 * ref + 5e-5 * gmax))
+        if float(w.abs().max()) >= 1e-3 * gmax:
+            worst_cos = min(worst_cos, float(torch.dot(got, w) / (got.norm() * w.norm() + 1e-30)))
+    return worst_cos, worst_excess
+
+
 def _record(name, value):
     import json
     import os
@@ -470,16 +490,10 @@ def test_timed_shape_parity_vs_oracle(dtype, mix, B):
         key_rel[k] = abs(sums[i, 0].item() - w) / max(abs(w), 1e-3 * want)
         assert abs(sums[i, 2].item() - float(info["scores"][k + "_score_den"])) < 1e-6, k      # counts: exact
     logit_err = max((outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item() for k in keys)
-    gd = model.store.grads_state_dict()
-    worst_cos = 1.0
-    for name, w in grads.items():
-        got, w = gd[name].double().reshape(-1), w.reshape(-1)
-        if w.norm() < 1e-8:
-            continue
-        worst_cos = min(worst_cos, float(torch.dot(got, w) / (got.norm() * w.norm() + 1e-30)))
+    worst_cos, excess = _bf16_grad_report(model.store.grads_state_dict(), grads)
     _record("%s_%s" % (mix, dtype), dict(B=B, S=S, D=D, L=L, loss=float(loss), oracle_loss=want, loss_rel_dev=rel,
                                          worst_key_loss_rel_dev=max(key_rel.values()), max_logit_abs_err=logit_err,
-                                         worst_grad_cosine=worst_cos))
+                                         worst_grad_cosine=worst_cos, worst_grad_rms_err_over_budget=excess))
     print("timed shape %s %s: loss rel dev %.2e, worst key %.2e, logits %.2e, worst grad cos %.6f"
           % (mix, dtype, rel, max(key_rel.values()), logit_err, worst_cos))
     if dtype == "fp32":
@@ -487,8 +501,8 @@ def test_timed_shape_parity_vs_oracle(dtype, mix, B):
         assert logit_err < 5e-4 and worst_cos > 0.99999
     else:
         assert rel <= BF16_LOSS_BUDGET, rel
-        assert max(key_rel.values()) <= 3 * BF16_LOSS_BUDGET, key_rel
-        assert worst_cos > 0.98
+        assert max(key_rel.values()) <= 5e-3, key_rel          # single keys (few masked fields each): measured <= 2.4e-3
+        assert worst_cos > 0.98 and excess <= 1.0, (worst_cos, excess)
 
 
 def test_grouped_wgrad_equals_per_product_path():
@@ -523,3 +537,46 @@ def test_grouped_wgrad_equals_per_product_path():
         scale = a.abs().max().item()
         err = (a - b).abs().max().item()
         assert err <= 2e-5 * scale + 1e-7, (name, err, scale)
+
+
+# ------------------------------------------------------------------ BASELINE config c5 shape (D=512, 8 blocks, S=256)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_c5_shape_parity_vs_oracle(dtype):
+    """Crello Ours-EXP-FT shape of BASELINE config 5 (d_model 512, 8 blocks, seq_len 256; head dim 64,
+    K = 512 / 1024 / 1536 products) with the EXP task mix, against the f64 oracle at B = 2."""
+    S, D, L, B = 256, 512, 8, 2
+    ic, params, batch, modified, masks, torch_ref, keys = _timed_shape_case("c3", B, S, D, L)
+    state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S)
+    model = _model(ic, params, D, L, dtype)
+    loss, sums, outputs = _run(model, ic, batch, modified, masks)
+    want = float(info["data_loss"])
+    rel = abs(float(loss) - want) / want
+    logit_err = max((outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item() for k in keys)
+    worst_cos, excess = _bf16_grad_report(model.store.grads_state_dict(), grads)
+    _record("c5_%s" % dtype, dict(B=B, S=S, D=D, L=L, loss=float(loss), oracle_loss=want, loss_rel_dev=rel,
+                                  max_logit_abs_err=logit_err, worst_grad_cosine=worst_cos,
+                                  worst_grad_rms_err_over_budget=excess))
+    print("c5 shape %s: loss rel dev %.2e, logits %.2e, worst grad cos %.6f" % (dtype, rel, logit_err, worst_cos))
+    if dtype == "fp32":
+        assert rel <= 1e-5 and logit_err < 5e-4 and worst_cos > 0.99999
+    else:
+        assert rel <= BF16_LOSS_BUDGET and worst_cos > 0.98 and excess <= 1.0, (rel, worst_cos, excess)
+
+
+def test_c5_shape_trains_bf16_graph():
+    """The c5 shape through the product API: fused masking, eager steps, hipGraph replay."""
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    B, S = 8, 256
+    batch = synthetic_batch(ic, B, S, seed=0, ragged=True, device=DEV)
+    model = MFP(ic, num_blocks=8, latent_dim=512, dropout=0.1, l2=1e-2, masking_method="elem_pos_attr_img_txt",
+                dtype="bf16", device=DEV)
+    model.compile(learning_rate=1e-4)
+    first = float(model.train_step(batch)[:, 0].sum())
+    model.capture_train_step(batch, warmup=1)
+    for _ in range(30):
+        sums = model.train_step(batch)
+    torch.cuda.synchronize()
+    last = float(sums[:, 0].sum())
+    assert np.isfinite(first) and np.isfinite(last) and last < first, (first, last)
