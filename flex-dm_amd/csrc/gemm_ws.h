@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
   constexpr int OS = OUT_BF16 ? 2 : 4, OROWB = BN * OS, OCPR = OROWB / 16, OSTAGE = BM * OROWB;
   constexpr int O_CH = BM * OCPR / 256;                                   // output chunks per memory thread
   constexpr bool PAIRED = OUT_BF16 && NQ >= 2;   // bf16 quads b, b+1 adjacent: one 16-byte stage unit
-  constexpr int XD = KS == 8 ? 4 : 2;   // X tiles in flight in registers (16 KB / 32 KB each)
+  constexpr int XD = KS == 8 ? 4 : (KS <= 24 ? 2 : 1);   // X tiles in flight in registers (16 / 32-48 / 64 KB each)
   constexpr int ED = 4;                 // rotating epilogue-operand sets (3 live: in use + two in flight)
   static_assert((BM * CPR) % 256 == 0 && (BM * OCPR) % 256 == 0 && NQ >= 1, "tile/thread mismatch");
   constexpr unsigned int OOB = 0xFFFFFFF0u;
@@ -392,6 +392,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
 // Host side: can this call take the weight-stationary kernel?
 inline bool ws_eligible(const mfp_gemm_args* a, int splitk) {
   if (!(a->a_kmajor && a->b_kmajor) || a->in_dtype != MFP_BF16 || splitk != 1) return false;
+  // K = 1024 (d_model 512: FFN2 forward, FFN1 input gradient) instantiates and is correct (KS = 32, one X tile
+  // in flight: two spill), but measured 46 us against 41 us for the tile kernel at T = 16384 -- not routed here
   if (a->K != 256 && a->K != 512 && a->K != 768) return false;
   if (a->K == 768 && (a->flags & ~(MFP_GEMM_BIAS | MFP_GEMM_RELU))) return false;   // plain epilogue only
   const int f = a->flags;

@@ -26,6 +26,7 @@ import torch
 
 from mfp.data.spec import get_valid_input_columns
 
+WS_K = (256, 512)   # contraction lengths the weight-stationary GEMM takes with every epilogue (csrc/gemm_ws.h)
 NUM_HEADS = 8  # transformer.py:147, never overridden by Blocks (transformer.py:263-270)
 
 
@@ -171,7 +172,7 @@ class ParamStore:
         if self.shadow is not None and torch.device(device).type == "cuda":
             segs = [(s.offset, s.shape[0], s.shape[1]) for s in layout.segments.values()
                     if s.transposed and ("/mlp/" in s.name or "/combine_heads/" in s.name)
-                    and s.shape[0] in (256, 512)]
+                    and s.shape[0] in WS_K]
             # fused Q|K|V ([3D][D], three adjacent variables) -> one [D][3D] block at the query offset
             if 3 * layout.D == 768:
                 for i in range(layout.L):
@@ -243,7 +244,7 @@ class ParamStore:
             if 3 * self.layout.D != 768:
                 return None
             return self.shadow_t[s.offset:s.offset + 3 * s.size].view(s.shape[1], 3 * s.shape[0])
-        if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and s.shape[0] in (256, 512)):
+        if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and s.shape[0] in WS_K):
             return None
         return self.shadow_t[s.offset:s.offset + s.size].view(s.shape[1], s.shape[0])
 

@@ -128,7 +128,7 @@ def test_gemm_epilogues(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["fwd", "dgrad"])
 @pytest.mark.parametrize("M,N,K", [(2304, 264, 256), (4100, 768, 128), (2050, 136, 512), (3000, 1384, 256),
-                                   (2200, 256, 768), (2048, 128, 72)])
+                                   (2200, 256, 768), (2048, 128, 72), (2100, 512, 1024), (1500, 200, 1024)])
 def test_gemm_large_m_epilogues(dtype, layout, M, N, K):
     """Train-step-like skinny shapes (large M, small N/K) through every epilogue flag."""
     ops = _ops()
