@@ -24,6 +24,25 @@ NUM_HEADS = 8
 # bf16 path: the weight gradients of a block (of the heads, of the encoder) as ONE grouped launch with the
 # split-K reduction inside it (csrc/gemm_wgg.h); 0 = one mfp_gemm + reduce kernel per product (A/B switch)
 WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
+# bf16 path, d_model 256 / 512: LayerNorm forward fused into the X staging of the product behind it (QKV,
+# FFN1: MFP_GEMM_LNORM_A, csrc/gemm_ws.h); 0 = stand-alone ln_fwd launch + product (A/B switch)
+LN_FUSE = os.environ.get("MFP_LN_FUSE", "0") == "1"
+
+
+def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False):
+    """``Dense(LayerNormalization(x))`` of a DeepSVG block (transformer.py:216-217 / 222-223): returns
+    (out, y = LN(x) in the compute dtype, mean, rstd)."""
+    cdt = ctx.cdt
+    if LN_FUSE and cdt == torch.bfloat16 and D in (256, 512) and T * D * 2 < 0x7FFFFFF0:
+        y = torch.empty((T, D), dtype=cdt, device=x.device)
+        mean = torch.empty((T,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((T,), dtype=torch.float32, device=x.device)
+        out = ops.gemm(x, W, T, N, D, a_kmajor=True, b_kmajor=True, bias=bias, relu=relu, out_dtype=cdt,
+                       ln=(gamma, beta, y, mean, rstd))
+        return out, y, mean, rstd
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, cdt)
+    out = ops.gemm(y, W, T, N, D, a_kmajor=True, b_kmajor=True, bias=bias, relu=relu, out_dtype=cdt)
+    return out, y, mean, rstd
 
 
 class StepCtx:
@@ -258,16 +277,16 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x = x.contiguous()
-        y1, mean1, rstd1 = ops.layernorm_fwd(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), cdt)
-        qkv = ops.gemm(y1, st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D, a_kmajor=True,
-                       b_kmajor=True, bias=st.span(st.w, p + "attn/dense_query/bias", 3 * D), out_dtype=cdt)
+        qkv, y1, mean1, rstd1 = _ln_dense(ctx, x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
+                                          st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
+                                          st.span(st.w, p + "attn/dense_query/bias", 3 * D))
         a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
         x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
                       bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
                       dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
-        y2, mean2, rstd2 = ops.layernorm_fwd(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"), cdt)
-        h = ops.gemm(y2, st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, a_kmajor=True, b_kmajor=True,
-                     bias=st.weight(p + "mlp/dense_0/bias"), relu=True, out_dtype=cdt)
+        h, y2, mean2, rstd2 = _ln_dense(ctx, x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
+                                        st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, st.weight(p + "mlp/dense_0/bias"),
+                                        relu=True)
         x2 = ops.gemm(h, st.cw(p + "mlp/dense_1/kernel"), T, D, 2 * D, a_kmajor=True, b_kmajor=True,
                       bias=st.weight(p + "mlp/dense_1/bias"), residual=x1,
                       dropout=(ctx.p, ctx.seed, 2 * i + 2), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
