@@ -784,6 +784,9 @@ extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t
   p.zstride = (long long)p.ntiles * 128 * 128 + WGG_ZPAD;
   p.ws_col = p.ws + (size_t)splitk * p.zstride;
   p.tickets = tickets;
+#ifdef MFP_GEMM_TRACE
+  p.trace = g_trace;
+#endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc = rowskip ? launch_wgg_t<true>(p, st) : launch_wgg_t<false>(p, st);
   if (rc != MFP_OK) return rc;

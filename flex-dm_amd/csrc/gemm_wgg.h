@@ -12,8 +12,8 @@
 // gemm_wg_kernel 563 us + splitk_reduce_kernel 200 us per step).  The 32 tiles of a block's four
 // products fill the chip with an 8-way split: 64 k-tiles per workgroup, 8x fewer partial bytes.
 //
-// Reduction: every workgroup stores its partial tile as a 64 KB slab ws[kz][tile], publishes it
-// (agent-scope release) and draws a ticket for the tile; the workgroup that draws the last ticket
+// Reduction: every workgroup stores its partial tile as a 64 KB slab ws[kz][tile] with write-through
+// (sc1) stores, drains them and draws a ticket for the tile; the workgroup that draws the last ticket
 // acquires, sums the slabs in FIXED order kz = 0 .. splitk-1 (data-parallel replicas stay bit-identical)
 // and writes the gradient.  Placement-independent (any distribution of a tile's chunks over XCDs /
 // CUs); the ticket word is reset by the last arriver, so the ticket array stays all-zero between
@@ -60,10 +60,16 @@ struct WggParams {
   unsigned int* tickets;        // [ntiles], zero on entry, zero on exit
   long long zstride;            // floats between the slabs of consecutive k-slices
   int njobs, ntiles, K, nk_max, splitk;   // nk_max = k-tiles of the longest k-slice
+#ifdef MFP_GEMM_TRACE
+  unsigned long long* trace;   // [workgroup][24] s_memrealtime stamps (100 MHz) of thread 0
+#endif
 };
 
+#ifndef MFP_WGG_OCC
+#define MFP_WGG_OCC 2
+#endif
 template <int XD, bool ROWSKIP>
-__global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
+__global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p) {
   constexpr int BM = 128, BN = 128, BK = 64, PAD = 8, LDS_S = BM + PAD;
   constexpr int TILE_E = BK * LDS_S;
   constexpr int STAGE_B = 2 * TILE_E * 2;
@@ -77,6 +83,13 @@ __global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
+#ifdef MFP_GEMM_TRACE
+  int trace_i = 0;
+#define WGG_STAMP() do { if (tid == 0 && trace_i < 24) p.trace[(long long)blockIdx.x * 24 + trace_i++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WGG_STAMP() do {} while (0)
+#endif
+  WGG_STAMP();   // 0: start
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int kz = (j / p.ntiles) * 8 + xcd, tile = j % p.ntiles;          // splitk % 8 == 0 (host)
   int ji = 0;
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();   // prologue barrier (stage 0 filled)
+    WGG_STAMP();   // 1: first tile staged
     for (int t = 0; t < nk; ++t) {
       const unsigned short* As = reinterpret_cast<const unsigned short*>(smem_raw + (t & 1) * STAGE_B);
       const unsigned short* Bs = As + TILE_E;
@@ -135,6 +149,7 @@ __global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
       }
       __syncthreads();
+      if ((t & 15) == 15) WGG_STAMP();   // 2..: every 16th k-tile
     }
     float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
@@ -208,32 +223,37 @@ __global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
     }
   }
   __syncthreads();   // partial tile (and column sums) are in LDS
+  WGG_STAMP();   // tile in LDS
 
   // (no further static __shared__ object: statics of a size that is not a multiple of 16 would shift the
   // dynamic region off its 16-byte alignment and ds_read_b64_tr_b16 would silently read the wrong bytes)
   volatile int* last_s = reinterpret_cast<volatile int*>(smem_raw + BM * CS_LD * 4);
-  // ---- publish the partial tile: slab ws[kz][tile] (whole 128 x 128, 512 B rows), then a ticket
+  // ---- publish the partial tile: slab ws[kz][tile] (whole 128 x 128, 512 B rows), then a ticket.
+  // Write-through (sc1) 16-byte stores, drained by every wave, need no release fence before the ticket
+  // (a plain-store slab + agent-scope release cost ~5 us more per workgroup: the fence writes the whole
+  // L2's dirty lines back).
   const int r0 = tid >> 5, c4 = (tid & 31) * 4;
   {
     const float* Cs = reinterpret_cast<const float*>(smem_raw);
     float* slab = p.ws + kz * p.zstride + (long long)tile * (BM * BN);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(slab, 0, BM * BN * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
       const int row = r0 + 16 * i;
-      *reinterpret_cast<f32x4*>(slab + row * BN + c4) = *reinterpret_cast<const f32x4*>(&Cs[row * CS_LD + c4]);
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&Cs[row * CS_LD + c4]), rss,
+                                             (unsigned int)((row * BN + c4) * 4), 0, 16 /* sc1 */);
     }
     if (do_colsum && tid < BM) {
       float s = 0.f;
 #pragma unroll
       for (int gI = 0; gI < 16; ++gI) s += colsum_s[gI][tid];
-      p.ws_col[((long long)kz * p.ntiles + tile) * BM + tid] = s;
+      __hip_atomic_store(&p.ws_col[((long long)kz * p.ntiles + tile) * BM + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
   __syncthreads();
+  WGG_STAMP();   // slab drained
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back must have left before the ticket is drawn
     const unsigned int ticket = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == (unsigned int)(p.splitk - 1);
     if (last) {
@@ -243,28 +263,39 @@ __global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
     *last_s = last;
   }
   __syncthreads();
+  WGG_STAMP();   // ticket drawn
   if (!*last_s) return;
 
-  // ---- last arriver: C[m][n] = sum over kz (ascending) of the slabs; colsum likewise
+  // ---- last arriver: C[m][n] = sum over kz (ascending) of the slabs; colsum likewise.  A thread owns 8
+  // float4 of the tile and keeps 4 slabs of them (32 loads) in flight: the slabs come from other XCDs'
+  // write-throughs, i.e. from memory, and a loop with one slab row in flight (8 dependent round trips
+  // of ~3 us) was HALF of this kernel's time.
   {
     const long long zstride = p.zstride;
-    const float* slab0 = p.ws + (long long)tile * (BM * BN);
-#pragma unroll 2
+    const float* src = p.ws + (long long)tile * (BM * BN) + r0 * BN + c4;
+    f32x4 acc8[BM / 16];
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) acc8[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int RZ = MFP_WGG_OCC >= 4 ? 2 : 4;      // slabs in flight per round (register budget)
+    for (int z0 = 0; z0 < p.splitk; z0 += RZ) {
+      f32x4 v[RZ][BM / 16];
+#pragma unroll
+      for (int u = 0; u < RZ; ++u)
+#pragma unroll
+        for (int i = 0; i < BM / 16; ++i)
+          v[u][i] = z0 + u < p.splitk ? *reinterpret_cast<const f32x4*>(src + (z0 + u) * zstride + 16 * i * BN) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < RZ; ++u)
+        if (z0 + u < p.splitk) {
+#pragma unroll
+          for (int i = 0; i < BM / 16; ++i) { acc8[i][0] += v[u][i][0]; acc8[i][1] += v[u][i][1]; acc8[i][2] += v[u][i][2]; acc8[i][3] += v[u][i][3]; }
+        }
+    }
+#pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
       const int row = r0 + 16 * i;
-      const float* src = slab0 + row * BN + c4;
-      f32x4 s = *reinterpret_cast<const f32x4*>(src);
-      for (int z0 = 1; z0 < p.splitk; z0 += 7) {      // 7 slabs in flight, summed in ascending order
-        f32x4 v[7];
-#pragma unroll
-        for (int u = 0; u < 7; ++u)
-          v[u] = z0 + u < p.splitk ? *reinterpret_cast<const f32x4*>(src + (z0 + u) * zstride) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 7; ++u)
-          if (z0 + u < p.splitk) { s[0] += v[u][0]; s[1] += v[u][1]; s[2] += v[u][2]; s[3] += v[u][3]; }
-      }
       if (m0 + row < M && n0 + c4 < N)
-        *reinterpret_cast<f32x4*>(jb.C + (long long)(m0 + row) * jb.ldc + n0 + c4) = s;
+        *reinterpret_cast<f32x4*>(jb.C + (long long)(m0 + row) * jb.ldc + n0 + c4) = acc8[i];
     }
     if (do_colsum && tid < BM && m0 + tid < M) {
       float s = 0.f;
@@ -272,6 +303,10 @@ __global__ __launch_bounds__(512) void gemm_wgg_kernel(WggParams p) {
       jb.colsum[m0 + tid] = s;
     }
   }
+#ifdef MFP_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WGG_STAMP();   // reduced (last arrivers only)
+#endif
 }
 
 template <bool ROWSKIP>
