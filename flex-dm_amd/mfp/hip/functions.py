@@ -69,6 +69,16 @@ class StepCtx:
         self.step_ptr = step_ptr
         self.cdt = store.compute_dtype
 
+    def with_context_token(self) -> "StepCtx":
+        """The same step seen by the blocks when a context token is prepended (encoder.py:245-248): one more
+        position per document, one more valid key.  Shares the pending-reduction list, the hand-off table
+        and the streams with the encoder / decoder context."""
+        import copy
+        c = copy.copy(self)
+        c.S, c.T = self.S + 1, self.B * (self.S + 1)
+        c.nvalid = (self.nvalid + 1).contiguous()
+        return c
+
     def on_side(self, fn, *tensors, which: int = 0):
         """Run ``fn`` (weight-gradient GEMMs: off the critical path, only Adam needs them) on the
         side HIP stream, forked after everything enqueued so far on the current stream.  Every
@@ -207,6 +217,25 @@ class PosConstFn(torch.autograd.Function):
         g.zero_()
         g[:S] = d.sum(dim=0)
         return dout, None, None
+
+
+class ContextTokenFn(torch.autograd.Function):
+    """``seq = concat([Embedding(task | length)[:, None], seq], axis=1)`` (reference encoder.py:226-248,
+    context in {"id", "length"}).  An ablation path (args.py --context): the row gather / scatter-add
+    around the HIP blocks is torch plumbing, like PosConstFn."""
+
+    @staticmethod
+    def forward(fctx, h, ids, anchor, ctx: StepCtx):
+        table = ctx.store.weight("encoder/input_task/embeddings")
+        fctx.ctx, fctx.ids = ctx, ids
+        return torch.cat([table[ids][:, None, :], h], dim=1)
+
+    @staticmethod
+    def backward(fctx, dout):
+        g = fctx.ctx.store.grad("encoder/input_task/embeddings")
+        g.zero_()
+        g.index_add_(0, fctx.ids, dout[:, 0].contiguous())
+        return dout[:, 1:], None, None, None
 
 
 class EncoderFn(torch.autograd.Function):

@@ -276,7 +276,8 @@ class MFP:
             ctx = self.model.make_ctx(batch, True)
             idx_all, codes, xs, masks = self._masker(batch, tasks, ctx.nvalid, ctx.B, ctx.S, self.model.step_ptr)
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, batch, masks)
-            loss, sums, _ = self.model.forward_loss(None, keys, training=True, premasked=(idx_all, codes, xs), ctx=ctx,
+            cin = {"task": tasks[..., None], "length": batch["length"]} if self.context is not None else None
+            loss, sums, _ = self.model.forward_loss(cin, keys, training=True, premasked=(idx_all, codes, xs), ctx=ctx,
                                                     loss_sort=loss_sort(batch))
         else:
             targets, modified_inputs, masks = preprocess_for_train(

@@ -35,7 +35,8 @@ class Model:
         self.arch_type = "oneshot"
         self.input_columns = input_columns
         self.dropout, self.seed = dropout, seed
-        self.layout = ModelLayout(input_columns, latent_dim, num_blocks, input_dtype)
+        self.layout = ModelLayout(input_columns, latent_dim, num_blocks, input_dtype, context)
+        self.context = context
         self.store = ParamStore(self.layout, device, DTYPES[dtype], l2=l2, seed=seed)
         self.blocks = Blocks(self.store, num_blocks=num_blocks, block_type=block_type,
                              latent_dim=latent_dim, dropout=dropout, l2=l2)
@@ -60,7 +61,9 @@ class Model:
     def hidden(self, inputs: Dict, training: bool = False, ctx: Optional[StepCtx] = None):
         ctx = ctx or self.make_ctx(inputs, training)
         h, mask = self.encoder(inputs, ctx)
-        h = self.blocks(h, mask, ctx)
+        bctx = ctx.with_context_token() if self.context is not None else ctx    # the blocks see S + 1 positions
+        h = self.blocks(h, mask, bctx)
+        ctx.mid = bctx.mid
         return h, ctx
 
     def __call__(self, inputs: Dict, training: bool = False) -> Dict[str, torch.Tensor]:
@@ -74,9 +77,16 @@ class Model:
         ``premasked`` = (idx_all, codes, xs) from the fused masking kernel replaces ``inputs``."""
         if premasked is not None:
             h = EncoderPreFn.apply(self.store.anchor, ctx, *premasked).view(ctx.B, ctx.S, self.layout.D)
-            h = self.blocks(h, None, ctx)
+            bctx = ctx
+            if self.context is not None:
+                h = self.encoder.add_context_token(h, inputs, ctx)
+                bctx = ctx.with_context_token()
+            h = self.blocks(h, None, bctx)
+            ctx.mid = bctx.mid
         else:
             h, ctx = self.hidden(inputs, training)
+        if self.context is not None:      # decoder.py:74-76
+            h = h[:, 1:]
         B, S, D = h.shape
         ctx.loss_sort = loss_sort
         loss, sums, logits = DecoderLossFn.apply(h.reshape(B * S, D), ctx, loss_keys)

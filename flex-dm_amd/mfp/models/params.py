@@ -41,7 +41,8 @@ class Segment:
 class ModelLayout:
     """Static description of the flat buffer for one (input_columns, D, L) configuration."""
 
-    def __init__(self, input_columns: Dict, latent_dim: int, num_blocks: int, input_dtype: str = "set"):
+    def __init__(self, input_columns: Dict, latent_dim: int, num_blocks: int, input_dtype: str = "set",
+                 context: Optional[str] = None):
         D = latent_dim
         assert D % NUM_HEADS == 0, "embedding dimension = %d should be divisible by number of heads = %d" % (
             D, NUM_HEADS)  # ValueError text of transformer.py:48-52
@@ -90,6 +91,20 @@ class ModelLayout:
         if input_dtype != "set":
             self.pos_rows = int(input_columns["length"]["input_dim"]) + 1
             self._add("encoder/input_const/embeddings", (self.pos_rows, D), True, False)
+        # context token (encoder.py:96-110): one row per task (context="id") or per length (context="length");
+        # the reference names both layers "input_task"
+        self.context = context
+        self.context_rows = 0
+        if context is not None:
+            if context == "id":
+                from mfp.models.masking import get_task_names
+                self.context_rows = len(get_task_names(input_columns))
+            elif context == "length":
+                self.context_rows = int(input_columns["length"]["input_dim"])
+            else:
+                raise NotImplementedError("context=%r: only None, 'id' and 'length' are provided (the canvas "
+                                          "contexts need the canvas heads, which are off the MFP path)" % context)
+            self._add("encoder/input_task/embeddings", (self.context_rows, D), True, False)
 
         # ---- transformer blocks
         for i in range(num_blocks):

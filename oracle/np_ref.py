@@ -55,8 +55,21 @@ def valid_columns(input_columns: Dict) -> Dict:
     return out
 
 
+def context_rows(input_columns: Dict, context: Optional[str]) -> int:
+    """Rows of the context-token table ``input_task`` (architecture/encoder.py:96-110): the number of
+    tasks for context="id" (models/masking.py:18-21: random, elem + the attribute groups), the
+    ``length`` vocabulary for context="length" (both layers are NAMED input_task in the reference)."""
+    if context == "id":
+        n_groups = 3 if "clickable" in input_columns else 5     # data/spec.py:364-391
+        return 2 + n_groups
+    if context == "length":
+        return int(input_columns["length"]["input_dim"])
+    assert context is None, "context=%r: canvas contexts are not on the MFP path" % context
+    return 0
+
+
 def param_shapes(input_columns: Dict, latent_dim: int, num_blocks: int,
-                 input_dtype: str = "set") -> Dict[str, Tuple[int, ...]]:
+                 input_dtype: str = "set", context: Optional[str] = None) -> Dict[str, Tuple[int, ...]]:
     """Variables created by Encoder/Blocks/Decoder, in creation order.
 
     encoder.py:72-92 (Embedding(C+2, D) per categorical; Embedding(2, D) + Dense(D) per
@@ -75,6 +88,8 @@ def param_shapes(input_columns: Dict, latent_dim: int, num_blocks: int,
             shapes["encoder/input_%s/bias" % key] = (D,)
     if input_dtype != "set":   # encoder.py:47-55: PositionEmbedding(maxlen = length.input_dim) -> maxlen + 1 rows
         shapes["encoder/input_const/embeddings"] = (int(input_columns["length"]["input_dim"]) + 1, D)
+    if context is not None:    # encoder.py:96-110
+        shapes["encoder/input_task/embeddings"] = (context_rows(input_columns, context), D)
     for i in range(num_blocks):
         p = "blocks/seq2seq_%d/" % i
         for name in ("dense_query", "dense_key", "dense_value", "combine_heads"):
@@ -101,14 +116,14 @@ def is_regularized(name: str) -> bool:
     return not (name.endswith("/gamma") or name.endswith("/beta"))
 
 
-def init_params(input_columns: Dict, latent_dim: int, num_blocks: int, seed: int = 0, input_dtype: str = "set"
-                ) -> Dict[str, np.ndarray]:
+def init_params(input_columns: Dict, latent_dim: int, num_blocks: int, seed: int = 0, input_dtype: str = "set",
+                context: Optional[str] = None) -> Dict[str, np.ndarray]:
     """[TF-EXT] Keras default initialisers: Dense glorot_uniform / zeros bias; Embedding
     U(-0.05, 0.05); LN gamma 1, beta 0.  (Biases are drawn small-random instead of zero when
     ``seed`` is negative so that tests exercise the bias paths.)"""
     rng = np.random.default_rng(abs(seed))
     params = {}
-    for name, shape in param_shapes(input_columns, latent_dim, num_blocks, input_dtype).items():
+    for name, shape in param_shapes(input_columns, latent_dim, num_blocks, input_dtype, context).items():
         if name.endswith("/embeddings"):
             w = rng.uniform(-0.05, 0.05, size=shape)
         elif name.endswith("/kernel"):
@@ -155,8 +170,15 @@ def dropout(x, rate, keep_mask):
 
 
 # ----------------------------------------------------------------------------- model
-def encoder_fwd(params, input_columns, inputs, maxlen=None):
-    """architecture/encoder.py:147-199 (fusion="add", context=None)."""
+def context_ids(inputs, context):
+    """The index of the context token (encoder.py:231-240): the task id or the (zero-based) length."""
+    v = np.asarray(inputs["task" if context == "id" else "length"])
+    return (v[:, 0] if v.ndim == 2 else v).astype(np.int64)
+
+
+def encoder_fwd(params, input_columns, inputs, maxlen=None, context=None):
+    """architecture/encoder.py:147-199 (fusion="add"); context in {None, "id", "length"} (:226-248: a
+    token looked up in ``input_task`` is PREPENDED and the sequence mask grows by one)."""
     seq_mask = get_seq_mask(inputs["length"], maxlen)
     seq = 0.0
     for key, col in valid_columns(input_columns).items():
@@ -177,6 +199,10 @@ def encoder_fwd(params, input_columns, inputs, maxlen=None):
     if "encoder/input_const/embeddings" in params:                # :241-242, transformer.py:24-30 (dropout 0)
         S = seq.shape[1]
         seq = seq + params["encoder/input_const/embeddings"].astype(F64)[np.arange(S)][None]
+    if context is not None:                                       # :231-248
+        canvas = params["encoder/input_task/embeddings"].astype(F64)[context_ids(inputs, context)]
+        seq = np.concatenate([canvas[:, None, :], seq], axis=1)
+        seq_mask = get_seq_mask(np.asarray(inputs["length"]) + 1, None if maxlen is None else maxlen + 1)
     return seq, seq_mask
 
 
@@ -217,8 +243,11 @@ def block_fwd(params, i, x, seq_mask, rate=0.0, keep1=None, keep2=None):
     return x + y                                                               # :225
 
 
-def decoder_fwd(params, input_columns, h):
-    """architecture/decoder.py:95-111 (detachment="default", context=None)."""
+def decoder_fwd(params, input_columns, h, context=None):
+    """architecture/decoder.py:72-111 (detachment="default"); with a context token the first position
+    is split off (:74-76) and, the canvas heads being off this path, dropped."""
+    if context is not None:
+        h = h[:, 1:]
     B, S, _ = h.shape
     outputs = {}
     for key, col in valid_columns(input_columns).items():
@@ -230,14 +259,14 @@ def decoder_fwd(params, input_columns, h):
     return outputs
 
 
-def model_fwd(params, input_columns, inputs, num_blocks, rate=0.0, keep_masks=None, maxlen=None):
+def model_fwd(params, input_columns, inputs, num_blocks, rate=0.0, keep_masks=None, maxlen=None, context=None):
     """_OneShot.call, models/model.py:26-30."""
-    h, seq_mask = encoder_fwd(params, input_columns, inputs, maxlen)
+    h, seq_mask = encoder_fwd(params, input_columns, inputs, maxlen, context)
     for i in range(num_blocks):
         k1 = keep_masks[(i, 1)] if keep_masks else None
         k2 = keep_masks[(i, 2)] if keep_masks else None
         h = block_fwd(params, i, h, seq_mask, rate, k1, k2)
-    return decoder_fwd(params, input_columns, h)
+    return decoder_fwd(params, input_columns, h, context)
 
 
 # ----------------------------------------------------------------------------- losses

@@ -61,8 +61,8 @@ def _dropout(x, rate, keep):
     return x * keep.to(x.dtype) / (1.0 - rate)
 
 
-def encoder_fwd(p, input_columns, inputs, maxlen=None):
-    """architecture/encoder.py:147-199."""
+def encoder_fwd(p, input_columns, inputs, maxlen=None, context=None):
+    """architecture/encoder.py:147-248 (fusion="add"; context in {None, "id", "length"})."""
     dtype = next(iter(p.values())).dtype
     seq_mask = get_seq_mask(inputs["length"], maxlen)
     data_s = []
@@ -87,6 +87,11 @@ def encoder_fwd(p, input_columns, inputs, maxlen=None):
     if "encoder/input_const/embeddings" in p:    # encoder.py:241-242 (PositionEmbedding, dropout rate 0)
         positions = torch.arange(seq.shape[1])
         seq = seq + p["encoder/input_const/embeddings"][positions][None, :, :]
+    if context is not None:                                   # encoder.py:231-248
+        ids = inputs["task" if context == "id" else "length"]
+        ids = (ids[:, 0] if ids.dim() == 2 else ids).to(torch.int64)
+        seq = torch.cat([p["encoder/input_task/embeddings"][ids][:, None, :], seq], dim=1)
+        seq_mask = get_seq_mask(inputs["length"] + 1, None if maxlen is None else maxlen + 1)
     return seq, seq_mask
 
 
@@ -122,8 +127,10 @@ def block_fwd(p, i, x, seq_mask, rate=0.0, keep1=None, keep2=None):
     return x + y
 
 
-def decoder_fwd(p, input_columns, h):
-    """architecture/decoder.py:95-111."""
+def decoder_fwd(p, input_columns, h, context=None):
+    """architecture/decoder.py:72-111."""
+    if context is not None:
+        h = h[:, 1:]
     B, S, _ = h.shape
     outputs = {}
     for key, col in valid_columns(input_columns).items():
@@ -136,16 +143,16 @@ def decoder_fwd(p, input_columns, h):
 
 
 def model_fwd(p, input_columns, inputs, num_blocks, rate=0.0, keep_masks=None, maxlen=None,
-              return_hidden=False):
+              return_hidden=False, context=None):
     """_OneShot.call, models/model.py:26-30."""
-    h, seq_mask = encoder_fwd(p, input_columns, inputs, maxlen)
+    h, seq_mask = encoder_fwd(p, input_columns, inputs, maxlen, context)
     hidden = [h]
     for i in range(num_blocks):
         k1 = keep_masks[(i, 1)] if keep_masks else None
         k2 = keep_masks[(i, 2)] if keep_masks else None
         h = block_fwd(p, i, h, seq_mask, rate, k1, k2)
         hidden.append(h)
-    out = decoder_fwd(p, input_columns, h)
+    out = decoder_fwd(p, input_columns, h, context)
     return (out, hidden) if return_hidden else out
 
 
@@ -351,12 +358,12 @@ class TrainState:
 
 
 def loss_and_grads(state: TrainState, input_columns, targets, modified_inputs, masks,
-                   num_blocks, rate=0.0, keep_masks=None, maxlen=None, sort_flag=None):
+                   num_blocks, rate=0.0, keep_masks=None, maxlen=None, sort_flag=None, context=None):
     """Keras Model.train_step with no compiled loss: total = sum(model.losses)
     = LossLayer add_loss (metrics.py:297) + every L2 regulariser (utils.py:8-22)."""
     for w in state.p.values():
         w.grad = None
-    out = model_fwd(state.p, input_columns, modified_inputs, num_blocks, rate, keep_masks, maxlen)
+    out = model_fwd(state.p, input_columns, modified_inputs, num_blocks, rate, keep_masks, maxlen, context=context)
     loss_total, losses, scores, metrics = loss_layer(input_columns, targets, out, masks, maxlen, sort_flag=sort_flag)
     reg = l2_loss(state.p, state.l2)
     total = loss_total + reg

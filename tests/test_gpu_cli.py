@@ -41,7 +41,7 @@ def test_train_cli_crello_bf16_graph(tmp_path):
     main(["--dataset_name", "crello", "--data_dir", "synthetic:16:32", "--job-dir", job, "--latent_dim", "128",
           "--num_blocks", "1", "--batch_size", "16", "--num_epochs", "2", "--validation_freq", "2",
           "--masking_method", "elem_pos_attr_img_txt", "--dtype", "bf16", "--use_graph", "--verbose", "0",
-          "--enable_profile"])
+          "--enable_profile", "--context", "id"])
     assert os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))
     # --enable_profile = TensorBoard(profile_batch=2) of the reference (callbacks.py:44-48): the 2nd
     # train step is traced; its kernel table must name kernels of the HIP library
@@ -49,6 +49,14 @@ def test_train_cli_crello_bf16_graph(tmp_path):
     assert os.path.exists(table) and os.path.exists(os.path.join(job, "logs", "profile_step2.trace.json"))
     txt = open(table).read()
     assert "gemm" in txt or "attn" in txt, txt[:2000]
+    # eval.py on a context="id" job sends the task id of the evaluated group (eval.py:96-100)
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_cli2", os.path.join(root, "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    res = ev.main(["--job-dir", job, "--task_mode", "pos", "--batch_size", "16"])
+    assert set(res) == {"left", "top", "width", "height"}
 
 
 def test_train_cli_on_tfrecord_directory(tmp_path, capsys):

@@ -580,3 +580,75 @@ def test_c5_shape_trains_bf16_graph():
     torch.cuda.synchronize()
     last = float(sums[:, 0].sum())
     assert np.isfinite(first) and np.isfinite(last) and last < first, (first, last)
+
+
+# ------------------------------------------------------------------ context tokens (args.py --context id | length)
+@pytest.mark.parametrize("dataset,context,dtype", [("rico", "id", "fp32"), ("crello", "length", "fp32"), ("crello", "id", "bf16")])
+def test_context_token_parity_vs_oracle(dataset, context, dtype):
+    """context="id" / "length" (reference architecture/encoder.py:96-110,226-248, decoder.py:74-76): a task /
+    length embedding is prepended to the sequence, the blocks run on S + 1 positions (one more valid key),
+    the heads on the last S.  Forward, losses and every gradient incl. the ``input_task`` table vs the oracle."""
+    from oracle import np_ref, torch_ref
+    from mfp.models.metrics import build_loss_keys
+    from mfp.models.model import Model
+    B, S, D, L = 5, 18, 128, 2
+    ic, _, batch, modified, masks, *_ = _setup(dataset, B, S, D, L, seed=6)
+    params = np_ref.init_params(ic, D, L, seed=-13, context=context)
+    ntask = params["encoder/input_task/embeddings"].shape[0]
+    modified["task"] = (torch.arange(B) % (ntask if context == "id" else 3))[:, None].to(torch.int32)
+    state = torch_ref.TrainState(params, l2=None, clipnorm=1.0, lr=1e-2, dtype=torch.float64)
+    cast = lambda d: {k: (v.to(torch.float64) if v.is_floating_point() else v) for k, v in d.items()}
+    info, grads = torch_ref.loss_and_grads(state, ic, cast(batch), cast(modified), masks, L, maxlen=S, context=context)
+    plain, _ = torch_ref.loss_and_grads(torch_ref.TrainState({k: v for k, v in params.items() if "input_task" not in k},
+                                                             l2=None, dtype=torch.float64), ic, cast(batch), cast(modified), masks, L, maxlen=S)
+    assert abs(float(plain["data_loss"]) - float(info["data_loss"])) > 1e-4 * float(info["data_loss"])    # the token matters
+    model = Model(ic, num_blocks=L, latent_dim=D, dropout=0.0, dtype=dtype, device=DEV, context=context)
+    model.store.load_state_dict(params)
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    keys = build_loss_keys(ic, model.layout.head_cols, dev(batch), dev(masks))
+    loss, sums, outputs = model.forward_loss(dev(modified), keys, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    want = float(info["data_loss"])
+    gd = model.store.grads_state_dict()
+    if dtype == "fp32":
+        assert abs(float(loss) - want) <= 1e-4 * max(1.0, want)
+        for k in info["outputs"]:
+            assert (outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item() < 1e-4, k
+        gmax = max(w.abs().max().item() for w in grads.values())
+        for name, w in grads.items():
+            err = (gd[name].double() - w).abs().max().item()
+            assert err <= 2e-4 * w.abs().max().item() + 5e-5 * gmax, (name, err)
+        used = torch.unique(modified["task" if context == "id" else "length"].reshape(-1).long())
+        g = gd["encoder/input_task/embeddings"]
+        unused = torch.ones(g.shape[0], dtype=torch.bool)
+        unused[used] = False
+        assert (g[unused] == 0).all() and (g[used].abs().sum(1) > 0).all()      # rows of absent ids get no gradient
+    else:
+        assert abs(float(loss) - want) <= 5e-3 * want
+        worst_cos, excess = _bf16_grad_report(gd, grads)
+        assert worst_cos > 0.98 and excess <= 1.0, (worst_cos, excess)
+
+
+def test_context_id_trains_through_the_api():
+    """--context id through MFP: fused masking + task token, eager steps, hipGraph replay, test_step."""
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    B, S = 8, 31
+    batch = synthetic_batch(ic, B, S, seed=0, ragged=True, device=DEV)
+    model = MFP(ic, num_blocks=2, latent_dim=128, dropout=0.1, l2=1e-2, masking_method="elem_pos_attr_img_txt",
+                dtype="bf16", device=DEV, context="id")
+    model.compile(learning_rate=1e-3)
+    w0 = model.model.store.weight("encoder/input_task/embeddings").clone()
+    first = float(model.train_step(batch)[:, 0].sum())
+    model.capture_train_step(batch, warmup=1)
+    for _ in range(40):
+        sums = model.train_step(batch)
+    torch.cuda.synchronize()
+    assert np.isfinite(first) and float(sums[:, 0].sum()) < first
+    w1 = model.model.store.weight("encoder/input_task/embeddings")
+    assert not torch.equal(w0[1], w1[1]) and torch.isfinite(w1).all()
+    assert torch.isfinite(model.test_step(batch)).all()
+    out = model(batch, training=False)
+    assert out["left"].shape == (B, S, 1, 64)

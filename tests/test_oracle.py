@@ -291,3 +291,31 @@ def test_position_token_of_shuffled_set():
     p = torch_ref.to_torch(params, torch.float64)
     ht, _ = torch_ref.encoder_fwd(p, ic, batch, S)
     np.testing.assert_allclose(ht.detach().numpy(), h1, rtol=1e-10, atol=1e-12)
+
+
+def test_context_token_numpy_vs_torch_and_known_answer():
+    """context="id" / "length" (encoder.py:226-248, decoder.py:74-76): both restatements agree; a zero
+    task table with zero attention output weights leaves the sequence logits what they are without it."""
+    import torch
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    ic = make_input_columns("rico")
+    for context in ("id", "length"):
+        params = np_ref.init_params(ic, 16, 2, seed=-2, context=context)
+        assert params["encoder/input_task/embeddings"].shape == ((5 if context == "id" else ic["length"]["input_dim"]), 16)
+        b = synthetic_batch(ic, 3, 7, seed=1, ragged=True)
+        b["task"] = torch.tensor([[1], [4], [0]])
+        nb = {k: v.numpy() for k, v in b.items()}
+        o = np_ref.model_fwd(params, ic, nb, 2, maxlen=7, context=context)
+        t = torch_ref.model_fwd(torch_ref.to_torch(params, torch.float64, False), ic, b, 2, maxlen=7, context=context)
+        for k in o:
+            assert o[k].shape[1] == 7 and np.abs(o[k] - t[k].numpy()).max() < 1e-10, k
+        # the token only talks to the elements through attention: with V = 0 in every block it is inert
+        inert = dict(params)
+        for i in range(2):
+            inert["blocks/seq2seq_%d/attn/dense_value/kernel" % i] = np.zeros_like(inert["blocks/seq2seq_%d/attn/dense_value/kernel" % i])
+            inert["blocks/seq2seq_%d/attn/dense_value/bias" % i] = np.zeros_like(inert["blocks/seq2seq_%d/attn/dense_value/bias" % i])
+        with_tok = np_ref.model_fwd(inert, ic, nb, 2, maxlen=7, context=context)
+        without = np_ref.model_fwd({k: v for k, v in inert.items() if "input_task" not in k}, ic, nb, 2, maxlen=7)
+        for k in with_tok:
+            assert np.abs(with_tok[k] - without[k]).max() < 1e-12, k
