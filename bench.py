@@ -16,7 +16,8 @@ N grows = weak scaling):
      d_model 256, 4 blocks, seq_len 128, 256 documents/GPU, bf16 MFMA operands + f32 accumulation
   c3  c2 with masking_method=elem_pos_attr_img_txt (Ours-EXP: all five task types active)
   c4  c2 with 128 documents/GPU (global batch 1024 at --gpus 8)
-  c5  Crello Ours-EXP-FT shape: d_model 512, 8 blocks, seq_len 256, 64 documents/GPU
+  c5  Crello Ours-EXP-FT shape: d_model 512, 8 blocks, seq_len 256, 64 documents/GPU, "fp8": bf16 with
+      e4m3 QKV / FFN1 forward products (per-tensor scales, v_mfma_f32_16x16x32_fp8_fp8)
 
 Extra objects on the line (prompt section 4):
   roofline     - the kernel FAMILY with the largest summed duration in a step, measured with HIP events
@@ -50,7 +51,7 @@ CONFIGS = {
     "c4": dict(name="Crello Ours-IMP (global batch 1024 at 8 GPUs)", masking_method="random", D=256, L=4, S=128, B=128,
                dtype="bf16"),
     "c5": dict(name="Crello Ours-EXP-FT shape", masking_method="elem_pos_attr_img_txt", D=512, L=8, S=256, B=64,
-               dtype="bf16"),
+               dtype="fp8"),
 }
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
@@ -73,7 +74,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="override the configuration's compute dtype")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp8"], help="override the configuration's compute dtype")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -179,13 +180,13 @@ def cpu_baseline(ic, cfg):
     return out
 
 
-def bf16_deviation(ic, cfg, batch, masking_method, device):
-    """Loss of the bf16 path against the f32 (exact-f32 MFMA) path on the same batch, masks and
+def bf16_deviation(ic, cfg, batch, masking_method, device, dtype="bf16"):
+    """Loss of the bf16 (or fp8) path against the f32 (exact-f32 MFMA) path on the same batch, masks and
     dropout streams at step 0 (forward only)."""
     import torch
     from mfp.models.mfp import MFP
     losses = {}
-    for dt in ("fp32", "bf16"):
+    for dt in ("fp32", dtype):
         m = MFP(ic, num_blocks=cfg["L"], latent_dim=cfg["D"], dropout=0.1, l2=1e-2, masking_method=masking_method,
                 dtype=dt, device=device, seed=0)
         m.compile(learning_rate=1e-4, clipnorm=1.0)
@@ -195,10 +196,10 @@ def bf16_deviation(ic, cfg, batch, masking_method, device):
         torch.cuda.synchronize()
         losses[dt] = sums[:, 0].double().cpu()
         del m
-    f, b = losses["fp32"], losses["bf16"]
+    f, b = losses["fp32"], losses[dtype]
     tot = float(f.sum())
-    return {"bf16_loss_rel_dev": abs(float(b.sum()) - tot) / tot,
-            "bf16_worst_key_loss_rel_dev": float(((b - f).abs() / f.abs().clamp(min=1e-3 * tot)).max())}
+    return {"%s_loss_rel_dev" % dtype: abs(float(b.sum()) - tot) / tot,
+            "%s_worst_key_loss_rel_dev" % dtype: float(((b - f).abs() / f.abs().clamp(min=1e-3 * tot)).max())}
 
 
 def main():
@@ -238,8 +239,8 @@ def main():
     ic = make_input_columns("crello")
     batch = synthetic_batch(ic, B, S, seed=rank, ragged=False, device=device)
     extra = {}
-    if dtype == "bf16" and rank == 0 and not args.no_roofline:
-        extra = bf16_deviation(ic, cfg, batch, masking_method, device)
+    if dtype in ("bf16", "fp8") and rank == 0 and not args.no_roofline:
+        extra = bf16_deviation(ic, cfg, batch, masking_method, device, dtype)
     model = MFP(ic, num_blocks=NB, latent_dim=D, dropout=0.1, l2=1e-2,
                 masking_method=masking_method, dtype=dtype, device=device, seed=0)
     model.compile(learning_rate=1e-4, clipnorm=1.0)
@@ -300,7 +301,8 @@ def main():
         "metric": "elements_per_sec_train_step", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if dtype == "bf16" else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8 (e4m3 QKV/FFN1 forward products; bf16 elsewhere)"}[dtype],
+        "data": "synthetic",
         "config": {"workload": "%s (%s) train step, masking_method=%s: d_model=%d, %d DeepSVG blocks, seq_len=%d, "
                                "%d documents/GPU, dropout 0.1, l2 1e-2, Adam lr 1e-4 clipnorm 1.0"
                                % (cfg["name"], args.config, masking_method, D, NB, S, B),

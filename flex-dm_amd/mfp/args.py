@@ -30,8 +30,9 @@ _BASE_FLAGS = [
     ("--input_dtype", dict(type=str, default="set", choices=["set", "shuffled_set"])),
     ("--batch_size", dict(default=256, type=int)),
     # ---- additive (this engine)
-    ("--dtype", dict(default="bf16", choices=["fp32", "bf16"],
-                     help="compute dtype of the HIP kernels (fp32 = exact-f32 MFMA parity path)")),
+    ("--dtype", dict(default="bf16", choices=["fp32", "bf16", "fp8"],
+                     help="compute dtype of the HIP kernels (fp32 = exact-f32 MFMA parity path; fp8 = bf16 with "
+                          "e4m3 QKV / FFN1 forward products)")),
     ("--device", dict(default="cuda", help="HIP device of this rank")),
     ("--seq_len", dict(default=None, type=int, help="synthetic batches: padded sequence length")),
     ("--use_graph", dict(action="store_true", help="capture the train step into hipGraphs")),

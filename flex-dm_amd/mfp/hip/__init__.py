@@ -88,6 +88,9 @@ SIGNATURES = {
     "mfp_wgrad_group_splitk": (c_int32, [POINTER(WgradJob), c_int32, c_int32]),
     "mfp_wgrad_group_workspace_bytes": (c_size_t, [POINTER(WgradJob), c_int32, c_int32]),
     "mfp_wgrad_group": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mfp_absmax": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "mfp_quantize_fp8": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mfp_gemm_fp8": (c_int32, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p]),
     "mfp_layernorm_fwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_int32, c_void_p]),
     "mfp_layernorm_bwd": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                     c_float, c_uint64, c_uint64, c_void_p, c_void_p]),

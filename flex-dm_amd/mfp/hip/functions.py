@@ -29,10 +29,13 @@ WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
 LN_FUSE = os.environ.get("MFP_LN_FUSE", "0") == "1"
 
 
-def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False):
+def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False, w8=None):
     """``Dense(LayerNormalization(x))`` of a DeepSVG block (transformer.py:216-217 / 222-223): returns
-    (out, y = LN(x) in the compute dtype, mean, rstd)."""
+    (out, y = LN(x) in the compute dtype, mean, rstd).  ``w8`` = (fp8 kernel, scale): fp8 mode."""
     cdt = ctx.cdt
+    if w8 is not None:      # e4m3 operands, per-tensor scales (csrc/gemm_fp8.hip); y stays bf16 for the backward pass
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, cdt)
+        return ops.gemm_fp8(y, w8[0], w8[1], T, N, D, bias=bias, relu=relu), y, mean, rstd
     if LN_FUSE and cdt == torch.bfloat16 and D in (256, 512) and T * D * 2 < 0x7FFFFFF0:
         y = torch.empty((T, D), dtype=cdt, device=x.device)
         mean = torch.empty((T,), dtype=torch.float32, device=x.device)
@@ -308,14 +311,15 @@ class BlockFn(torch.autograd.Function):
         x = x.contiguous()
         qkv, y1, mean1, rstd1 = _ln_dense(ctx, x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
                                           st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
-                                          st.span(st.w, p + "attn/dense_query/bias", 3 * D))
+                                          st.span(st.w, p + "attn/dense_query/bias", 3 * D),
+                                          w8=st.w8(p + "attn/dense_query/kernel", 3 * D) if st.fp8 else None)
         a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
         x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
                       bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
                       dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
         h, y2, mean2, rstd2 = _ln_dense(ctx, x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
                                         st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, st.weight(p + "mlp/dense_0/bias"),
-                                        relu=True)
+                                        relu=True, w8=st.w8(p + "mlp/dense_0/kernel", 2 * D) if st.fp8 else None)
         x2 = ops.gemm(h, st.cw(p + "mlp/dense_1/kernel"), T, D, 2 * D, a_kmajor=True, b_kmajor=True,
                       bias=st.weight(p + "mlp/dense_1/bias"), residual=x1,
                       dropout=(ctx.p, ctx.seed, 2 * i + 2), step_ptr=ctx.step_ptr, out_dtype=torch.float32)

@@ -2,7 +2,8 @@
 
 The baselines in the reference's model.py (VanillaTransformer, AutoReg, BART) are unreachable
 from train.py/eval.py (mfp.py:230 asserts ``arch_type == "oneshot"``) and are not provided.
-New, additive constructor arguments: ``dtype`` ("fp32" parity path / "bf16" MFMA path),
+New, additive constructor arguments: ``dtype`` ("fp32" parity path / "bf16" MFMA path / "fp8": bf16 with
+e4m3 QKV and FFN1 forward products, BASELINE config c5),
 ``device``, ``seed``.
 """
 from typing import Dict, Optional, Union
@@ -16,7 +17,8 @@ from mfp.models.architecture.encoder import Encoder
 from mfp.models.architecture.transformer import Blocks
 from mfp.models.params import ModelLayout, ParamStore
 
-DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+          "fp8": torch.bfloat16}   # fp8: bf16 everywhere except the QKV / FFN1 forward products (e4m3 operands)
 
 
 def _first_seq_key(input_columns):
@@ -37,7 +39,7 @@ class Model:
         self.dropout, self.seed = dropout, seed
         self.layout = ModelLayout(input_columns, latent_dim, num_blocks, input_dtype, context)
         self.context = context
-        self.store = ParamStore(self.layout, device, DTYPES[dtype], l2=l2, seed=seed)
+        self.store = ParamStore(self.layout, device, DTYPES[dtype], l2=l2, seed=seed, fp8=(dtype == "fp8"))
         self.blocks = Blocks(self.store, num_blocks=num_blocks, block_type=block_type,
                              latent_dim=latent_dim, dropout=dropout, l2=l2)
         self.encoder = Encoder(input_columns, self.store, context=context, input_dtype=input_dtype,

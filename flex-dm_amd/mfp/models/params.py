@@ -171,8 +171,12 @@ class ParamStore:
     """Device buffers + named views for one model instance."""
 
     def __init__(self, layout: ModelLayout, device, compute_dtype: torch.dtype = torch.float32,
-                 l2: Optional[float] = 1e-2, seed: int = 0):
+                 l2: Optional[float] = 1e-2, seed: int = 0, fp8: bool = False):
         self.layout = layout
+        # fp8 mode (BASELINE config c5): e4m3 copies of the fused Q|K|V and FFN1 kernels ([out][in], as stored)
+        # with one scale per copy, refreshed after every optimizer step; everything else stays bf16
+        self.fp8 = bool(fp8) and compute_dtype == torch.bfloat16 and torch.device(device).type == "cuda"
+        self.shadow8, self.scale8, self._fp8_tensors = None, None, []
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
         n = layout.numel
@@ -199,6 +203,14 @@ class ParamStore:
                 from mfp.hip import ops
                 self.shadow_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
                 self._ttable = ops.TransposeTable(segs, device)
+        if self.fp8:
+            self.shadow8 = torch.zeros(n, dtype=torch.uint8, device=device)
+            D = layout.D
+            for i in range(layout.L):
+                q = layout.segments["blocks/seq2seq_%d/attn/dense_query/kernel" % i]
+                f = layout.segments["blocks/seq2seq_%d/mlp/dense_0/kernel" % i]
+                self._fp8_tensors += [(q.offset, 3 * D * D), (f.offset, f.size)]
+            self.scale8 = torch.ones(len(self._fp8_tensors), dtype=torch.float32, device=device)
         self.l2 = l2
         self.seg_l2 = torch.tensor([(l2 or 0.0) if s.l2 else 0.0 for s in layout.segments.values()],
                                    dtype=torch.float32, device=device)
@@ -273,6 +285,22 @@ class ParamStore:
         if self.shadow_t is not None:
             from mfp.hip import ops
             ops.transpose_cast_bf16(self.w, self.shadow_t, self._ttable)
+        self.refresh_fp8()
+
+    def refresh_fp8(self):
+        """Re-quantise the fp8 weight copies from the f32 master weights (per-tensor scale 448 / amax)."""
+        if not self.fp8:
+            return
+        from mfp.hip import ops
+        for j, (off, n) in enumerate(self._fp8_tensors):
+            ops.quantize_fp8(self.w[off:off + n], self.shadow8[off:off + n], self.scale8[j:j + 1])
+
+    def w8(self, name: str, rows: int):
+        """(fp8 view [rows][in], its scale [1]) of the kernel starting at ``name`` (fp8 mode only)."""
+        s = self.layout.segments[name]
+        j = [o for o, _ in self._fp8_tensors].index(s.offset)
+        cols = s.shape[-1]
+        return self.shadow8[s.offset:s.offset + rows * cols].view(rows, cols), self.scale8[j:j + 1]
 
     def refresh_shadow(self):
         if self.shadow is not None:

@@ -136,6 +136,22 @@ size_t mfp_wgrad_group_workspace_bytes(const mfp_wgrad_job* jobs /*host*/, int32
 int mfp_wgrad_group(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t splitk,
                     void* workspace, size_t workspace_bytes, uint32_t* tickets, mfp_stream_t stream);
 
+/* ------------------------------------------------------------------------ fp8 forward Dense
+ * BASELINE config c5 ("fp8 MFMA"): the QKV / FFN1 products of a block (transformer.py:85-90,161-166)
+ * with OCP e4m3 operands, per-tensor scales and f32 accumulation (v_mfma_f32_16x16x32_fp8_fp8).
+ *   mfp_absmax:       parts[MFP_ABSMAX_PARTS] = block maxima of |x| (x f32 or bf16, n elements); the
+ *                     consumer reduces them: scale = 448 / max(parts) (no atomics, no zero fill).
+ *   mfp_quantize_fp8: out[i] = e4m3(scale * w[i]), *scale_out = scale (weights, once per optimizer step).
+ *   mfp_gemm_fp8:     C[M][N] (bf16) = relu?((e4m3(sx X) Wq^T) / (sx sw) + bias), X bf16 [M][lda] quantised
+ *                     on the fly with sx from x_parts, Wq fp8 [N][K], sw = *w_scale. K % 16 == 0, N % 8 == 0. */
+#define MFP_ABSMAX_PARTS 256
+int mfp_absmax(const void* x, int64_t n, int32_t dtype, float* parts, mfp_stream_t stream);
+int mfp_quantize_fp8(const float* w, int64_t n, const float* parts, uint8_t* out, float* scale_out,
+                     mfp_stream_t stream);
+int mfp_gemm_fp8(const void* X, const uint8_t* Wq, const float* x_parts, const float* w_scale,
+                 const float* bias, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
+                 int32_t relu, mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- LayerNorm
  * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
  * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.

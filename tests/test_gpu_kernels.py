@@ -742,3 +742,32 @@ def test_gemm_layernorm_fused(T, K, N, relu):
     assert (y.float() - y2.float()).abs().max().item() <= 0.04     # at most one bf16 ulp apart at |y| <= 4
     assert (y != y2).float().mean().item() < 0.01
     assert_close(out, out2.float().cpu().double(), 3e-2, 2e-2, "fused vs unfused pair")
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 1536, 512, False), (2050, 1024, 512, True), (300, 768, 256, False), (64, 8, 16, True)])
+def test_gemm_fp8(M, N, K, relu):
+    """mfp_gemm_fp8 (BASELINE config c5): e4m3 operands with per-tensor scales 448 / amax, activations
+    quantised on the fly, f32 accumulation -- against a reference that quantises the same way on the host
+    (torch.float8_e4m3fn, round to nearest even), and within the expected e4m3 error of the unquantised product."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    X = bf16_round(torch.randn(M, K, generator=g) * 1.7)
+    W = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g) * 0.1
+    Wd = W.to(DEV)
+    Wq = torch.empty(N * K, dtype=torch.uint8, device=DEV)
+    wscale = torch.zeros(1, device=DEV)
+    ops.quantize_fp8(Wd.reshape(-1), Wq, wscale)
+    sw, sx = 448.0 / W.abs().max().item(), 448.0 / X.abs().max().item()
+    assert abs(wscale.item() - sw) <= 1e-5 * sw
+    Wq_ref = (W * sw).to(torch.float8_e4m3fn)
+    assert torch.equal(Wq.cpu().view(N, K), Wq_ref.view(torch.uint8))
+    out = ops.gemm_fp8(X.to(DEV, torch.bfloat16), Wq.view(N, K), wscale, M, N, K, bias=bias.to(DEV), relu=relu)
+    Xq_ref = (X * sx).to(torch.float8_e4m3fn)
+    want = (Xq_ref.double() @ Wq_ref.double().t()) / (sx * sw) + bias.double()
+    exact = X.double() @ W.double().t() + bias.double()
+    if relu:
+        want, exact = want.clamp(min=0), exact.clamp(min=0)
+    assert_close(out, want, 2e-2, 1e-2, "fp8 product vs host-quantised reference")      # + one bf16 rounding of the output
+    rel = (out.float().cpu().double() - exact).norm() / exact.norm()
+    assert rel < 0.06, rel                      # e4m3: 3 mantissa bits on both operands
