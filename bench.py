@@ -360,8 +360,9 @@ def main():
                          "hbm_frac": (blk[1] / nprof / (blk[2] / nprof * 1e-3) / 1e9) / HBM_PEAK_GBS,
                          "algorithmic_gb_per_step": blk[1] / nprof / 1e9,
                          "note": "all kernels of the DeepSVG blocks (LN, QKV/O/FFN GEMMs, attention, their input and "
-                                 "weight gradients): sum of event-timed launch durations in eager steps (side-stream "
-                                 "weight gradients overlap the main chain, so the sum over-counts wall time)"},
+                                 "weight gradients), all on one stream: sum of event-timed launch durations in EAGER "
+                                 "steps (launch gaps included; the same kernels under hipGraph replay sum to ~1.53 ms: "
+                                 "profiles/r02_step_dump.txt)"},
                      "step": {"achieved": step_tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": step_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS},
                      "kernels_us_per_step": {k: round(1e3 * v[3] / nprof, 1) for k, v in table}})
