@@ -10,6 +10,8 @@
 //     row-major LDS image with ds_read_b64_tr_b16.  The k-order of those MFMAs is the permuted
 //     {4g+j, 16+4g+j} order the C-fragment dictates; both operands use the same order.
 // Layout: qkv [B*S][3D] (q | k | v, head h at columns h*hd), out/dout [B*S][D], lse [B][H][S].
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -217,7 +219,7 @@ __device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long 
 
 // MAX_KT = key tiles held in registers: 8 (S <= 128) or 16 (S <= 256)
 template <int HD, int MAX_KT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
+__global__ __launch_bounds__(512, 2) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
                                                      bf16_t* __restrict__ out, float* __restrict__ lse, int S,
                                                      int H, float scale) {
   constexpr int HDP = HD < 32 ? 32 : HD, LDH = HDP + 8, KS = HDP / 32, DT = HD / 16;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16(const bf16_t* __restrict
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int nkt = SP / 16;
-  for (int qt = wave; qt < nkt; qt += 4) {
+  for (int qt = wave; qt < nkt; qt += (int)(blockDim.x >> 6)) {
     bf16x8 bq[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) bq[ks] = frag_k(Qs, LDH, qt * 16 + li, ks * 32, lg);
@@ -539,6 +541,8 @@ int fwd_hd(const void* qkv, const int* nvalid, void* out, float* lse, int B, int
     constexpr int LDH = (HD < 32 ? 32 : HD) + 8;
     const int SP = (S + 31) & ~31;
     size_t lds = (size_t)3 * SP * LDH * sizeof(bf16_t) + (size_t)SP * sizeof(float);
+    static const int fwd_threads = getenv("MFP_ATTN_FWD_THREADS") ? atoi(getenv("MFP_ATTN_FWD_THREADS")) : 512;   // 8 waves: one 16-query tile each at S = 128 (measured 20.0 vs 21.0 us with 4)
+    block = dim3(fwd_threads);
     if (SP <= 128) {
       if (int rc = set_lds(attn_fwd_bf16<HD, 8>, lds)) return rc;
       hipLaunchKernelGGL((attn_fwd_bf16<HD, 8>), grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);

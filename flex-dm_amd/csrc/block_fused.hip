@@ -1,0 +1,389 @@
+// Fused MLP half of a DeepSVG block, forward (reference architecture/transformer.py:222-225,161-171):
+//
+//     x2 = x1 + Dropout( relu( LN2(x1) W1 + b1 ) W2 + b2 )
+//
+// in ONE launch, for d_model 256.  Saved for the backward pass as before: y2 = LN2(x1) (bf16), mean /
+// rstd, h = relu(.) (bf16).  Unfused this is three launches (ln_fwd 12 us + FFN1 16.5 us + FFN2 27 us at
+// T = 32 768) moving 6.1 KB per element; fused it is 4.6 KB per element: y2 and h are written once and
+// never read back, x1 is read twice.
+//
+// Shape of the kernel (activation-stationary, all 8 waves compute; one workgroup per 128 rows = one per CU at
+// 256 documents x 128 elements):
+//   * LN: wave w normalises rows 16 w .. + 15 in the MFMA operand layout (lane (li, g) holds row li's columns
+//     32 ks + 8 g .. + 7, statistics by two xor-shuffles); the bf16 result passes through a swizzled LDS image,
+//     from which y2 leaves in whole rows and every wave picks up the B-operand fragments of ITS two row tiles;
+//   * products are issued transposed (D^T = W X^T: the weight tile is the MFMA A operand), so a lane ends up
+//     with 4 CONSECUTIVE output columns of its own row: bias / ReLU / dropout / residual are 16-byte vector
+//     work and h goes to LDS as the next product's operand rows;
+//   * wave (rp, nh) owns rows 32 rp .. + 31 and half of the output columns of every chunk: each weight fragment
+//     read from LDS feeds two MFMAs (with one row tile per wave the kernel sits at one ds_read_b128 per MFMA,
+//     100 % of the LDS read port -- measured 19 us of product time instead of 11);
+//   * the 512 KB of W1 | W2 stream from L2 straight into LDS (global_load_lds, 16 B per lane, source columns
+//     pre-swizzled) in 16 chunks of 32 KB through three buffers: chunk c + 2 is issued when chunk c starts and
+//     only chunk c + 1 is waited for at the barrier that ends chunk c (counted vmcnt; loads return in order);
+//   * the hidden layer is processed in quarters of 128 units (h quarter = 32 KB of LDS): FFN1 (2 chunks) ->
+//     FFN2 partial sums into 64 accumulator registers (2 chunks) -> next quarter; the x2 epilogue of each
+//     column half runs inside the last quarter's FFN2 chunks.
+// Measured at T = 32 768 (MI355X): 43 us against 56-58 us for the three launches.  Timeline of one workgroup
+// (s_memtime): LN prologue 8.5 us (33 MB of x1 from HBM), 14 product chunks of 1.05 us (0.45 us of MFMA each;
+// h and y2 leave in the background), last two chunks 13 us (x1 again + x2: 66 MB).  150 MB in 38 us = 3.9 TB/s
+// average: the kernel is within 25 % of what HBM delivers for its byte count; every workgroup is in the same
+// phase at the same time (one per CU), which is what keeps it from overlapping the prologue / epilogue traffic
+// with the products.  A first attempt in round 1 kept 64 rows per workgroup and lost to the three launches.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+struct MlpParams {
+  const float* x1; const float* gamma; const float* beta;
+  const unsigned short* W1; const float* b1;      // [512][256] bf16 (out, in), f32 [512]
+  const unsigned short* W2; const float* b2;      // [256][512] bf16 (out, in), f32 [256]
+  unsigned short* y2; float* mean; float* rstd;   // saved LN output / statistics
+  unsigned short* h;                              // [T][512] bf16
+  float* x2;                                      // [T][256] f32
+  int T; float eps;
+  float dropout_p; unsigned long long seed, offset; const int* step_ptr;
+#ifdef MFP_GEMM_TRACE
+  unsigned long long* trace;   // [workgroup][24] s_memrealtime stamps (100 MHz) of thread 0
+#endif
+};
+
+constexpr int MLP_D = 256, MLP_F = 512, MLP_ROWS = 128;
+// LDS images have 512- or 256-byte rows with the 16-byte slot index XORed with (row & 15): a ds_read_b128 of 16
+// rows x 4 slots (one MFMA operand fragment) then touches every bank once, and the image stays lane-linear for
+// the direct global -> LDS loads (the same involution is applied to the SOURCE column of each lane).
+constexpr int MLP_HS_B = MLP_ROWS * 256;            // h quarter: 128 rows x 128 hidden units, 32 KB
+constexpr int MLP_WS_B = 32768;                     // one weight chunk; three buffers in rotation
+constexpr int MLP_B1_OFF = MLP_HS_B + 3 * MLP_WS_B; // b1 (2 KB) | b2 (1 KB) | ...
+constexpr int MLP_LDS = MLP_B1_OFF + (MLP_F + 3 * MLP_D) * 4;   // ... | gamma (1 KB) | beta (1 KB)
+constexpr int MLP_CHUNKS = 16;
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+// Chunk c (32 KB of weights), hidden quarter q = c >> 2:
+//   c & 3 = 0, 1: W1 rows q*128 + 64 j .. + 63, all 256 k      -> image [64][512 B]   (FFN1 of the quarter)
+//   c & 3 = 2, 3: W2 rows 128 j .. + 127, k = q*128 .. + 127    -> image [128][256 B]  (FFN2 partial sums)
+// Wave (rp, nh) = (wave & 3, wave >> 2) owns rows 32 rp .. + 31 (two MFMA row tiles) and half of every chunk's
+// output columns: each weight fragment read from LDS feeds two products (LDS reads would otherwise cap the kernel
+// at one ds_read_b128 per MFMA: 100 % of the LDS read port).
+template <bool DROPOUT>
+__global__ __launch_bounds__(512) void mlp_fused_kernel(MlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const Hs = smem;
+  unsigned char* const Ws = smem + MLP_HS_B;
+  const float* const B1s = reinterpret_cast<const float*>(smem + MLP_B1_OFF);
+  const float* const B2s = B1s + MLP_F;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int rp = wave & 3, nh = wave >> 2;
+  const int row0 = blockIdx.x * MLP_ROWS;
+#ifdef MFP_GEMM_TRACE
+#define MLP_STAMP(i) do { if (tid == 0 && p.trace) p.trace[(long long)blockIdx.x * 24 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MLP_STAMP(i) do {} while (0)
+#endif
+  MLP_STAMP(0);    // start
+  // (the step counter is read first: its load must not sit between the counted waits of the chunk loop)
+  const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
+
+  // every global access goes through a buffer descriptor (SGPRs) + a 32-bit offset: no 64-bit address pairs
+  // in VGPRs (the kernel runs at the 256-register limit; a spill is a scratch access, and scratch accesses retire
+  // through the same in-order counter as the weight loads), and rows >= T need no predication (reads return 0,
+  // writes are dropped)
+  const unsigned int xbytes = (unsigned int)p.T * (MLP_D * 4), hbytes = (unsigned int)p.T * (MLP_F * 2);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W1), 0, MLP_F * MLP_D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W2), 0, MLP_F * MLP_D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(p.x2, 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, xbytes / 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, hbytes, 0x00020000);
+
+  // weight piece i of a chunk (1 KB per wave instruction): W1 chunks are 64 rows x 512 B (2 rows per piece), W2
+  // chunks 128 rows x 256 B out of 1 KB rows (4 rows per piece); the source column slot is the destination
+  // slot ^ (row & 15).  Piece i differs from piece 0 by a row step and one XOR on the slot
+  const unsigned int w1off = (unsigned int)((wave * 8 + (lane >> 5)) * 512 + (((lane & 31) ^ ((wave & 1) * 8 + (lane >> 5))) << 4));
+  const unsigned int w2off = (unsigned int)((wave * 16 + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
+  auto wload = [&](int c) {
+    const int q = c >> 2, ffn2 = (c >> 1) & 1, j = c & 1;
+    unsigned char* dst = Ws + ((c + 1) % 3) * MLP_WS_B + wave * 4096;
+    if (!ffn2) {
+      const int base = (q * 128 + j * 64) * (MLP_D * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_u8*)(dst + i * 1024), 16, w1off ^ (i << 5), base + i * 1024, 0, 0);
+    } else {
+      const int base = (j * 128) * (MLP_F * 2) + q * 256;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_u8*)(dst + i * 1024), 16, w2off ^ (i << 6), base + i * 4096, 0, 0);
+    }
+  };
+  wload(0);
+  wload(1);
+  if (tid < (MLP_F + 3 * MLP_D) / 4) {     // per-column vectors -> LDS (ds_read latency instead of L2 latency at every use)
+    const float* src = tid < 128 ? p.b1 + tid * 4 : tid < 192 ? p.b2 + (tid - 128) * 4
+                     : tid < 256 ? p.gamma + (tid - 192) * 4 : p.beta + (tid - 256) * 4;
+    *reinterpret_cast<f32x4*>(smem + MLP_B1_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(src);
+  }
+  const float* const Gs = B2s + MLP_D;
+  const float* const Bs = Gs + MLP_D;
+
+  // ---- LayerNorm: wave w normalises rows 16 w .. + 15 in the MFMA operand layout (lane (li, g) holds row li,
+  // columns 32 ks + 8 g .. + 7: statistics by two xor-shuffles), and the bf16 result goes through a [128][512 B]
+  // LDS image (Hs + the weight buffer chunk 2 will use) so that every wave can pick up the fragments of ITS
+  // two row tiles and y2 leaves in whole rows
+  bf16x8 xf[2][8];
+  {
+    const int lrow = wave * 16 + li, row = row0 + lrow;
+    const bool rok = row < p.T;
+    float v[8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const unsigned int vo = (unsigned int)row * (MLP_D * 4) + g * 32;
+      const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x1, vo + ks * 128, 0, 0));
+      const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x1, vo + ks * 128 + 16, 0, 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[ks][e] = a[e]; v[ks][4 + e] = b[e]; s += a[e] + b[e]; }
+    }
+    __syncthreads();      // gamma / beta are in LDS
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mu = s * (1.0f / MLP_D);
+    float qq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[ks][e] -= mu; qq += v[ks][e] * v[ks][e]; }
+    qq += __shfl_xor(qq, 16, 64);
+    qq += __shfl_xor(qq, 32, 64);
+    const float rs = rsqrtf(qq * (1.0f / MLP_D) + p.eps);
+    if (g == 0 && rok) { p.mean[row] = mu; p.rstd[row] = rs; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int col = ks * 32 + 8 * g;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gs + col), g1 = *reinterpret_cast<const f32x4*>(Gs + col + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + col), b1 = *reinterpret_cast<const f32x4*>(Bs + col + 4);
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] = v[ks][e] * rs * g0[e] + b0[e]; y[4 + e] = v[ks][4 + e] * rs * g1[e] + b1[e]; }
+      const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+      *reinterpret_cast<u32x4*>(smem + lrow * 512 + (((ks * 4 + g) ^ li) << 4)) = pk;
+    }
+  }
+  __syncthreads();
+  // y2 leaves in whole rows, straight from the image.  No wait for these stores before the barrier below: the
+  // weight loads of chunks 0 and 1 were the first memory operations of the kernel and every x1 load issued
+  // after them has been consumed, so (in-order retirement) they have landed
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 512 * i, r = idx >> 5, c16 = idx & 31;
+    const u32x4 yv = *reinterpret_cast<const u32x4*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4));
+    __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y2, (unsigned int)(row0 + r) * (MLP_D * 2) + c16 * 16, 0, 0);
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rp * 32 + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+  MLP_STAMP(1);  // LN done, fragments picked up
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();       // chunks 0, 1 are in LDS; the y2 image has been read by everyone
+  MLP_STAMP(2);
+
+  f32x4 acc2[8][2];      // first written by the first quarter's FFN2 chunks (not live before)
+  bf16x8 hf[2][4];
+  const float inv_keep = DROPOUT ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const unsigned long long rng_off = p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE;
+  const unsigned int dthr = drop_thr16(p.dropout_p), dkey = drop_key(p.seed, rng_off);
+  // slot term of a fragment address: (4 ks + g) ^ li, in bytes (ks < 4; ks >= 4 adds 256 in the 512-byte images)
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+
+  auto chunk = [&](auto cc_) {
+    constexpr int c = decltype(cc_)::value;
+    constexpr int q = c >> 2, ffn2 = (c >> 1) & 1, j = c & 1;
+    if (c + 2 < MLP_CHUNKS) wload(c + 2);    // into the buffer the barrier that ended chunk c - 1 released
+    f32x4 res[4][2];
+    if (q == 3 && ffn2) {
+      // residual rows for this chunk's epilogue, ahead of the stores below: a wait for a load also waits for
+      // every older store
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = row0 + rp * 32 + rt * 16 + li;
+          res[nt][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              rs_x1, (unsigned int)row * (MLP_D * 4) + (nh * 4 * 16 + 4 * g) * 4 + (j * 8 + nt) * 64, 0, 0));
+        }
+    }
+    const unsigned char* wb = Ws + ((c + 1) % 3) * MLP_WS_B;
+    if (!ffn2) {
+      // FFN1: h[row][q*128 + j*64 + (2 nh + nt)*16 + 4 g + r] = relu(sum_k W1[n][k] y2[row][k] + b1[n])
+      const unsigned char* wa = wb + ((nh * 2) * 16 + li) * 512;
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 wf[3][2];
+#pragma unroll
+      for (int pre = 0; pre < 2; ++pre)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wf[pre][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[pre & 3] + (pre >> 2) * 256);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 2 < 8) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            wf[(ks + 2) % 3][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[(ks + 2) & 3] + ((ks + 2) >> 2) * 256);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % 3][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(B1s + q * 128 + j * 64 + (nh * 2 + nt) * 16 + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const u32x2 pk = {pack_bf16x2(fmaxf(acc[nt][rt][0] + bb[0], 0.f), fmaxf(acc[nt][rt][1] + bb[1], 0.f)),
+                            pack_bf16x2(fmaxf(acc[nt][rt][2] + bb[2], 0.f), fmaxf(acc[nt][rt][3] + bb[3], 0.f))};
+          *reinterpret_cast<u32x2*>(Hs + (rp * 32 + rt * 16 + li) * 256 + (((j * 8 + (nh * 2 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = pk;
+        }
+      }
+    } else {
+      // FFN2 partial sums over this quarter of the hidden units: column (8 j + 4 nh + nt)*16 + 4 g + r.
+      // Last quarter: these columns are final after this chunk -- their epilogue (x2 = x1 + dropout(. + b2),
+      // 4 consecutive columns per lane and tile) runs here, so half of the residual reads and x2 stores overlap
+      // the last chunk's products
+      constexpr bool last = q == 3;
+      const unsigned char* wa = wb + ((nh * 4) * 16 + li) * 256;
+      bf16x8 wf[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[ks + 1]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
+                                                                         (q == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
+      }
+      if (last) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = row0 + rp * 32 + rt * 16 + li;
+          const unsigned int rowh = drop_row(dkey, (unsigned int)row);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int n = (j * 8 + nh * 4 + nt) * 16 + 4 * g;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(B2s + n);
+            bool keep[4] = {true, true, true, true};
+            if (DROPOUT) drop_keep4(rowh, (unsigned int)n, dthr, keep);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = res[nt][rt][r] + (keep[r] ? (acc2[j * 4 + nt][rt][r] + bb[r]) * inv_keep : 0.f);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_x2,
+                                                   (unsigned int)row * (MLP_D * 4) + (nh * 4 * 16 + 4 * g) * 4 + (j * 8 + nt) * 64, 0, 0);
+          }
+        }
+      }
+    }
+    // chunk c + 1 has landed: memory operations retire in order, so it is enough that no more operations are
+    // outstanding than were issued AFTER its loads.  The h stores (4, issued behind the barrier of chunks 1, 5, 9,
+    // 13) are younger than the loads of the chunk two ahead: the wait that includes them comes two chunks later
+    // (a store acknowledged late by a busy memory system otherwise holds every wave at the barrier -- measured:
+    // chunks behind a store burst took 3-6 us instead of 1).  This wave's LDS writes are done (lgkmcnt), and
+    // after the barrier chunk c's buffer is free again
+    {
+      constexpr int st_prev = (c & 3) == 2 ? 4 : 0;                       // h stores of the previous chunk's tail
+      constexpr int st_this = c == 0 ? 10 : c == 14 ? 16 : 0;             // prologue stores (chunk 1 landed long ago); residual loads + x2 stores
+      constexpr int allowed = st_prev + (c + 2 < MLP_CHUNKS ? 4 : 0) + st_this;
+      if (c + 1 < MLP_CHUNKS) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    MLP_STAMP(3 + c);   // chunk c done
+    if (!ffn2 && j == 1) {
+      // the h quarter is complete in LDS: write it out (256-byte row pieces, 16 B per lane) and pick up this
+      // wave's rows as the next product's operand fragments
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 4, c16 = idx & 15;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(Hs + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_h,
+                                               (unsigned int)(row0 + r) * (MLP_F * 2) + c16 * 16 + q * 256, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
+    }
+    // (the next quarter's first FFN1 chunk rewrites Hs: two barriers -- the ends of this quarter's FFN2 chunks --
+    //  lie between every wave's hf reads above and those writes)
+  };
+  chunk(std::integral_constant<int, 0>{});  chunk(std::integral_constant<int, 1>{});
+  chunk(std::integral_constant<int, 2>{});  chunk(std::integral_constant<int, 3>{});
+  chunk(std::integral_constant<int, 4>{});  chunk(std::integral_constant<int, 5>{});
+  chunk(std::integral_constant<int, 6>{});  chunk(std::integral_constant<int, 7>{});
+  chunk(std::integral_constant<int, 8>{});  chunk(std::integral_constant<int, 9>{});
+  chunk(std::integral_constant<int, 10>{}); chunk(std::integral_constant<int, 11>{});
+  chunk(std::integral_constant<int, 12>{}); chunk(std::integral_constant<int, 13>{});
+  chunk(std::integral_constant<int, 14>{}); chunk(std::integral_constant<int, 15>{});
+  MLP_STAMP(19);
+}
+
+}  // namespace
+
+#ifdef MFP_GEMM_TRACE
+static unsigned long long* g_mlp_trace = nullptr;
+extern "C" void mfp_mlp_trace_buffer(void* ptr) { g_mlp_trace = reinterpret_cast<unsigned long long*>(ptr); }
+#endif
+
+extern "C" int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const float* beta, const void* W1, const float* b1,
+                                 const void* W2, const float* b2, void* y2, float* mean, float* rstd, void* h, float* x2,
+                                 int32_t T, int32_t D, float eps, float dropout_p, uint64_t seed, uint64_t offset,
+                                 const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(x1 && gamma && beta && W1 && b1 && W2 && b2 && y2 && mean && rstd && h && x2);
+  MFP_CHECK_ARG(T > 0 && T <= (1 << 21) && D == MLP_D && eps > 0.f && dropout_p >= 0.f && dropout_p < 1.f);
+  MFP_CHECK_ARG(((uintptr_t)x1 % 16) == 0 && ((uintptr_t)W1 % 16) == 0 && ((uintptr_t)W2 % 16) == 0 &&
+                ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)x2 % 16) == 0);
+  MlpParams p;
+  p.x1 = x1; p.gamma = gamma; p.beta = beta;
+  p.W1 = reinterpret_cast<const unsigned short*>(W1); p.b1 = b1;
+  p.W2 = reinterpret_cast<const unsigned short*>(W2); p.b2 = b2;
+  p.y2 = reinterpret_cast<unsigned short*>(y2); p.mean = mean; p.rstd = rstd;
+  p.h = reinterpret_cast<unsigned short*>(h); p.x2 = x2;
+  p.T = T; p.eps = eps; p.dropout_p = dropout_p; p.seed = seed; p.offset = offset; p.step_ptr = step_ptr;
+#ifdef MFP_GEMM_TRACE
+  p.trace = g_mlp_trace;
+#endif
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_mlp_fused_fwd: cannot raise dynamic LDS to %d: %s", MLP_LDS, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int blocks = (T + MLP_ROWS - 1) / MLP_ROWS;
+  if (dropout_p > 0.f)
+    hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(blocks), dim3(512), MLP_LDS, st, p);
+  else
+    hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(blocks), dim3(512), MLP_LDS, st, p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

@@ -499,6 +499,7 @@ int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     ncu = n;
+    if (const char* ov = getenv("MFP_WS_NCU")) ncu = atoi(ov);   // experiment: size the persistent grid for part of the chip
   }
   // narrow column slices (half the weight prologue per CU, twice the row tiles per workgroup) pay
   // off when a full-width slice would leave a workgroup only a handful of 32-row tiles

@@ -27,6 +27,9 @@ WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
 # bf16 path, d_model 256 / 512: LayerNorm forward fused into the X staging of the product behind it (QKV,
 # FFN1: MFP_GEMM_LNORM_A, csrc/gemm_ws.h); 0 = stand-alone ln_fwd launch + product (A/B switch)
 LN_FUSE = os.environ.get("MFP_LN_FUSE", "0") == "1"
+# bf16 path, d_model 256: LN2 + FFN1 + ReLU + FFN2 + dropout + residual of a block as ONE launch
+# (csrc/block_fused.hip); 0 = ln_fwd + two products (A/B switch)
+MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
 
 
 def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False, w8=None):
@@ -317,6 +320,14 @@ class BlockFn(torch.autograd.Function):
         x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
                       bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
                       dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
+        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and not st.fp8:
+            x2, y2, mean2, rstd2, h = ops.mlp_fused_fwd(
+                x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"), st.cw(p + "mlp/dense_0/kernel"),
+                st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"), st.weight(p + "mlp/dense_1/bias"),
+                (ctx.p, ctx.seed, 2 * i + 2), ctx.step_ptr)
+            fctx.ctx, fctx.i = ctx, i
+            fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
+            return x2
         h, y2, mean2, rstd2 = _ln_dense(ctx, x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
                                         st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, st.weight(p + "mlp/dense_0/bias"),
                                         relu=True, w8=st.w8(p + "mlp/dense_0/kernel", 2 * D) if st.fp8 else None)

@@ -294,6 +294,27 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
     return y, mean, rstd
 
 
+def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2, b2, dropout: Tuple[float, int, int], step_ptr=None):
+    """x2 = x1 + Dropout(relu(LN(x1) W1^T + b1) W2^T + b2) in one launch (d_model 256, bf16 weights).
+    Returns (x2, y2, mean, rstd, h) -- the tensors the three-launch path saves for backward."""
+    lib = load()
+    T, D = x1.shape
+    F = 2 * D
+    dev = x1.device
+    y2 = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    h = torch.empty((T, F), dtype=torch.bfloat16, device=dev)
+    mean = torch.empty((T,), dtype=torch.float32, device=dev)
+    rstd = torch.empty((T,), dtype=torch.float32, device=dev)
+    x2 = torch.empty((T, D), dtype=torch.float32, device=dev)
+    with _timed("mlp_fused_kernel", 2 * 2 * T * D * F, T * (D * 4 * 3 + D * 2 + F * 2) + 2 * D * F * 2):
+        check(lib.mfp_mlp_fused_fwd(_ptr(x1), _ptr(gamma), _ptr(beta), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
+                                    _ptr(y2), _ptr(mean), _ptr(rstd), _ptr(h), _ptr(x2), T, D, LN_EPS,
+                                    float(dropout[0]), int(dropout[1]), int(dropout[2]),
+                                    _ptr(step_ptr) if step_ptr is not None else None, _stream()),
+              "mfp_mlp_fused_fwd")
+    return x2, y2, mean, rstd, h
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,
                   dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None, defer=None,
                   jobs: Optional[list] = None):

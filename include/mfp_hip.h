@@ -152,6 +152,17 @@ int mfp_gemm_fp8(const void* X, const uint8_t* Wq, const float* x_parts, const f
                  const float* bias, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
                  int32_t relu, mfp_stream_t stream);
 
+/* --------------------------------------------------------------------------- fused MLP half (forward)
+ * x2 = x1 + Dropout(relu(LN(x1) W1^T + b1) W2^T + b2) in one launch (transformer.py:161-171,222-225),
+ * d_model 256 / dim_feedforward 512 only.  x1, x2 f32 [T,256]; W1 bf16 [512][256], W2 bf16 [256][512]
+ * (out, in); saved for the backward pass: y2 = LN(x1) bf16 [T,256], mean/rstd f32 [T], h bf16 [T,512].
+ * Dropout stream identical to MFP_GEMM_DROPOUT of mfp_gemm (same seed / offset / step_ptr meaning).
+ */
+int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const float* beta, const void* W1,
+                      const float* b1, const void* W2, const float* b2, void* y2, float* mean,
+                      float* rstd, void* h, float* x2, int32_t T, int32_t D, float eps, float dropout_p,
+                      uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- LayerNorm
  * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
  * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.

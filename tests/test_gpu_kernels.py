@@ -771,3 +771,45 @@ def test_gemm_fp8(M, N, K, relu):
     assert_close(out, want, 2e-2, 1e-2, "fp8 product vs host-quantised reference")      # + one bf16 rounding of the output
     rel = (out.float().cpu().double() - exact).norm() / exact.norm()
     assert rel < 0.06, rel                      # e4m3: 3 mantissa bits on both operands
+
+
+@pytest.mark.parametrize("T,p", [(4096, 0.1), (1000, 0.0), (33, 0.1), (128 * 3 + 5, 0.1)])
+def test_mlp_fused_fwd(T, p):
+    """mfp_mlp_fused_fwd: x2 = x1 + Dropout(relu(LN(x1) W1^T + b1) W2^T + b2) in one launch
+    (transformer.py:161-171,222-225) against the three-launch path it replaces (same bf16 rounding points,
+    same dropout stream) and a double reference; ragged last row group."""
+    ops = _ops()
+    D, F = 256, 512
+    g = torch.Generator().manual_seed(T)
+    x1 = (torch.randn(T, D, generator=g) * (1.0 + torch.rand(T, 1, generator=g)) + 0.3 * torch.randn(T, 1, generator=g))
+    gamma, beta = 1.0 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    W1 = bf16_round(torch.randn(F, D, generator=g) * 0.06)
+    W2 = bf16_round(torch.randn(D, F, generator=g) * 0.05)
+    b1, b2 = torch.randn(F, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+    xd, gd, bd = x1.to(DEV), gamma.to(DEV), beta.to(DEV)
+    W1d, W2d, b1d, b2d = W1.to(DEV, torch.bfloat16), W2.to(DEV, torch.bfloat16), b1.to(DEV), b2.to(DEV)
+    step = torch.tensor([3], dtype=torch.int32, device=DEV)
+    x2, y2, mean, rstd, h = ops.mlp_fused_fwd(xd, gd, bd, W1d, b1d, W2d, b2d, (p, 1234, 6), step)
+    # the path it replaces
+    y2u, meanu, rstdu = ops.layernorm_fwd(xd, gd, bd, torch.bfloat16)
+    hu = ops.gemm(y2u, W1d, T, F, D, a_kmajor=True, b_kmajor=True, bias=b1d, relu=True, out_dtype=torch.bfloat16)
+    x2u = ops.gemm(hu, W2d, T, D, F, a_kmajor=True, b_kmajor=True, bias=b2d, residual=xd,
+                   dropout=(p, 1234, 6), step_ptr=step, out_dtype=torch.float32)
+    assert_close(mean, meanu.cpu().double(), 1e-5, 1e-5, "mean")
+    assert_close(rstd, rstdu.cpu().double(), 1e-5, 1e-5, "rstd")
+    assert (y2.float() - y2u.float()).abs().max().item() <= 0.04
+    assert (y2 != y2u).float().mean().item() < 0.01
+    assert (h != hu).float().mean().item() < 0.02
+    assert_close(h, hu.float().cpu().double(), 3e-2, 2e-2, "h vs unfused")
+    # the dropout mask is the unfused product's, element for element: dropped entries are exactly x1
+    dropped_u, dropped = (x2u == xd), (x2 == xd)
+    assert torch.equal(dropped, dropped_u)
+    if p > 0:
+        assert abs(dropped.float().mean().item() - p) < 0.02
+    assert_close(x2, x2u.cpu().double(), 3e-2, 2e-2, "x2 vs unfused")
+    # double reference from the kernel's own rounded intermediates
+    keep = (~dropped).cpu().double() / (1.0 - p) if p > 0 else torch.ones(T, D, dtype=torch.double)
+    hr = (y2.float().cpu().double() @ W1.double().t() + b1.double()).clamp(min=0)
+    assert_close(h, hr, 2e-2, 1e-2, "h vs double")
+    want = x1.double() + keep * (h.float().cpu().double() @ W2.double().t() + b2.double())
+    assert_close(x2, want, 2e-3, 2e-3, "x2 vs double")

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Stand-alone timing of the MLP half of a block at the timed shape (T = 256 x 128, d_model 256):
+the fused launch (csrc/block_fused.hip) beside ln_fwd + FFN1 + FFN2."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "flex-dm_amd")]
+import torch  # noqa: E402
+
+from mfp.hip import ops  # noqa: E402
+
+T, D = int(os.environ.get("T", 32768)), 256
+F = 2 * D
+dev = "cuda"
+
+
+KEEP = []
+
+
+def timeit(fn, n=48):
+    """Graph replay (launch overhead out of the picture, as in the step).  Every iteration reads its own x1
+    and keeps its outputs alive, as the train step does with the tensors saved for backward: the working set
+    (n x 115 MB) does not fit the 256 MB infinity cache -- re-using one set of buffers flatters a kernel
+    that is bound by memory traffic (fused: 43 us hot, 58 us with distinct buffers)."""
+    for _ in range(3):
+        fn(0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(n):
+            KEEP.append(fn(i % len(X1)))
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / n
+
+
+X1 = [torch.randn(T, D, device=dev) for _ in range(int(os.environ.get('NSETS', 12)))]
+gamma, beta = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+W1 = (torch.randn(F, D, device=dev) * 0.06).to(torch.bfloat16)
+W2 = (torch.randn(D, F, device=dev) * 0.05).to(torch.bfloat16)
+b1, b2 = torch.zeros(F, device=dev), torch.zeros(D, device=dev)
+step = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+def unfused(i):
+    x1 = X1[i]
+    y2, m, r = ops.layernorm_fwd(x1, gamma, beta, torch.bfloat16)
+    h = ops.gemm(y2, W1, T, F, D, a_kmajor=True, b_kmajor=True, bias=b1, relu=True, out_dtype=torch.bfloat16)
+    return (y2, m, r, h, ops.gemm(h, W2, T, D, F, a_kmajor=True, b_kmajor=True, bias=b2, residual=x1, dropout=(0.1, 7, 2),
+                                  step_ptr=step, out_dtype=torch.float32))
+
+
+def fused(i):
+    return ops.mlp_fused_fwd(X1[i], gamma, beta, W1, b1, W2, b2, (0.1, 7, 2), step)
+
+
+with torch.cuda.stream(torch.cuda.Stream()):
+    tu = timeit(unfused)
+    KEEP.clear()
+    tf = timeit(fused)
+nb = T * (D * 4 * 2 + D * 2 + F * 2)
+print("MLP half T=%d: unfused %.1f us   fused %.1f us (%.2f TB/s algorithmic, %.0f TFLOP/s)"
+      % (T, tu, tf, nb / tf / 1e6, 4 * T * D * F / tf / 1e6))
