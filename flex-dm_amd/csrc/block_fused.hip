@@ -341,6 +341,224 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpParams p) {
   MLP_STAMP(19);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of the MLP half, input gradients (reference: Keras autodiff of transformer.py:161-171,224-225):
+//
+//     dh  = (d_o2 W2) * [h > 0]           d_o2 = dropout-masked gradient of the block output, bf16 [T,256]
+//     dy2 = dh W1                          (gradient of LN2's output, consumed by ln_bwd)
+//
+// The same machine as the forward kernel with W2^T [512][256] in the place of W1 and W1^T [256][512] in the
+// place of W2 (the transposed bf16 shadows): d_o2 fragments come straight from global memory (no LayerNorm),
+// the ReLU mask comes from the saved h, whose quarter is loaded into its own LDS image two chunks ahead (every lane
+// reads the 8 bytes that match the 4 values it holds), and dy2 leaves as bf16 through LDS in whole rows.
+// Unfused: two launches, 23 + 17.5 us, 131 MB; fused 98 MB.
+struct MlpBwdParams {
+  const unsigned short* d_o2;      // [T][256] bf16
+  const unsigned short* h;         // [T][512] bf16 (saved by the forward pass)
+  const unsigned short* W2t;       // [512][256] bf16: W2t[k][n] = W2[n][k]
+  const unsigned short* W1t;       // [256][512] bf16: W1t[c][k] = W1[k][c]
+  unsigned short* dh;              // [T][512] bf16
+  unsigned short* dy2;             // [T][256] bf16
+  int T;
+#ifdef MFP_GEMM_TRACE
+  unsigned long long* trace;
+#endif
+};
+
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const Hs = smem;
+  unsigned char* const Ws = smem + MLP_HS_B;
+  unsigned char* const Hm = smem + MLP_HS_B + 3 * MLP_WS_B;      // saved h of the quarter (ReLU mask), own 32 KB image
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int rp = wave & 3, nh = wave >> 2;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  const unsigned int xbytes = (unsigned int)p.T * (MLP_D * 2), hbytes = (unsigned int)p.T * (MLP_F * 2);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W2t), 0, MLP_F * MLP_D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W1t), 0, MLP_F * MLP_D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.d_o2), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.h), 0, hbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(p.dh, 0, hbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(p.dy2, 0, xbytes, 0x00020000);
+
+  // Memory roles are split by latency class, because a wave's memory operations retire in order: waves 0-3 issue
+  // ALL weight pieces (L2 hits, needed every chunk, counted waits), waves 4-7 issue all pieces of the saved h (first
+  // touched since the forward pass: HBM latency under a burst of 8 MB per quarter across the chip).  With both in
+  // one queue the weight loads queue up behind the h loads (measured: the chunks behind an h load took 2-4 us)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);       // scalar: the role branches below are uniform
+  const int wl = wv & 3;
+  // weight piece i (0..7) of this wave: W "1" chunks are 64 rows x 512 B (2 rows per 1 KB piece), W "2" chunks 128
+  // rows x 256 B out of 1 KB rows (4 rows per piece); source column slot = destination slot ^ (row & 15)
+  const unsigned int w1off = (unsigned int)((wl * 16 + (lane >> 5)) * 512 + (((lane & 31) ^ (lane >> 5)) << 4));
+  const unsigned int w2off = (unsigned int)((wl * 32 + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
+  auto wload = [&](int c) {
+    if (wv >= 4) return;
+    const int q = c >> 2, ffn2 = (c >> 1) & 1, j = c & 1;
+    unsigned char* dst = Ws + ((c + 1) % 3) * MLP_WS_B + wl * 8192;
+    if (!ffn2) {
+      const int base = (q * 128 + j * 64) * (MLP_D * 2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_u8*)(dst + i * 1024), 16, w1off ^ (i << 5), base + i * 1024, 0, 0);
+    } else {
+      const int base = (j * 128) * (MLP_F * 2) + q * 256;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_u8*)(dst + i * 1024), 16, w2off ^ ((i & 3) << 6), base + i * 4096, 0, 0);
+    }
+  };
+  // h quarter q -> image [128][256 B]: the row / slot pattern of a W "2" chunk, on the 1 KB rows of h
+  const unsigned int hoff = (unsigned int)((row0 + wl * 32 + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
+  auto hload = [&](int q) {
+    if (wv < 4) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_u8*)(Hm + wl * 8192 + i * 1024), 16, hoff ^ ((i & 3) << 6), q * 256 + i * 4096, 0, 0);
+  };
+  MLP_STAMP(0);
+  wload(0);
+  wload(1);
+  hload(0);
+  // operand fragments of d_o2: lane (li, g) holds row li of the tile, columns 32 ks + 8 g .. + 7
+  bf16x8 xf[2][8];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      xf[rt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+          rs_do, (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (MLP_D * 2) + g * 16 + ks * 64, 0, 0));
+  MLP_STAMP(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();       // chunks 0, 1 and the first h quarter are in LDS
+  MLP_STAMP(2);
+
+  f32x4 acc2[8][2];
+  bf16x8 hf[2][4];
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+
+  auto chunk = [&](auto cc_) {
+    constexpr int c = decltype(cc_)::value;
+    constexpr int q = c >> 2, ffn2 = (c >> 1) & 1, j = c & 1;
+    // the next quarter's h goes into its image while the two dy2 chunks of this quarter run (the masks of this
+    // quarter were read before the barrier that ended the previous chunk); waited for at the end of the next chunk
+    if (ffn2 && j == 0 && q < 3) hload(q + 1);
+    if (c + 2 < MLP_CHUNKS) wload(c + 2);
+    const unsigned char* wb = Ws + ((c + 1) % 3) * MLP_WS_B;
+    if (!ffn2) {
+      // dh[row][q*128 + j*64 + (2 nh + nt)*16 + 4 g + r] = [h > 0] * sum_n W2t[k][n] d_o2[row][n]
+      const unsigned char* wa = wb + ((nh * 2) * 16 + li) * 512;
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 wf[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[0]);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int slot = (rp * 32 + rt * 16 + li) * 256 + (((j * 8 + (nh * 2 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8;
+          const u32x2 hv = *reinterpret_cast<const u32x2*>(Hm + slot);      // 4 bf16 of h: positive <=> nonzero, sign clear
+          const bool m0 = (short)(hv[0] & 0xFFFFu) > 0, m1 = (int)hv[0] >= 0x10000;
+          const bool m2 = (short)(hv[1] & 0xFFFFu) > 0, m3 = (int)hv[1] >= 0x10000;
+          const u32x2 pk = {pack_bf16x2(m0 ? acc[nt][rt][0] : 0.f, m1 ? acc[nt][rt][1] : 0.f),
+                            pack_bf16x2(m2 ? acc[nt][rt][2] : 0.f, m3 ? acc[nt][rt][3] : 0.f)};
+          *reinterpret_cast<u32x2*>(Hs + slot) = pk;
+        }
+    } else {
+      const unsigned char* wa = wb + ((nh * 4) * 16 + li) * 256;
+      bf16x8 wf[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[ks + 1]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
+                                                                         (q == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
+      }
+    }
+    if (c >= MLP_CHUNKS - 2) {
+      // dy2 columns 128 j .. + 127 are final: bf16 into a free [128][256 B] image -- the weight buffer of the
+      // chunk before this one (every wave finished reading it before the barrier that ended that chunk)
+      unsigned char* img = Ws + (c % 3) * MLP_WS_B;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const u32x2 pk = {pack_bf16x2(acc2[j * 4 + nt][rt][0], acc2[j * 4 + nt][rt][1]), pack_bf16x2(acc2[j * 4 + nt][rt][2], acc2[j * 4 + nt][rt][3])};
+          *reinterpret_cast<u32x2*>(img + (rp * 32 + rt * 16 + li) * 256 + ((((nh * 4 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = pk;
+        }
+    }
+    // end of chunk.  Weight waves: chunk c + 1 has landed when at most the 8 loads of chunk c + 2 and the stores
+    // issued behind the previous barrier (dh: 4, chunks 2, 6, 10, 14; dy2 of chunk 14: 4) are younger.  h waves: the
+    // next h quarter must be there at the end of a quarter's last chunk; otherwise nothing to wait for
+    {
+      constexpr int st_prev = ((c & 3) == 2 || c == MLP_CHUNKS - 1) ? 4 : 0;
+      constexpr int allowed_w = st_prev + (c + 2 < MLP_CHUNKS ? 8 : 0);
+      constexpr bool h_due = (c & 3) == 3 && q < 3;
+      if (wv < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
+      else if (h_due) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    MLP_STAMP(3 + c);
+    if (!ffn2 && j == 1) {
+      // dh quarter complete in LDS: write it out in 256-byte row pieces and pick up this wave's operand fragments
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 4, c16 = idx & 15;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(Hs + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_dh,
+                                               (unsigned int)(row0 + r) * (MLP_F * 2) + c16 * 16 + q * 256, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
+    }
+    if (c >= MLP_CHUNKS - 2) {
+      const unsigned char* img = Ws + (c % 3) * MLP_WS_B;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 4, c16 = idx & 15;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(img + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_dy,
+                                               (unsigned int)(row0 + r) * (MLP_D * 2) + c16 * 16 + j * 256, 0, 0);
+      }
+    }
+  };
+  chunk(std::integral_constant<int, 0>{});  chunk(std::integral_constant<int, 1>{});
+  chunk(std::integral_constant<int, 2>{});  chunk(std::integral_constant<int, 3>{});
+  chunk(std::integral_constant<int, 4>{});  chunk(std::integral_constant<int, 5>{});
+  chunk(std::integral_constant<int, 6>{});  chunk(std::integral_constant<int, 7>{});
+  chunk(std::integral_constant<int, 8>{});  chunk(std::integral_constant<int, 9>{});
+  chunk(std::integral_constant<int, 10>{}); chunk(std::integral_constant<int, 11>{});
+  chunk(std::integral_constant<int, 12>{}); chunk(std::integral_constant<int, 13>{});
+  chunk(std::integral_constant<int, 14>{}); chunk(std::integral_constant<int, 15>{});
+  MLP_STAMP(19);
+}
+
 }  // namespace
 
 #ifdef MFP_GEMM_TRACE
@@ -384,6 +602,36 @@ extern "C" int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const floa
     hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(blocks), dim3(512), MLP_LDS, st, p);
   else
     hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(blocks), dim3(512), MLP_LDS, st, p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, void* dy2,
+                                 int32_t T, int32_t D, mfp_stream_t stream) {
+  MFP_CHECK_ARG(d_o2 && h && W2t && W1t && dh && dy2);
+  MFP_CHECK_ARG(T > 0 && T <= (1 << 21) && D == MLP_D);
+  MFP_CHECK_ARG(((uintptr_t)d_o2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)W2t % 16) == 0 &&
+                ((uintptr_t)W1t % 16) == 0 && ((uintptr_t)dh % 16) == 0 && ((uintptr_t)dy2 % 16) == 0);
+  MlpBwdParams p;
+  p.d_o2 = reinterpret_cast<const unsigned short*>(d_o2); p.h = reinterpret_cast<const unsigned short*>(h);
+  p.W2t = reinterpret_cast<const unsigned short*>(W2t); p.W1t = reinterpret_cast<const unsigned short*>(W1t);
+  p.dh = reinterpret_cast<unsigned short*>(dh); p.dy2 = reinterpret_cast<unsigned short*>(dy2);
+  p.T = T;
+#ifdef MFP_GEMM_TRACE
+  p.trace = g_mlp_trace;
+#endif
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;      // 160 KB: all of a CU's LDS
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_mlp_fused_bwd: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

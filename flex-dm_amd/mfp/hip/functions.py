@@ -27,8 +27,9 @@ WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
 # bf16 path, d_model 256 / 512: LayerNorm forward fused into the X staging of the product behind it (QKV,
 # FFN1: MFP_GEMM_LNORM_A, csrc/gemm_ws.h); 0 = stand-alone ln_fwd launch + product (A/B switch)
 LN_FUSE = os.environ.get("MFP_LN_FUSE", "0") == "1"
-# bf16 path, d_model 256: LN2 + FFN1 + ReLU + FFN2 + dropout + residual of a block as ONE launch
-# (csrc/block_fused.hip); 0 = ln_fwd + two products (A/B switch)
+# bf16 path, d_model 256: LN2 + FFN1 + ReLU + FFN2 + dropout + residual of a block as ONE launch, and the two
+# input-gradient products of the same half as one launch (csrc/block_fused.hip); 0 = ln_fwd + two products,
+# two dgrad products (A/B switch)
 MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
 
 
@@ -353,8 +354,13 @@ class BlockFn(torch.autograd.Function):
         if d_o2 is None:
             d_o2 = ops.dropout_bwd(dx2, cdt, st.grad(p + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * i + 2, ctx.step_ptr)
         wt = st.cwt(p + "mlp/dense_1/kernel")     # [2D][D]: dgrad as a k-major product when kept
-        dh = ops.gemm(d_o2, wt if wt is not None else st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True,
-                      b_kmajor=wt is not None, out_dtype=cdt, relu_bwd_aux=h)
+        wt0 = st.cwt(p + "mlp/dense_0/kernel")    # [D][2D]
+        fused_bwd = MLP_FUSE and cdt == torch.bfloat16 and D == 256 and wt is not None and wt0 is not None
+        if fused_bwd:      # both input-gradient products of the half in one launch (csrc/block_fused.hip)
+            dh, dy2 = ops.mlp_fused_bwd(d_o2, h, wt, wt0)
+        else:
+            dh = ops.gemm(d_o2, wt if wt is not None else st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True,
+                          b_kmajor=wt is not None, out_dtype=cdt, relu_bwd_aux=h)
 
         grouped = WGRAD_GROUP and cdt == torch.bfloat16
 
@@ -365,9 +371,9 @@ class BlockFn(torch.autograd.Function):
                      colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
         if not grouped:
             ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
-        wt = st.cwt(p + "mlp/dense_0/kernel")     # [D][2D]
-        dy2 = ops.gemm(dh, wt if wt is not None else st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True,
-                       b_kmajor=wt is not None, out_dtype=cdt)
+        if not fused_bwd:
+            dy2 = ops.gemm(dh, wt0 if wt0 is not None else st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True,
+                           b_kmajor=wt0 is not None, out_dtype=cdt)
         # LN2 backward also emits the masked/cast gradient of the attention Dropout + its bias grad
         dx1, d_o1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
                                       st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),

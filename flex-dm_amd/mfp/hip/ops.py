@@ -315,6 +315,19 @@ def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2, b2, dropout: Tuple[float, int, in
     return x2, y2, mean, rstd, h
 
 
+def mlp_fused_bwd(d_o2, h, W2t, W1t):
+    """dh = (d_o2 W2) * [h > 0], dy2 = dh W1 in one launch (d_model 256, bf16); W2t / W1t are the transposed
+    (k-major) shadows.  Returns (dh, dy2)."""
+    lib = load()
+    T, D = d_o2.shape
+    dh = torch.empty((T, 2 * D), dtype=torch.bfloat16, device=d_o2.device)
+    dy2 = torch.empty((T, D), dtype=torch.bfloat16, device=d_o2.device)
+    with _timed("mlp_bwd_kernel", 2 * 2 * T * D * 2 * D, T * (D * 2 * 2 + 2 * D * 2 * 2) + 2 * D * 2 * D * 2):
+        check(lib.mfp_mlp_fused_bwd(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(dy2), T, D, _stream()),
+              "mfp_mlp_fused_bwd")
+    return dh, dy2
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,
                   dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None, defer=None,
                   jobs: Optional[list] = None):

@@ -163,6 +163,12 @@ int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const float* beta, co
                       float* rstd, void* h, float* x2, int32_t T, int32_t D, float eps, float dropout_p,
                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
+/* Input gradients of the same half in one launch: dh = (d_o2 W2) * [h > 0] (bf16 [T,512]) and dy2 = dh W1
+ * (bf16 [T,256]).  d_o2 = the dropout-masked output gradient, bf16 [T,256]; h as saved by the forward pass;
+ * W2t bf16 [512][256] = W2 transposed, W1t bf16 [256][512] = W1 transposed (the k-major shadows). */
+int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, void* dy2,
+                      int32_t T, int32_t D, mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- LayerNorm
  * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
  * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.

@@ -813,3 +813,32 @@ def test_mlp_fused_fwd(T, p):
     assert_close(h, hr, 2e-2, 1e-2, "h vs double")
     want = x1.double() + keep * (h.float().cpu().double() @ W2.double().t() + b2.double())
     assert_close(x2, want, 2e-3, 2e-3, "x2 vs double")
+
+
+@pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
+def test_mlp_fused_bwd(T):
+    """mfp_mlp_fused_bwd: dh = (d_o2 W2) * [h > 0], dy2 = dh W1 in one launch against the two products it replaces
+    (same bf16 rounding point: dh is rounded before the second product) and a double reference."""
+    ops = _ops()
+    D, F = 256, 512
+    g = torch.Generator().manual_seed(T + 1)
+    d_o2 = bf16_round(torch.randn(T, D, generator=g) * 0.5)
+    h = bf16_round(torch.randn(T, F, generator=g).clamp(min=0))       # about half the units inactive
+    W1 = bf16_round(torch.randn(F, D, generator=g) * 0.06)            # [out = hidden][in]
+    W2 = bf16_round(torch.randn(D, F, generator=g) * 0.05)            # [out][in = hidden]
+    dd, hd = d_o2.to(DEV, torch.bfloat16), h.to(DEV, torch.bfloat16)
+    W2t = W2.t().contiguous().to(DEV, torch.bfloat16)                 # [512][256]
+    W1t = W1.t().contiguous().to(DEV, torch.bfloat16)                 # [256][512]
+    dh, dy2 = ops.mlp_fused_bwd(dd, hd, W2t, W1t)
+    # the two launches it replaces
+    dhu = ops.gemm(dd, W2t, T, F, D, a_kmajor=True, b_kmajor=True, out_dtype=torch.bfloat16, relu_bwd_aux=hd)
+    dy2u = ops.gemm(dhu, W1t, T, D, F, a_kmajor=True, b_kmajor=True, out_dtype=torch.bfloat16)
+    assert torch.equal((dh == 0), (dhu == 0) | (dh == 0))
+    assert (dh != dhu).float().mean().item() < 0.02
+    assert_close(dh, dhu.float().cpu().double(), 3e-2, 2e-2, "dh vs unfused")
+    assert_close(dy2, dy2u.float().cpu().double(), 3e-2, 2e-2, "dy2 vs unfused")
+    want_dh = (d_o2.double() @ W2.double()) * (h.double() > 0)
+    assert_close(dh, want_dh, 2e-2, 1e-2, "dh vs double")
+    assert torch.equal(dh.cpu()[h == 0], torch.zeros_like(dh.cpu()[h == 0]))       # inactive units get exactly zero
+    want = dh.float().cpu().double() @ W1.double()
+    assert_close(dy2, want, 2e-2, 1e-2, "dy2 vs double")

@@ -59,10 +59,29 @@ def fused(i):
     return ops.mlp_fused_fwd(X1[i], gamma, beta, W1, b1, W2, b2, (0.1, 7, 2), step)
 
 
+W2t, W1t = W2.t().contiguous(), W1.t().contiguous()
+DO = [(torch.randn(T, D, device=dev) * 0.3).to(torch.bfloat16) for _ in range(len(X1))]
+HH = [torch.randn(T, F, device=dev).clamp(min=0).to(torch.bfloat16) for _ in range(len(X1))]
+
+
+def unfused_bwd(i):
+    dh = ops.gemm(DO[i], W2t, T, F, D, a_kmajor=True, b_kmajor=True, out_dtype=torch.bfloat16, relu_bwd_aux=HH[i])
+    return dh, ops.gemm(dh, W1t, T, D, F, a_kmajor=True, b_kmajor=True, out_dtype=torch.bfloat16)
+
+
+def fused_bwd(i):
+    return ops.mlp_fused_bwd(DO[i], HH[i], W2t, W1t)
+
+
 with torch.cuda.stream(torch.cuda.Stream()):
     tu = timeit(unfused)
     KEEP.clear()
     tf = timeit(fused)
+    KEEP.clear()
+    tub = timeit(unfused_bwd)
+    KEEP.clear()
+    tfb = timeit(fused_bwd)
 nb = T * (D * 4 * 2 + D * 2 + F * 2)
 print("MLP half T=%d: unfused %.1f us   fused %.1f us (%.2f TB/s algorithmic, %.0f TFLOP/s)"
       % (T, tu, tf, nb / tf / 1e6, 4 * T * D * F / tf / 1e6))
+print("MLP half input gradients: unfused %.1f us   fused %.1f us" % (tub, tfb))

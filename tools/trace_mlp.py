@@ -24,13 +24,25 @@ trace = torch.zeros(nb, 24, dtype=torch.int64, device=dev)
 lib = hip.load()
 lib.mfp_mlp_trace_buffer.restype = None
 keep = []
+bwd = os.environ.get("BWD", "0") == "1"
+W2t, W1t = W2.t().contiguous(), W1.t().contiguous()
+DO = [(x * 0.3).to(torch.bfloat16) for x in X1]
+HH = [torch.randn(T, F, device=dev).clamp(min=0).to(torch.bfloat16) for _ in X1]
+
+
+def run(i):
+    if bwd:
+        return ops.mlp_fused_bwd(DO[i], HH[i], W2t, W1t)
+    return ops.mlp_fused_fwd(X1[i], gamma, beta, W1, b1, W2, b2, (0.1, 7, 2), step)
+
+
 for i in range(11):
-    out = ops.mlp_fused_fwd(X1[i % len(X1)], gamma, beta, W1, b1, W2, b2, (0.1, 7, 2), step)
+    out = run(i % len(X1))
     if cold:
         keep.append(out)
 torch.cuda.synchronize()
 lib.mfp_mlp_trace_buffer(ctypes.c_void_p(trace.data_ptr()))
-out = ops.mlp_fused_fwd(X1[-1], gamma, beta, W1, b1, W2, b2, (0.1, 7, 2), step)
+out = run(len(X1) - 1)
 torch.cuda.synchronize()
 lib.mfp_mlp_trace_buffer(None)
 t = trace[:, :20].cpu().double()
@@ -38,7 +50,7 @@ rel = (t - t[:, 0].min()) / 100.0
 names = ["start", "LN done", "barrier"] + ["chunk %d" % c for c in range(16)] + ["end"]
 med, p90 = rel.median(0).values, rel.quantile(0.9, 0)
 prev = 0.0
-print("cold buffers: %s" % cold)
+print("cold buffers: %s, backward: %s" % (cold, bwd))
 for i, n in enumerate(names):
     print("%-9s median %6.2f us (+%5.2f)   p90 %6.2f   max %6.2f" % (n, med[i], med[i] - prev, p90[i], rel[:, i].max()))
     prev = med[i]
