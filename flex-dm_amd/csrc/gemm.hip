@@ -53,6 +53,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int kz_xcd;      // 1: 1-D grid, k-chunks grouped per XCD (split-K with splitk % 8 == 0)
   const float* ln_gamma; const float* ln_beta; unsigned short* ln_y; float* ln_mean; float* ln_rstd; float ln_eps;   // MFP_GEMM_LNORM_A
+  const int* m_dev;   // device row count or nullptr: rows >= *m_dev are not computed
 #ifdef MFP_GEMM_TRACE
   unsigned long long* trace;  // [workgroup][16] s_memtime stamps of wave 0
 #endif
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
   }
   const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (p.m_dev != nullptr && m0 >= *p.m_dev) return;     // row count decided on the device: tiles past it have no work
   const int kbeg = kz * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -639,6 +641,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   if (a->flags & MFP_GEMM_RESIDUAL) MFP_CHECK_ARG(a->residual != nullptr);
   if (a->flags & MFP_GEMM_RELU_BWD) MFP_CHECK_ARG(a->aux != nullptr);
   if (a->flags & MFP_GEMM_ACCUM) MFP_CHECK_ARG(a->out_dtype == MFP_F32);
+  if (a->m_dev != nullptr) MFP_CHECK_ARG(a->a_kmajor == 1 && splitk == 1 && !(a->flags & MFP_GEMM_LNORM_A));
   if (a->flags & MFP_GEMM_DROPOUT) MFP_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f);
   if (a->out_dtype == MFP_BF16) MFP_CHECK_ARG(a->ldc % 8 == 0);
   const bool ws_path = uses_workspace(a);
@@ -662,6 +665,7 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   p.tiles_m = 0; p.tiles_n = 0; p.kz_xcd = 0;  // set per tile configuration in launch_one
   p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_y = reinterpret_cast<unsigned short*>(a->ln_y);
   p.ln_mean = a->ln_mean; p.ln_rstd = a->ln_rstd; p.ln_eps = a->ln_eps;
+  p.m_dev = a->m_dev;
 #ifdef MFP_GEMM_TRACE
   p.trace = g_trace;
 #endif
@@ -764,7 +768,7 @@ extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t
     WggJob& d = p.job[i];
     d.A = reinterpret_cast<const unsigned short*>(j.A);
     d.B = reinterpret_cast<const unsigned short*>(j.B);
-    d.C = j.C; d.colsum = j.colsum; d.rowcode = j.rowcode;
+    d.C = j.C; d.colsum = j.colsum; d.rowcode = j.rowcode; d.k_dev = j.k_dev;
     d.M = j.M; d.N = j.N; d.lda = j.lda; d.ldb = j.ldb; d.ldc = j.ldc;
     d.tiles_n = (j.N + 127) / 128;
     d.tile0 = tile0; d.pad_ = 0;

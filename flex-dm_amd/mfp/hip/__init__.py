@@ -41,7 +41,7 @@ class GemmArgs(Structure):
         ("in_dtype", c_int32), ("out_dtype", c_int32), ("flags", c_int32), ("splitk", c_int32),
         ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64), ("step_ptr", c_void_p),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_y", c_void_p), ("ln_mean", c_void_p),
-        ("ln_rstd", c_void_p), ("ln_eps", c_float),
+        ("ln_rstd", c_void_p), ("ln_eps", c_float), ("m_dev", c_void_p),
     ]
 
 
@@ -49,6 +49,7 @@ class WgradJob(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("colsum", c_void_p), ("rowcode", c_void_p),
         ("M", c_int32), ("N", c_int32), ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
+        ("k_dev", c_void_p),
     ]
 
 
@@ -110,6 +111,13 @@ SIGNATURES = {
     "mfp_row_flags": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p]),
     "mfp_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
                                    c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mfp_loss_fwd_bwd_categorical": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
+                                               c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mfp_compact_tokens": (c_int32, [POINTER(LossKey), c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "mfp_gather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "mfp_scatter_add_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "mfp_loss_numeric_compact": (c_int32, [c_void_p, c_void_p, POINTER(LossKey), c_int32, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mfp_loss_fwd_bwd_sorted": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
                                           c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "mfp_sort_positions": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_void_p, c_int32, POINTER(c_int32),

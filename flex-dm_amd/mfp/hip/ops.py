@@ -119,10 +119,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
          rowskip_a: Optional[torch.Tensor] = None, splitk: int = 1,
          step_ptr: Optional[torch.Tensor] = None,
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
-         ln: Optional[tuple] = None) -> torch.Tensor:
+         ln: Optional[tuple] = None, m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out[M,N] = epilogue(op(A) @ op(B))`` -- see ``mfp_gemm`` in include/mfp_hip.h.
     ``ln`` = (gamma, beta, y_out bf16 [M,K], mean_out [M], rstd_out [M]): A is the f32 input of a
-    LayerNormalization; the kernel multiplies LN(A) and also writes y / mean / rstd (MFP_GEMM_LNORM_A)."""
+    LayerNormalization; the kernel multiplies LN(A) and also writes y / mean / rstd (MFP_GEMM_LNORM_A).
+    ``m_dev`` (int32 [1] on the device): only the first min(M, m_dev) rows are computed (compacted rows)."""
     lib = load()
     assert ln is not None or A.dtype == B.dtype, (A.dtype, B.dtype)
     if out is None:
@@ -168,6 +169,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
         flags |= GEMM_ROWSKIP_A
         a.rowcode = _ptr(rowskip_a)
     a.flags, a.splitk = flags, splitk
+    a.m_dev = _ptr(m_dev)
     nbytes = lib.mfp_gemm_workspace_bytes(ctypes.byref(a))
     if nbytes:
         ws = workspace(nbytes, A.device)
@@ -266,6 +268,7 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None) -> N
         a = arr[i]
         a.A, a.B, a.C = _ptr(A), _ptr(B), _ptr(out)
         a.colsum, a.rowcode = _ptr(j.get("colsum")), _ptr(j.get("rowskip"))
+        a.k_dev = _ptr(j.get("k_dev"))      # int32 [1] on the device: this job contracts over min(K, k_dev) rows
         a.M, a.N = j["M"], j["N"]
         a.lda, a.ldb = A.stride(0), B.stride(0)
         a.ldc = out.stride(0) if out.dim() == 2 else j["N"]
@@ -488,6 +491,78 @@ def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tenso
                                               _ptr(sums), B, S, code, _ptr(pred_row), _ptr(true_row), _stream()),
                   "mfp_loss_fwd_bwd_sorted")
     return sums, dlogits
+
+
+def _loss_keys(keys: Sequence[dict]):
+    arr = (LossKey * len(keys))()
+    for i, k in enumerate(keys):
+        arr[i].col_off, arr[i].n_feat, arr[i].n_class = k["col_off"], k["n_feat"], k["n_class"]
+        arr[i].is_numerical = int(k["is_numerical"])
+        arr[i].target, arr[i].mask = _ptr(k["target"]), _ptr(k["mask"])
+        arr[i].cond_idx = _ptr(k.get("cond_idx"))
+        arr[i].cond_stride = k.get("cond_stride", 1)
+        arr[i].cond_bits = k.get("cond_bits", 0xFFFFFFFF)
+    return arr
+
+
+def loss_fwd_bwd_categorical(logits, keys: Sequence[dict], nvalid, B: int, S: int, dlogits, sums=None):
+    """:func:`loss_fwd_bwd` restricted to the categorical keys of ``keys``; every row of ``sums`` is zeroed, the
+    numerical keys' rows are then filled by :func:`loss_numeric_compact`."""
+    lib = load()
+    if sums is None:
+        sums = torch.empty((len(keys), 3), dtype=torch.float32, device=logits.device)
+    ncat = sum(k["n_feat"] * k["n_class"] for k in keys if not k["is_numerical"])
+    with _timed("loss_kernels(ce+mse)", 0, logits.shape[0] * ncat * (4 + _esz(dlogits))):
+        check(lib.mfp_loss_fwd_bwd_categorical(_ptr(logits), _ptr(dlogits), logits.shape[1], _loss_keys(keys), len(keys),
+                                               _ptr(nvalid), _ptr(sums), B, S, dt_code(dlogits.dtype), _stream()),
+              "mfp_loss_fwd_bwd_categorical")
+    return sums
+
+
+def compact_tokens(keys: Sequence[dict], nvalid, B: int, S: int):
+    """Per key: the ascending list of tokens with a non-zero loss weight.  Returns (idx int32 [nkeys, B*S], count
+    int32 [nkeys]) -- both on the device; nothing is read back."""
+    lib = load()
+    idx = torch.empty((len(keys), B * S), dtype=torch.int32, device=nvalid.device)
+    count = torch.empty((len(keys) * 65,), dtype=torch.int32, device=nvalid.device)   # lengths | scan scratch
+    with _timed("compact_tokens_kernel", 0, len(keys) * B * S * 8):
+        check(lib.mfp_compact_tokens(_loss_keys(keys), len(keys), _ptr(nvalid), B, S, _ptr(idx), _ptr(count), _stream()),
+              "mfp_compact_tokens")
+    return idx, count[:len(keys)]
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, count: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """out[i] = src[idx[i]] for i < count (rows beyond are left untouched)."""
+    lib = load()
+    T, D = src.shape
+    if out is None:
+        out = torch.empty_like(src)
+    with _timed("gather_rows_kernel", 0, 0):
+        check(lib.mfp_gather_rows(_ptr(src), _ptr(out), _ptr(idx), _ptr(count), T, D * _esz(src), _stream()), "mfp_gather_rows")
+    return out
+
+
+def scatter_add_rows(dst: torch.Tensor, src: torch.Tensor, idx: torch.Tensor, count: torch.Tensor) -> None:
+    """dst[idx[i]] += src[i] for i < count (f32 rows; the indices are distinct)."""
+    lib = load()
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.shape[1] == src.shape[1]
+    with _timed("scatter_add_rows_kernel", 0, 0):
+        check(lib.mfp_scatter_add_rows(_ptr(dst), _ptr(src), _ptr(idx), _ptr(count), src.shape[0], dst.shape[1], _stream()),
+              "mfp_scatter_add_rows")
+
+
+def loss_numeric_compact(pred: torch.Tensor, key: dict, slot: int, idx, count, nvalid, sums, B: int, S: int,
+                         dl_dtype: torch.dtype, dpred: Optional[torch.Tensor] = None):
+    """Numerical key on compacted rows (row i of ``pred`` = token idx[i], i < count): accumulates into sums[slot]
+    and returns d(loss)/d(pred) in ``dl_dtype`` (same compact rows)."""
+    lib = load()
+    if dpred is None:
+        dpred = torch.empty(pred.shape, dtype=dl_dtype, device=pred.device)
+    with _timed("loss_kernels(ce+mse)", 0, 0):
+        check(lib.mfp_loss_numeric_compact(_ptr(pred), _ptr(dpred), _loss_keys([key]), slot, _ptr(idx), _ptr(count),
+                                           _ptr(nvalid), _ptr(sums), B, S, dt_code(dpred.dtype), _stream()),
+              "mfp_loss_numeric_compact")
+    return dpred
 
 
 def sort_positions(nvalid: torch.Tensor, flag: torch.Tensor, B: int, S: int, labels: Sequence[torch.Tensor] = None,

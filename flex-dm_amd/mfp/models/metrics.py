@@ -114,7 +114,7 @@ class LossLayer:
         self._U = col
         self._model_head_cols, self._model_ld = None, None
         if model_layout is not None:
-            assert list(model_layout.head_cols) == list(self._head_cols)
+            assert sorted(model_layout.head_cols) == sorted(self._head_cols)      # (the model keeps categorical heads first)
             self._model_head_cols, self._model_ld = dict(model_layout.head_cols), model_layout.Upad
 
     def _flat_logits(self, y_pred: Dict, B: int, S: int):

@@ -274,6 +274,7 @@ class MFP:
                                    tasks == self.task_names.index("pos"))
         if self.fast_masking and self.input_dtype == "set":
             ctx = self.model.make_ctx(batch, True)
+            ctx.sparse_heads = True     # the step only needs the loss: numerical heads on the masked tokens only
             idx_all, codes, xs, masks = self._masker(batch, tasks, ctx.nvalid, ctx.B, ctx.S, self.model.step_ptr)
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, batch, masks)
             cin = {"task": tasks[..., None], "length": batch["length"]} if self.context is not None else None

@@ -127,11 +127,17 @@ class ModelLayout:
         # ---- decoder heads: rows [Upad][D] + bias [Upad]; per key a row block.  Every head starts
         # at a multiple of 8 logits columns (zero-weight pad rows in between: 16-byte bf16 / float4
         # access for the loss kernels and the GEMM epilogues); U counts the real units.
+        # Categorical heads first, numerical (regression) heads behind them: the categorical logits are one
+        # contiguous column range, which is what the train step evaluates on every token (the numerical heads run
+        # on the compacted rows of the tokens that carry a loss: hip/functions.py DecoderLossFn).
         self.head_cols: Dict[str, Tuple[int, int]] = {}
         col, real = 0, 0
         self.heads_start = self._cursor
         pads = {}
-        for k, c in self.columns.items():
+        self.head_order = ([k for k, c in self.columns.items() if c["type"] == "categorical"]
+                           + [k for k, c in self.columns.items() if c["type"] != "categorical"])
+        for k in self.head_order:
+            c = self.columns[k]
             units = c["shape"][-1] * c["input_dim"] if c["type"] == "categorical" else c["shape"][-1]
             self._add("decoder/decoder_%s/kernel" % k, (units, D), True, True)
             self.head_cols[k] = (col, units)
@@ -144,7 +150,7 @@ class ModelLayout:
         self.U = real
         self.Upad = col
         self.heads_bias_start = self._cursor
-        for k in self.columns:
+        for k in self.head_order:
             self._add("decoder/decoder_%s/bias" % k, (self.head_cols[k][1],), True, False)
             if pads[k]:
                 self._add("decoder/_pad/%s/bias" % k, (pads[k],), False, False)

@@ -98,6 +98,8 @@ typedef struct mfp_gemm_args {
   float* ln_mean;
   float* ln_rstd;
   float ln_eps;
+  const int32_t* m_dev;    /* device or NULL: the launch covers min(M, *m_dev) rows (a_kmajor = 1, splitk = 1): row count
+                            * decided on the device (compacted rows), launch configuration still static */
 } mfp_gemm_args;
 
 int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);
@@ -129,6 +131,7 @@ typedef struct mfp_wgrad_job {
   float* colsum;
   const uint8_t* rowcode;
   int32_t M, N, lda, ldb, ldc;
+  const int32_t* k_dev;    /* device or NULL: this job contracts over min(K, *k_dev) rows */
 } mfp_wgrad_job;
 int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs /*host*/, int32_t njobs);
 int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K);
@@ -280,6 +283,33 @@ int mfp_loss_fwd_bwd_sorted(const float* logits, void* dlogits, int32_t ld, cons
                             int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
                             int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row,
                             mfp_stream_t stream);
+
+/* Compacted numerical heads.  Under masked-field prediction only the masked tokens of an attribute carry a
+ * loss (metrics.py:251-267: weight 0 elsewhere, so neither the loss nor any gradient depends on the other
+ * rows); the 512-wide regression heads (decoder.py:39-43 on image / text embeddings) are therefore evaluated
+ * on the compacted token list only.  Launch shapes stay static (hipGraph): the list length lives on the device
+ * and is consumed through mfp_gemm_args.m_dev / mfp_wgrad_job.k_dev.
+ *   mfp_loss_fwd_bwd_categorical: mfp_loss_fwd_bwd restricted to the categorical keys (all sums rows are zeroed,
+ *     the numerical keys' rows are filled by mfp_loss_numeric_compact afterwards);
+ *   mfp_compact_tokens: per key k (only mask / cond_* are read): idx[k*T .. k*T + count[k]) = tokens with a
+ *     non-zero weight, ascending; T = B*S <= 65536; count is int32 [nkeys + 64 * nkeys] (the lengths, then
+ *     scratch for the per-workgroup counts of the two-pass scan);
+ *   mfp_gather_rows / mfp_scatter_add_rows: dst[i] = src[idx[i]] (rows of row_bytes bytes) / dst[idx[i]] += src[i]
+ *     (f32 rows) for i < *count; max_rows bounds the launch;
+ *   mfp_loss_numeric_compact: pred f32 [>= *count][n_class] (row i = token idx[i]), dpred cdt same shape;
+ *     accumulates {loss / B, score, count} into sums[slot] exactly as mfp_loss_fwd_bwd does for that key. */
+int mfp_loss_fwd_bwd_categorical(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys /*host*/,
+                                 int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
+                                 int32_t dl_dtype, mfp_stream_t stream);
+int mfp_compact_tokens(const mfp_loss_key* keys /*host*/, int32_t nkeys, const int32_t* nvalid, int32_t B, int32_t S,
+                       int32_t* idx, int32_t* count, mfp_stream_t stream);
+int mfp_gather_rows(const void* src, void* dst, const int32_t* idx, const int32_t* count, int32_t max_rows,
+                    int32_t row_bytes, mfp_stream_t stream);
+int mfp_scatter_add_rows(float* dst, const float* src, const int32_t* idx, const int32_t* count, int32_t max_rows,
+                         int32_t row_floats, mfp_stream_t stream);
+int mfp_loss_numeric_compact(const float* pred, void* dpred, const mfp_loss_key* key /*host*/, int32_t slot,
+                             const int32_t* idx, const int32_t* count, const int32_t* nvalid, float* sums,
+                             int32_t B, int32_t S, int32_t dl_dtype, mfp_stream_t stream);
 
 /* sort_inputs (reference models/tensor_utils.py:14-44) as a row map.  Per document b with flag[b]:
  *   priority(s) = sum_k v_k(s) * 100^(4-k) + [s >= nvalid[b]] * 100^5   (k over type, left, top,
