@@ -321,7 +321,12 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x = x.contiguous()
-        qkv, y1, mean1, rstd1 = _ln_dense(ctx, x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
+        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and not st.fp8:      # LN1 + Q|K|V in one launch
+            qkv, y1, mean1, rstd1 = ops.qkv_fused_fwd(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
+                                                      st.cw(p + "attn/dense_query/kernel", rows=3 * D),
+                                                      st.span(st.w, p + "attn/dense_query/bias", 3 * D))
+        else:
+            qkv, y1, mean1, rstd1 = _ln_dense(ctx, x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
                                           st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
                                           st.span(st.w, p + "attn/dense_query/bias", 3 * D),
                                           w8=st.w8(p + "attn/dense_query/kernel", 3 * D) if st.fp8 else None)

@@ -318,6 +318,21 @@ def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2, b2, dropout: Tuple[float, int, in
     return x2, y2, mean, rstd, h
 
 
+def qkv_fused_fwd(x, gamma, beta, W, bias):
+    """qkv = LN(x) W^T + bias in one launch (d_model 256, bf16 weights [768][256]).  Returns (qkv, y1, mean, rstd)."""
+    lib = load()
+    T, D = x.shape
+    dev = x.device
+    y1 = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    qkv = torch.empty((T, 3 * D), dtype=torch.bfloat16, device=dev)
+    mean = torch.empty((T,), dtype=torch.float32, device=dev)
+    rstd = torch.empty((T,), dtype=torch.float32, device=dev)
+    with _timed("qkv_fused_kernel", 2 * T * D * 3 * D, T * (D * 4 + D * 2 + 3 * D * 2) + 3 * D * D * 2):
+        check(lib.mfp_qkv_fused_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(W), _ptr(bias), _ptr(y1), _ptr(mean), _ptr(rstd),
+                                    _ptr(qkv), T, D, LN_EPS, _stream()), "mfp_qkv_fused_fwd")
+    return qkv, y1, mean, rstd
+
+
 def mlp_fused_bwd(d_o2, h, W2t, W1t):
     """dh = (d_o2 W2) * [h > 0], dy2 = dh W1 in one launch (d_model 256, bf16); W2t / W1t are the transposed
     (k-major) shadows.  Returns (dh, dy2)."""

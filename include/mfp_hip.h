@@ -166,6 +166,13 @@ int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const float* beta, co
                       float* rstd, void* h, float* x2, int32_t T, int32_t D, float eps, float dropout_p,
                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
+/* LayerNormalization + the fused Q | K | V Dense of a block in one launch (transformer.py:216-217,85-90):
+ * qkv bf16 [T,768] = LN(x) W^T + bias, with y1 = LN(x) (bf16 [T,256]), mean, rstd (f32 [T]) saved for the
+ * backward pass.  x f32 [T,256]; W bf16 [768][256] (out, in); d_model 256 only. */
+int mfp_qkv_fused_fwd(const float* x, const float* gamma, const float* beta, const void* W, const float* bias,
+                      void* y1, float* mean, float* rstd, void* qkv, int32_t T, int32_t D, float eps,
+                      mfp_stream_t stream);
+
 /* Input gradients of the same half in one launch: dh = (d_o2 W2) * [h > 0] (bf16 [T,512]) and dy2 = dh W1
  * (bf16 [T,256]).  d_o2 = the dropout-masked output gradient, bf16 [T,256]; h as saved by the forward pass;
  * W2t bf16 [512][256] = W2 transposed, W1t bf16 [256][512] = W1 transposed (the k-major shadows). */

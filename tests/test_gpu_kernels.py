@@ -903,3 +903,28 @@ def test_compact_gather_scatter_and_device_row_counts():
     xx = X.float().cpu().double()
     assert_close(gW2, xx.t() @ xx, 2e-3, 2e-3, "static-K job in the same launch")
     assert int(ops._wgrad_tickets(DEV).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
+def test_qkv_fused_fwd(T):
+    """mfp_qkv_fused_fwd: qkv = LN(x) Wqkv^T + b in one launch (transformer.py:216-217,85-90) against ln_fwd + the
+    product it replaces (same bf16 rounding point) and a double reference; ragged last row group."""
+    ops = _ops()
+    D, N = 256, 768
+    g = torch.Generator().manual_seed(T + 2)
+    x = (torch.randn(T, D, generator=g) * (1.0 + torch.rand(T, 1, generator=g)) + 0.3 * torch.randn(T, 1, generator=g))
+    gamma, beta = 1.0 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    W = bf16_round(torch.randn(N, D, generator=g) * 0.06)
+    bias = torch.randn(N, generator=g) * 0.1
+    xd, gd, bd, Wd, biasd = x.to(DEV), gamma.to(DEV), beta.to(DEV), W.to(DEV, torch.bfloat16), bias.to(DEV)
+    qkv, y1, mean, rstd = ops.qkv_fused_fwd(xd, gd, bd, Wd, biasd)
+    y1u, meanu, rstdu = ops.layernorm_fwd(xd, gd, bd, torch.bfloat16)
+    qkvu = ops.gemm(y1u, Wd, T, N, D, a_kmajor=True, b_kmajor=True, bias=biasd, out_dtype=torch.bfloat16)
+    assert_close(mean, meanu.cpu().double(), 1e-5, 1e-5, "mean")
+    assert_close(rstd, rstdu.cpu().double(), 1e-5, 1e-5, "rstd")
+    assert (y1.float() - y1u.float()).abs().max().item() <= 0.04
+    assert (y1 != y1u).float().mean().item() < 0.01
+    assert (qkv != qkvu).float().mean().item() < 0.02
+    assert_close(qkv, qkvu.float().cpu().double(), 3e-2, 2e-2, "qkv vs unfused")
+    want = y1.float().cpu().double() @ W.double().t() + bias.double()
+    assert_close(qkv, want, 2e-2, 1e-2, "qkv vs double")
