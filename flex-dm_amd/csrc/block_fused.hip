@@ -725,6 +725,134 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   MLP_STAMP(19);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Input gradient of the fused Q | K | V Dense: dy1 = dqkv Wqkv  (bf16 [T][256], K = 768; Keras autodiff of
+// transformer.py:85-90).  Activation-stationary like the kernels above: 128 rows per workgroup, the 64
+// accumulator registers of a lane hold its share of the 128 x 256 result for the whole launch; dqkv streams through
+// two LDS images in six 128-column pieces (loaded by waves 4-7, straight into LDS), the transposed weights [256][768]
+// in twelve 32 KB chunks through three buffers (waves 0-3).  The weight-stationary kernel did this product at
+// 2.6 TB/s (24-26 us for 66 MB).
+struct DgradParams {
+  const unsigned short* A;     // [T][768] bf16
+  const unsigned short* Wt;    // [256][768] bf16: Wt[c][n] = W[n][c]
+  unsigned short* C;           // [T][256] bf16
+  int T;
+};
+constexpr int DG_K = 768, DG_KQ = DG_K / 128, DG_CHUNKS = 2 * DG_KQ;
+
+__global__ __launch_bounds__(512) void dgrad_qkv_kernel(DgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const As = smem;                       // two [128][256 B] images of dqkv pieces
+  unsigned char* const Ws = smem + 2 * MLP_HS_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int rp = wave & 3, nh = wave >> 2;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wt), 0, MLP_D * DG_K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, (unsigned int)p.T * (DG_K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (unsigned int)p.T * (MLP_D * 2), 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave), wl = wv & 3;
+  // both streams: [128 rows][256 B] pieces out of 1536-byte rows, 4 rows per 1 KB instruction, source slot =
+  // destination slot ^ (row & 15); 8 instructions per wave
+  const unsigned int poff = (unsigned int)((wl * 32 + (lane >> 4)) * (DG_K * 2) + (((lane & 15) ^ (lane >> 4)) << 4));
+  auto wload = [&](int c) {          // chunk c = (kq, j): Wt rows 128 j .. + 127, columns 128 kq .. + 127
+    if (wv >= 4) return;
+    unsigned char* dst = Ws + (c % 3) * MLP_WS_B + wl * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6),
+                                               (c & 1) * 128 * (DG_K * 2) + (c >> 1) * 256 + i * 4 * (DG_K * 2), 0, 0);
+  };
+  auto aload = [&](int kq) {
+    if (wv < 4) return;
+    unsigned char* dst = As + (kq & 1) * MLP_HS_B + wl * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6),
+                                               row0 * (DG_K * 2) + kq * 256 + i * 4 * (DG_K * 2), 0, 0);
+  };
+  wload(0);
+  wload(1);
+  aload(0);
+  aload(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 acc2[8][2];
+  bf16x8 hf[2][4];
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+
+  auto chunk = [&](auto cc_) {
+    constexpr int c = decltype(cc_)::value;
+    constexpr int kq = c >> 1, j = c & 1;
+    if (c + 2 < DG_CHUNKS) wload(c + 2);
+    // piece kq + 1 goes into the image piece kq - 1 was read from (every wave picked up its fragments of it before
+    // the barrier that ended chunk (kq - 1, 0)); waited for at the end of chunk (kq, 1): two chunk periods
+    if (j == 0 && kq >= 1 && kq + 1 < DG_KQ) aload(kq + 1);
+    if (j == 0) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          hf[rt][ks] = *reinterpret_cast<const bf16x8*>(As + (kq & 1) * MLP_HS_B + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
+    }
+    const unsigned char* wa = Ws + (c % 3) * MLP_WS_B + ((nh * 4) * 16 + li) * 256;
+    bf16x8 wf[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[ks + 1]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
+                                                                       (kq == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
+    }
+    if (c >= DG_CHUNKS - 2) {
+      // columns 128 j .. + 127 of the result are final: bf16 into a free [128][256 B] image (the weight buffer of
+      // the chunk before this one), stored in whole 256-byte row pieces behind the barrier
+      unsigned char* img = Ws + ((c + 2) % 3) * MLP_WS_B;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const u32x2 pk = {pack_bf16x2(acc2[j * 4 + nt][rt][0], acc2[j * 4 + nt][rt][1]), pack_bf16x2(acc2[j * 4 + nt][rt][2], acc2[j * 4 + nt][rt][3])};
+          *reinterpret_cast<u32x2*>(img + (rp * 32 + rt * 16 + li) * 256 + ((((nh * 4 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = pk;
+        }
+    }
+    {
+      // weight waves: chunk c + 1 landed when at most the 8 loads of chunk c + 2 (and, in the last chunk, the 4 result
+      // stores of the chunk before) are outstanding; activation waves: piece kq + 1 is due at the end of (kq, 1)
+      constexpr int allowed_w = (c + 2 < DG_CHUNKS ? 8 : 0) + (c == DG_CHUNKS - 1 ? 4 : 0);
+      if (wv < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
+      else if (j == 1 && kq + 1 < DG_KQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (c >= DG_CHUNKS - 2) {
+      const unsigned char* img = Ws + ((c + 2) % 3) * MLP_WS_B;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 512 * i, r = idx >> 4, c16 = idx & 15;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(img + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_c,
+                                               (unsigned int)(row0 + r) * (MLP_D * 2) + c16 * 16 + j * 256, 0, 0);
+      }
+    }
+  };
+  chunk(std::integral_constant<int, 0>{});  chunk(std::integral_constant<int, 1>{});
+  chunk(std::integral_constant<int, 2>{});  chunk(std::integral_constant<int, 3>{});
+  chunk(std::integral_constant<int, 4>{});  chunk(std::integral_constant<int, 5>{});
+  chunk(std::integral_constant<int, 6>{});  chunk(std::integral_constant<int, 7>{});
+  chunk(std::integral_constant<int, 8>{});  chunk(std::integral_constant<int, 9>{});
+  chunk(std::integral_constant<int, 10>{}); chunk(std::integral_constant<int, 11>{});
+}
+
 }  // namespace
 
 #ifdef MFP_GEMM_TRACE
@@ -824,6 +952,28 @@ extern "C" int mfp_qkv_fused_fwd(const float* x, const float* gamma, const float
     attr_set = true;
   }
   hipLaunchKernelGGL(qkv_fused_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), QKV_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t D, mfp_stream_t stream) {
+  MFP_CHECK_ARG(dqkv && Wt && dy && T > 0 && T <= (1 << 20) && D == MLP_D);
+  MFP_CHECK_ARG(((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)dy % 16) == 0);
+  DgradParams p;
+  p.A = reinterpret_cast<const unsigned short*>(dqkv); p.Wt = reinterpret_cast<const unsigned short*>(Wt);
+  p.C = reinterpret_cast<unsigned short*>(dy); p.T = T;
+  constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_dgrad_qkv: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dgrad_qkv_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

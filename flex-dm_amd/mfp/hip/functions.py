@@ -417,8 +417,11 @@ class BlockFn(torch.autograd.Function):
         else:
             ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
         wt = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
-        dy1 = ops.gemm(dqkv, wt if wt is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
-                       3 * D, a_kmajor=True, b_kmajor=wt is not None, out_dtype=cdt)
+        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and wt is not None:
+            dy1 = ops.dgrad_qkv(dqkv, wt)       # activation-stationary (csrc/block_fused.hip)
+        else:
+            dy1 = ops.gemm(dqkv, wt if wt is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
+                           3 * D, a_kmajor=True, b_kmajor=wt is not None, out_dtype=cdt)
         if i > 0:   # dx is the dx2 of block i-1: hand its masked/cast copy over (skips a dropout_bwd)
             pp = "blocks/seq2seq_%d/" % (i - 1)
             dx, nxt = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,

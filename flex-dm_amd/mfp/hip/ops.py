@@ -333,6 +333,17 @@ def qkv_fused_fwd(x, gamma, beta, W, bias):
     return qkv, y1, mean, rstd
 
 
+def dgrad_qkv(dqkv: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
+    """dy1 = dqkv Wqkv (bf16 [T,256]) with Wt = the [256][768] transposed shadow of the fused Q|K|V kernel."""
+    lib = load()
+    T, K = dqkv.shape
+    D = K // 3
+    dy = torch.empty((T, D), dtype=torch.bfloat16, device=dqkv.device)
+    with _timed("dgrad_qkv_kernel", 2 * T * K * D, T * (K + D) * 2 + K * D * 2):
+        check(lib.mfp_dgrad_qkv(_ptr(dqkv), _ptr(Wt), _ptr(dy), T, D, _stream()), "mfp_dgrad_qkv")
+    return dy
+
+
 def mlp_fused_bwd(d_o2, h, W2t, W1t):
     """dh = (d_o2 W2) * [h > 0], dy2 = dh W1 in one launch (d_model 256, bf16); W2t / W1t are the transposed
     (k-major) shadows.  Returns (dh, dy2)."""

@@ -179,6 +179,10 @@ int mfp_qkv_fused_fwd(const float* x, const float* gamma, const float* beta, con
 int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, void* dy2,
                       int32_t T, int32_t D, mfp_stream_t stream);
 
+/* Input gradient of the fused Q | K | V Dense in one activation-stationary launch: dy bf16 [T,256] = dqkv Wqkv,
+ * dqkv bf16 [T,768], Wt bf16 [256][768] = the kernel transposed (k-major shadow).  d_model 256 only. */
+int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t D, mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- LayerNorm
  * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
  * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.

@@ -928,3 +928,20 @@ def test_qkv_fused_fwd(T):
     assert_close(qkv, qkvu.float().cpu().double(), 3e-2, 2e-2, "qkv vs unfused")
     want = y1.float().cpu().double() @ W.double().t() + bias.double()
     assert_close(qkv, want, 2e-2, 1e-2, "qkv vs double")
+
+
+@pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
+def test_dgrad_qkv(T):
+    """mfp_dgrad_qkv: dy1 = dqkv Wqkv (K = 768) in the activation-stationary kernel against the product it
+    replaces and a double reference; ragged last row group."""
+    ops = _ops()
+    D, K = 256, 768
+    g = torch.Generator().manual_seed(T + 3)
+    dq = bf16_round(torch.randn(T, K, generator=g) * 0.5)
+    W = bf16_round(torch.randn(K, D, generator=g) * 0.05)             # [out = 768][in = 256]
+    Wt = W.t().contiguous().to(DEV, torch.bfloat16)                   # [256][768]
+    dqd = dq.to(DEV, torch.bfloat16)
+    dy = ops.dgrad_qkv(dqd, Wt)
+    dyu = ops.gemm(dqd, Wt, T, D, K, a_kmajor=True, b_kmajor=True, out_dtype=torch.bfloat16)
+    assert_close(dy, dyu.float().cpu().double(), 2e-2, 1e-2, "vs the weight-stationary product")
+    assert_close(dy, dq.double() @ W.double(), 2e-2, 1e-2, "vs double")
