@@ -31,7 +31,9 @@ __device__ __forceinline__ float token_weight(const mfp_loss_key& k, const int* 
   return (m != 0 && s < nv && c) ? 1.f : 0.f;
 }
 
-constexpr int CE_TOK = 16;        // token rows per workgroup
+// token rows per workgroup (16 lanes each): 32 when the staged rows fit 64 KB of LDS (fewer, fatter workgroups: the
+// per-workgroup fixed costs -- barriers, compaction, sum atomics -- dominate; 8 rows +33 us, 4 rows +80 us, 32 rows
+// -10 us per step against 16), else 16
 constexpr int CE_MAX_RANGES = 4;  // contiguous column ranges holding categorical heads
 constexpr int CE_MAX_ITEMS = 16;  // (key, feature) items per token
 constexpr int CE_MAX_GAPS = 20;   // padding column runs (< 8 columns each) inside the ranges
@@ -55,15 +57,15 @@ struct CeRanges {
 //     kernel walked an item's classes serially in one thread: 102 us for 50 MB);
 //  4. rows go back as d(logits) in the compute dtype, 16 bytes per lane.
 // Loss / score / denominator: LDS accumulation + one global atomic per key and workgroup.
-template <typename TDL>
-__global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ logits, TDL* __restrict__ dlogits,
+template <typename TDL, int CE_TOK>
+__global__ __launch_bounds__(CE_TOK * 16) void ce_tile_kernel(const float* __restrict__ logits, TDL* __restrict__ dlogits,
                                                       int ld, LossKeys keys, CeRanges rg, const int* __restrict__ nvalid,
                                                       float* __restrict__ sums, int T, int S, float inv_B,
                                                       const int* __restrict__ pred_row, const int* __restrict__ true_row) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // [CE_TOK][rg.width]
   __shared__ float red[MFP_MAX_LOSS_KEYS][3];
   __shared__ int nactive;
-  __shared__ unsigned char active[CE_TOK * CE_MAX_ITEMS];   // compacted (row << 4 | item)
+  __shared__ unsigned short active[CE_TOK * CE_MAX_ITEMS];   // compacted (row << 4 | item)
   __shared__ unsigned char isact[CE_TOK][CE_MAX_ITEMS];
   __shared__ int ylabel[CE_TOK][CE_MAX_ITEMS];
   const int t0 = blockIdx.x * CE_TOK;
@@ -106,9 +108,9 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
   for (int gI = 0; gI < rg.ngap; ++gI)      // padding columns: d(logits) = 0
     if (l16 < rg.gap_len[gI]) tile[row16 * W + rg.gap_pos[gI] + l16] = 0.f;
   __syncthreads();
-  if (isact[row16][l16]) active[atomicAdd(&nactive, 1)] = (unsigned char)(threadIdx.x);
+  if (isact[row16][l16]) active[atomicAdd(&nactive, 1)] = (unsigned short)(threadIdx.x);
   // ---- 3a. inactive items zero their classes (group = 16 lanes, item a = group, group + 16, ...)
-  for (int a = row16; a < CE_TOK * rg.nitem; a += 16) {
+  for (int a = row16; a < CE_TOK * rg.nitem; a += CE_TOK) {
     const int row = a / rg.nitem, item = a % rg.nitem;
     if (isact[row][item]) continue;
     float* z = tile + row * W + rg.item_pos[item];
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void ce_tile_kernel(const float* __restrict__ 
   __syncthreads();
   // ---- 3b. active items: one 16-lane group each
   const int na = nactive;
-  for (int a = row16; a < na; a += 16) {
+  for (int a = row16; a < na; a += CE_TOK) {
     const int code = active[a], row = code >> 4, item = code & 15;
     const int kidx = rg.item_key[item], C = rg.item_C[item];
     float* z = tile + row * W + rg.item_pos[item];
@@ -576,8 +578,9 @@ static int loss_fwd_bwd_impl(const float* logits, void* dlogits, int32_t ld, con
     for (int r = 0; r < rg.n; ++r)
       if (rg.beg[r] % 8 != 0 || rg.len[r] % 8 != 0) rg.vec = 0;
     rg.width = (rg.width + 3) / 4 * 4 + 4;   // 16-byte rows; +4 floats: 16-lane groups of different rows hit different banks
-    const size_t lds = (size_t)CE_TOK * rg.width * sizeof(float);
-    MFP_CHECK_ARG(lds <= 60 * 1024);
+    const int ce_tok = (size_t)32 * rg.width * sizeof(float) <= 64 * 1024 ? 32 : 16;
+    const size_t lds = (size_t)ce_tok * rg.width * sizeof(float);
+    MFP_CHECK_ARG(lds <= 64 * 1024);
     rg.nitem = 0;
     for (int i = 0; i < cat.n; ++i) {
       for (int f = 0; f < cat.k[i].n_feat; ++f) {
@@ -591,11 +594,11 @@ static int loss_fwd_bwd_impl(const float* logits, void* dlogits, int32_t ld, con
         rg.nitem++;
       }
     }
-    const int bx = (T + CE_TOK - 1) / CE_TOK;
-    if (dl_dtype == MFP_F32)
-      hipLaunchKernelGGL(ce_tile_kernel<float>, dim3(bx), dim3(256), lds, st, logits, (float*)dlogits, ld, cat, rg, nvalid, sums, T, S, inv_B, pred_row, true_row);
-    else
-      hipLaunchKernelGGL(ce_tile_kernel<unsigned short>, dim3(bx), dim3(256), lds, st, logits, (unsigned short*)dlogits, ld, cat, rg, nvalid, sums, T, S, inv_B, pred_row, true_row);
+    const int bx = (T + ce_tok - 1) / ce_tok;
+#define CE_LAUNCH(TT, TOK) hipLaunchKernelGGL((ce_tile_kernel<TT, TOK>), dim3(bx), dim3(TOK * 16), lds, st, logits, (TT*)dlogits, ld, cat, rg, nvalid, sums, T, S, inv_B, pred_row, true_row)
+    if (dl_dtype == MFP_F32) { if (ce_tok == 32) CE_LAUNCH(float, 32); else CE_LAUNCH(float, 16); }
+    else { if (ce_tok == 32) CE_LAUNCH(unsigned short, 32); else CE_LAUNCH(unsigned short, 16); }
+#undef CE_LAUNCH
     MFP_CHECK_LAUNCH();
   }
   if (num.n > 0 && !skip_numerical) {
