@@ -853,6 +853,150 @@ __global__ __launch_bounds__(512) void dgrad_qkv_kernel(DgradParams p) {
   chunk(std::integral_constant<int, 10>{}); chunk(std::integral_constant<int, 11>{});
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Encoder: both numerical-attribute Dense layers in one launch (reference encoder.py:156-160,174-175,194-198):
+//
+//     h[t] += sum_j [code_j[t] == 0] * (x_j[t] W_j^T + b_j)        j = image embedding, text embedding (512-wide)
+//
+// (a masked / padded attribute contributes its special-token embedding instead, which the embedding kernel has
+// already put into h).  The same activation-stationary machine as dgrad_qkv_kernel with two activation sources:
+// K = 2 x 512 in eight 128-column pieces, the Dense kernels [256][512] are k-major as stored; rows whose code is
+// non-zero get zero fragments and no bias; h is read and rewritten in the epilogue.  Two weight-stationary launches
+// did this in 45 us for 198 MB (h read and rewritten twice); one pass moves 132 MB.
+struct EncParams {
+  const unsigned short* X[2];        // [T][512] bf16
+  const unsigned short* W[2];        // [256][512] bf16 (out, in)
+  const float* bias[2];              // f32 [256]
+  const unsigned char* code[2];      // u8 [T]
+  float* h;                          // [T][256] f32, accumulated in place
+  int T;
+};
+constexpr int ENC_K = 512, ENC_KQ = 2 * ENC_K / 128, ENC_CHUNKS = 2 * ENC_KQ;
+
+__global__ __launch_bounds__(512) void enc_dense_kernel(EncParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const As = smem;
+  unsigned char* const Ws = smem + 2 * MLP_HS_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int rp = wave & 3, nh = wave >> 2;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  const unsigned int xbytes = (unsigned int)p.T * (ENC_K * 2);
+  const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W[0]), 0, MLP_D * ENC_K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W[1]), 0, MLP_D * ENC_K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.X[0]), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.X[1]), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, (unsigned int)p.T * (MLP_D * 4), 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave), wl = wv & 3;
+  const unsigned int poff = (unsigned int)((wl * 32 + (lane >> 4)) * (ENC_K * 2) + (((lane & 15) ^ (lane >> 4)) << 4));
+  auto wload = [&](int c) {          // chunk c = (kq, j): W_{kq >> 2} rows 128 j .. + 127, columns 128 (kq & 3) .. + 127
+    if (wv >= 4) return;
+    unsigned char* dst = Ws + (c % 3) * MLP_WS_B + wl * 8192;
+    const int so = (c & 1) * 128 * (ENC_K * 2) + ((c >> 1) & 3) * 256;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if ((c >> 3) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w0, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6), so + i * 4 * (ENC_K * 2), 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6), so + i * 4 * (ENC_K * 2), 0, 0);
+    }
+  };
+  auto aload = [&](int kq) {
+    if (wv < 4) return;
+    unsigned char* dst = As + (kq & 1) * MLP_HS_B + wl * 8192;
+    const int so = row0 * (ENC_K * 2) + (kq & 3) * 256;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if ((kq >> 2) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x0, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6), so + i * 4 * (ENC_K * 2), 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x1, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6), so + i * 4 * (ENC_K * 2), 0, 0);
+    }
+  };
+  wload(0);
+  wload(1);
+  aload(0);
+  aload(1);
+  // row codes of this lane's two rows, per source (rows >= T: skipped)
+  bool live[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = row0 + rp * 32 + rt * 16 + li;
+      live[j][rt] = row < p.T && p.code[j][row] == 0;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 acc2[8][2];
+  bf16x8 hf[2][4];
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+
+  auto chunk = [&](auto cc_) {
+    constexpr int c = decltype(cc_)::value;
+    constexpr int kq = c >> 1, j = c & 1, src = kq >> 2;
+    if (c + 2 < ENC_CHUNKS) wload(c + 2);
+    if (j == 0 && kq >= 1 && kq + 1 < ENC_KQ) aload(kq + 1);
+    if (j == 0) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(As + (kq & 1) * MLP_HS_B + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
+          hf[rt][ks] = live[src][rt] ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const unsigned char* wa = Ws + (c % 3) * MLP_WS_B + ((nh * 4) * 16 + li) * 256;
+    bf16x8 wf[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[ks + 1]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
+                                                                       (kq == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
+    }
+    if (c >= ENC_CHUNKS - 2) {
+      // columns 128 j .. + 127 are final: h += acc + the biases of the live sources, 4 consecutive columns per lane
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = (j * 8 + nh * 4 + nt) * 16 + 4 * g;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias[0] + n), b1 = *reinterpret_cast<const f32x4*>(p.bias[1] + n);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const unsigned int off = (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (MLP_D * 4) + n * 4;
+          f32x4 o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_h, off, 0, 0));
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            o[r] += acc2[j * 4 + nt][rt][r] + (live[0][rt] ? b0[r] : 0.f) + (live[1][rt] ? b1[r] : 0.f);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_h, off, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < ENC_CHUNKS) {
+      // (chunk 14: its 8 epilogue loads were consumed, so chunk 15 -- older -- has landed; the 8 stores may stay)
+      constexpr int allowed_w = (c + 2 < ENC_CHUNKS ? 8 : 0) + (c == ENC_CHUNKS - 2 ? 8 : 0);
+      if (wv < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
+      else if (j == 1 && kq + 1 < ENC_KQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  chunk(std::integral_constant<int, 0>{});  chunk(std::integral_constant<int, 1>{});
+  chunk(std::integral_constant<int, 2>{});  chunk(std::integral_constant<int, 3>{});
+  chunk(std::integral_constant<int, 4>{});  chunk(std::integral_constant<int, 5>{});
+  chunk(std::integral_constant<int, 6>{});  chunk(std::integral_constant<int, 7>{});
+  chunk(std::integral_constant<int, 8>{});  chunk(std::integral_constant<int, 9>{});
+  chunk(std::integral_constant<int, 10>{}); chunk(std::integral_constant<int, 11>{});
+  chunk(std::integral_constant<int, 12>{}); chunk(std::integral_constant<int, 13>{});
+  chunk(std::integral_constant<int, 14>{}); chunk(std::integral_constant<int, 15>{});
+}
+
 }  // namespace
 
 #ifdef MFP_GEMM_TRACE
@@ -974,6 +1118,33 @@ extern "C" int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t
     attr_set = true;
   }
   hipLaunchKernelGGL(dgrad_qkv_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_encoder_dense2(const void* x0, const void* x1, const void* W0, const void* W1, const float* b0, const float* b1,
+                                  const uint8_t* code0, const uint8_t* code1, float* h, int32_t T, int32_t D, int32_t K,
+                                  mfp_stream_t stream) {
+  MFP_CHECK_ARG(x0 && x1 && W0 && W1 && b0 && b1 && code0 && code1 && h);
+  MFP_CHECK_ARG(T > 0 && T <= (1 << 20) && D == MLP_D && K == ENC_K);
+  MFP_CHECK_ARG(((uintptr_t)x0 % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)W0 % 16) == 0 && ((uintptr_t)W1 % 16) == 0 &&
+                ((uintptr_t)b0 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)h % 16) == 0);
+  EncParams p;
+  p.X[0] = reinterpret_cast<const unsigned short*>(x0); p.X[1] = reinterpret_cast<const unsigned short*>(x1);
+  p.W[0] = reinterpret_cast<const unsigned short*>(W0); p.W[1] = reinterpret_cast<const unsigned short*>(W1);
+  p.bias[0] = b0; p.bias[1] = b1; p.code[0] = code0; p.code[1] = code1; p.h = h; p.T = T;
+  constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_encoder_dense2: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(enc_dense_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -140,6 +140,11 @@ def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
             ctx.onehot = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
         ctx.on_side(build, idx_all, which=2)
     h = ops.embed_pool_fwd(idx_all, st.rowoff, st.tables())
+    if (MLP_FUSE and ctx.cdt == torch.bfloat16 and D == 256 and len(L.num_keys) == 2 and not st.fp8
+            and all(x.shape[1] == 512 and x.dtype == torch.bfloat16 for x in xs)):
+        # both numerical-attribute Dense layers in one activation-stationary launch (csrc/block_fused.hip)
+        return ops.encoder_dense2(xs, [st.cw("encoder/input_%s/kernel" % k) for k in L.num_keys],
+                                  [st.weight("encoder/input_%s/bias" % k) for k in L.num_keys], codes, h)
     for j, k in enumerate(L.num_keys):
         width = xs[j].shape[1]
         ops.gemm(xs[j], st.cw("encoder/input_%s/kernel" % k), T, D, width, a_kmajor=True, b_kmajor=True,

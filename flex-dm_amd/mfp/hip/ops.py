@@ -344,6 +344,17 @@ def dgrad_qkv(dqkv: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
     return dy
 
 
+def encoder_dense2(xs, Ws, biases, codes, h: torch.Tensor) -> torch.Tensor:
+    """h += sum_j [codes[j] == 0] (xs[j] Ws[j]^T + biases[j]) for two 512-wide numerical attributes, in place."""
+    lib = load()
+    T, D = h.shape
+    K = xs[0].shape[1]
+    with _timed("enc_dense_kernel", 2 * 2 * T * K * D, T * (2 * K * 2 + 2 * D * 4) + 2 * K * D * 2):
+        check(lib.mfp_encoder_dense2(_ptr(xs[0]), _ptr(xs[1]), _ptr(Ws[0]), _ptr(Ws[1]), _ptr(biases[0]), _ptr(biases[1]),
+                                     _ptr(codes[0]), _ptr(codes[1]), _ptr(h), T, D, K, _stream()), "mfp_encoder_dense2")
+    return h
+
+
 def mlp_fused_bwd(d_o2, h, W2t, W1t):
     """dh = (d_o2 W2) * [h > 0], dy2 = dh W1 in one launch (d_model 256, bf16); W2t / W1t are the transposed
     (k-major) shadows.  Returns (dh, dy2)."""

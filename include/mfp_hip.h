@@ -183,6 +183,14 @@ int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2t, const vo
  * dqkv bf16 [T,768], Wt bf16 [256][768] = the kernel transposed (k-major shadow).  d_model 256 only. */
 int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t D, mfp_stream_t stream);
 
+/* Encoder, both 512-wide numerical attributes in one launch (encoder.py:156-160,174-175,194-198):
+ * h[t] += sum_j [code_j[t] == 0] (x_j[t] W_j^T + b_j), x_j bf16 [T,512], W_j bf16 [256][512], b_j f32 [256],
+ * code_j u8 [T] (non-zero: the attribute is masked / absent at that position and contributes nothing here),
+ * h f32 [T,256] accumulated in place.  d_model 256, K = 512 only. */
+int mfp_encoder_dense2(const void* x0, const void* x1, const void* W0, const void* W1, const float* b0, const float* b1,
+                       const uint8_t* code0, const uint8_t* code1, float* h, int32_t T, int32_t D, int32_t K,
+                       mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- LayerNorm
  * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
  * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.

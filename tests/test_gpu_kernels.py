@@ -945,3 +945,30 @@ def test_dgrad_qkv(T):
     dyu = ops.gemm(dqd, Wt, T, D, K, a_kmajor=True, b_kmajor=True, out_dtype=torch.bfloat16)
     assert_close(dy, dyu.float().cpu().double(), 2e-2, 1e-2, "vs the weight-stationary product")
     assert_close(dy, dq.double() @ W.double(), 2e-2, 1e-2, "vs double")
+
+
+@pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
+def test_encoder_dense2(T):
+    """mfp_encoder_dense2: h += sum_j [code_j == 0] (x_j W_j^T + b_j) in one launch (encoder.py:156-160,174-175)
+    against the two row-skipping accumulate products it replaces and a double reference; ragged last row group."""
+    ops = _ops()
+    D, K = 256, 512
+    g = torch.Generator().manual_seed(T + 4)
+    xs = [bf16_round(torch.randn(T, K, generator=g)) for _ in range(2)]
+    Ws = [bf16_round(torch.randn(D, K, generator=g) * 0.05) for _ in range(2)]
+    bs = [torch.randn(D, generator=g) * 0.1 for _ in range(2)]
+    codes = [(torch.rand(T, generator=g) < 0.3).to(torch.uint8) * torch.randint(1, 3, (T,), generator=g, dtype=torch.uint8) for _ in range(2)]
+    h0 = torch.randn(T, D, generator=g)
+    xd = [x.to(DEV, torch.bfloat16) for x in xs]
+    Wd = [w.to(DEV, torch.bfloat16) for w in Ws]
+    bd = [b.to(DEV) for b in bs]
+    cd = [c.to(DEV) for c in codes]
+    h = ops.encoder_dense2(xd, Wd, bd, cd, h0.to(DEV))
+    hu = h0.to(DEV)
+    for j in range(2):
+        ops.gemm(xd[j], Wd[j], T, D, K, a_kmajor=True, b_kmajor=True, out=hu, accum=True, rowskip=cd[j], bias=bd[j])
+    assert_close(h, hu.cpu().double(), 1e-3, 1e-3, "vs the two accumulate products")
+    want = h0.double()
+    for j in range(2):
+        want = want + (codes[j] == 0).double()[:, None] * (xs[j].double() @ Ws[j].double().t() + bs[j].double())
+    assert_close(h, want, 1e-3, 1e-3, "vs double")
