@@ -997,6 +997,117 @@ __global__ __launch_bounds__(512) void enc_dense_kernel(EncParams p) {
   chunk(std::integral_constant<int, 14>{}); chunk(std::integral_constant<int, 15>{});
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Input gradient of the concatenated decoder heads: dh f32 [T][256] = dlogits[T][U] Wheads (decoder.py:39-43 under
+// Keras autodiff), U = 1384 at Crello.  dgrad_qkv_kernel's machine with the piece count as a run-time loop:
+// dlogits in 128-column pieces (the last one reaches past the row end: those columns meet ZERO weights -- the
+// transposed weight copy [256][ldw] is zero-padded to a multiple of 128 columns), f32 result straight from the
+// accumulators.  The LDS-tiled kernel took 44 us (2 us per 64-wide k-tile and workgroup, 22 of them).
+struct DgradRowsParams {
+  const unsigned short* A;     // [T][lda] bf16
+  const unsigned short* Wt;    // [256][ldw] bf16, zero beyond the real columns
+  float* C;                    // [T][256] f32
+  int T, KQ, lda, ldw;         // lda, ldw in ELEMENTS; KQ = 128-column pieces (ldw >= 128 KQ)
+};
+
+__global__ __launch_bounds__(512) void dgrad_rows_kernel(DgradRowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const As = smem;
+  unsigned char* const Ws = smem + 2 * MLP_HS_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int rp = wave & 3, nh = wave >> 2;
+  const int row0 = blockIdx.x * MLP_ROWS;
+  const int lda2 = p.lda * 2, ldw2 = p.ldw * 2, KQ = p.KQ;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wt), 0, (unsigned int)(MLP_D * ldw2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, (unsigned int)p.T * (unsigned int)lda2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (unsigned int)p.T * (MLP_D * 4), 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave), wl = wv & 3;
+  const unsigned int slot0 = (unsigned int)(((lane & 15) ^ (lane >> 4)) << 4);
+  // (row strides are arbitrary multiples of 16 bytes here: the slot XOR is applied to the slot term alone)
+  const unsigned int woff = (unsigned int)((wl * 32 + (lane >> 4)) * ldw2);
+  const unsigned int aoff = (unsigned int)((row0 + wl * 32 + (lane >> 4)) * lda2);
+  auto wload = [&](int c) {          // chunk c = (kq, j): Wt rows 128 j .. + 127, columns 128 kq .. + 127
+    if (wv >= 4) return;
+    unsigned char* dst = Ws + (c % 3) * MLP_WS_B + wl * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_u8*)(dst + i * 1024), 16, woff + (slot0 ^ ((i & 3) << 6)),
+                                               (c & 1) * 128 * ldw2 + (c >> 1) * 256 + i * 4 * ldw2, 0, 0);
+  };
+  auto aload = [&](int kq) {
+    if (wv < 4) return;
+    unsigned char* dst = As + (kq & 1) * MLP_HS_B + wl * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_u8*)(dst + i * 1024), 16, aoff + (slot0 ^ ((i & 3) << 6)), kq * 256 + i * 4 * lda2, 0, 0);
+  };
+  wload(0);
+  wload(1);
+  aload(0);
+  if (KQ > 1) aload(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 acc2[8][2];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) acc2[a][0] = acc2[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 hf[2][4];
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+  const int nchunks = 2 * KQ;
+  for (int kq = 0; kq < KQ; ++kq) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = 2 * kq + j;
+      if (c + 2 < nchunks) wload(c + 2);
+      if (j == 0 && kq >= 1 && kq + 1 < KQ) aload(kq + 1);
+      if (j == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            hf[rt][ks] = *reinterpret_cast<const bf16x8*>(As + (kq & 1) * MLP_HS_B + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
+      }
+      const unsigned char* wa = Ws + (c % 3) * MLP_WS_B + ((nh * 4) * 16 + li) * 256;
+      bf16x8 wf[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[ks + 1]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks], acc2[j * 4 + nt][rt], 0, 0, 0);
+      }
+      if (kq == KQ - 1) {
+        // columns 128 j .. + 127 of the result are final: 4 consecutive f32 per lane and tile, straight out
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[j * 4 + nt][rt]), rs_c,
+                                                   (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (MLP_D * 4) + ((j * 8 + nh * 4 + nt) * 16 + 4 * g) * 4, 0, 0);
+      }
+      if (c + 1 < nchunks) {
+        // weight waves: chunk c + 1 landed when at most the 8 loads of chunk c + 2 (and the 8 result stores of the
+        // second to last chunk) are outstanding; activation waves: piece kq + 1 is due at the end of (kq, 1)
+        if (wv < 4) {
+          if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");       // (here the 8 are the result stores)
+        } else if (j == 1 && kq + 1 < KQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef MFP_GEMM_TRACE
@@ -1145,6 +1256,29 @@ extern "C" int mfp_encoder_dense2(const void* x0, const void* x1, const void* W0
     attr_set = true;
   }
   hipLaunchKernelGGL(enc_dense_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_dgrad_rows(const void* A, int32_t lda, const void* Wt, int32_t ldw, float* C, int32_t T, int32_t D, int32_t K,
+                              mfp_stream_t stream) {
+  MFP_CHECK_ARG(A && Wt && C && T > 0 && T <= (1 << 19) && D == MLP_D && K > 0 && lda >= K && lda % 8 == 0 && ldw % 128 == 0 && ldw >= K);
+  MFP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)C % 16) == 0);
+  DgradRowsParams p;
+  p.A = reinterpret_cast<const unsigned short*>(A); p.Wt = reinterpret_cast<const unsigned short*>(Wt); p.C = C;
+  p.T = T; p.KQ = (K + 127) / 128; p.lda = lda; p.ldw = ldw;
+  constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_dgrad_rows: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dgrad_rows_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

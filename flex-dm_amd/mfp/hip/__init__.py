@@ -97,6 +97,7 @@ SIGNATURES = {
     "mfp_qkv_fused_fwd": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_float, c_void_p]),
     "mfp_dgrad_qkv": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_encoder_dense2": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_void_p]),
+    "mfp_dgrad_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mfp_mlp_fused_bwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
     "mfp_layernorm_fwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_int32, c_void_p]),
     "mfp_layernorm_bwd": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,

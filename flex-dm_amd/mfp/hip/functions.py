@@ -471,6 +471,9 @@ def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Ten
                  out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
                  colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U), splitk=ops.wgrad_splitk(T, U, D))
     ctx.on_side(wgrad_heads, dl_c, h_c)
+    wt = st.heads_t()
+    if MLP_FUSE and wt is not None and dl_c.dtype == torch.bfloat16 and D == 256 and T <= (1 << 19):
+        return ops.dgrad_rows(dl_c, wt, U)        # activation-stationary (csrc/block_fused.hip)
     dh = ops.gemm(dl_c, st.cw("decoder/decoder_%s/kernel" % first, rows=U), T, D, U, a_kmajor=True,
                   b_kmajor=False, out_dtype=torch.float32)
     return dh

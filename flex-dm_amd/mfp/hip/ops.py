@@ -355,6 +355,17 @@ def encoder_dense2(xs, Ws, biases, codes, h: torch.Tensor) -> torch.Tensor:
     return h
 
 
+def dgrad_rows(A: torch.Tensor, Wt: torch.Tensor, K: int) -> torch.Tensor:
+    """C f32 [T,256] = A[:, :K] Wt[:, :K]^T; A bf16 [T][lda], Wt bf16 [256][ldw] zero-padded beyond K (ldw % 128 == 0)."""
+    lib = load()
+    T = A.shape[0]
+    out = torch.empty((T, Wt.shape[0]), dtype=torch.float32, device=A.device)
+    with _timed("dgrad_rows_kernel", 2 * T * K * Wt.shape[0], T * (K * 2 + Wt.shape[0] * 4) + Wt.numel() * 2):
+        check(lib.mfp_dgrad_rows(_ptr(A), A.stride(0), _ptr(Wt), Wt.stride(0), _ptr(out), T, Wt.shape[0], K, _stream()),
+              "mfp_dgrad_rows")
+    return out
+
+
 def mlp_fused_bwd(d_o2, h, W2t, W1t):
     """dh = (d_o2 W2) * [h > 0], dy2 = dh W1 in one launch (d_model 256, bf16); W2t / W1t are the transposed
     (k-major) shadows.  Returns (dh, dy2)."""

@@ -205,9 +205,17 @@ class ParamStore:
                     for j, nm in enumerate(("dense_query", "dense_key", "dense_value")):
                         sg = layout.segments["blocks/seq2seq_%d/attn/%s/kernel" % (i, nm)]
                         segs.append((sg.offset, sg.shape[0], sg.shape[1], q.offset + j * layout.D, 3 * layout.D))
+            # concatenated decoder heads [Upad][D] -> [D][Upad rounded up to 128] (zero pad columns), behind the end of
+            # the buffer: the activation-stationary input gradient of the heads (csrc/block_fused.hip)
+            self._heads_t = None
+            if layout.D == 256:
+                ldw = (layout.Upad + 127) // 128 * 128
+                segs.append((layout.heads_start, layout.Upad, layout.D, n, ldw))
+                self._heads_t = (n, ldw)
             if segs:
                 from mfp.hip import ops
-                self.shadow_t = torch.zeros(n, dtype=torch.bfloat16, device=device)
+                self.shadow_t = torch.zeros(n + (layout.D * self._heads_t[1] if self._heads_t else 0), dtype=torch.bfloat16,
+                                            device=device)
                 self._ttable = ops.TransposeTable(segs, device)
         if self.fp8:
             self.shadow8 = torch.zeros(n, dtype=torch.uint8, device=device)
@@ -280,6 +288,13 @@ class ParamStore:
         if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and s.shape[0] in WS_K):
             return None
         return self.shadow_t[s.offset:s.offset + s.size].view(s.shape[1], s.shape[0])
+
+    def heads_t(self) -> Optional[torch.Tensor]:
+        """[D][ldw] bf16: the concatenated head kernels transposed, zero beyond column Upad (None when not kept)."""
+        if self.shadow_t is None or getattr(self, "_heads_t", None) is None:
+            return None
+        off, ldw = self._heads_t
+        return self.shadow_t[off:off + self.layout.D * ldw].view(self.layout.D, ldw)
 
     def tables_padded(self, buf=None) -> torch.Tensor:
         """[table_rows_pad][D] view: the tables plus the zero pad rows behind them."""

@@ -191,6 +191,12 @@ int mfp_encoder_dense2(const void* x0, const void* x1, const void* W0, const voi
                        const uint8_t* code0, const uint8_t* code1, float* h, int32_t T, int32_t D, int32_t K,
                        mfp_stream_t stream);
 
+/* Input gradient of a wide Dense in one activation-stationary launch: C f32 [T,256] = A[T][:K] Wt^T with A bf16
+ * [T][lda] and Wt bf16 [256][ldw] = the kernel transposed, ZERO beyond column K (ldw a multiple of 128, >= K): the
+ * decoder heads (decoder.py:39-43; K = 1384 at Crello).  d_model 256 only. */
+int mfp_dgrad_rows(const void* A, int32_t lda, const void* Wt, int32_t ldw, float* C, int32_t T, int32_t D, int32_t K,
+                   mfp_stream_t stream);
+
 /* --------------------------------------------------------------------------- LayerNorm
  * Keras LayerNormalization(), eps 1e-3 (transformer.py:172-173,216,222).
  * x f32 [T,D]; y cdt [T,D]; mean/rstd f32 [T].  D % 64 == 0, D <= 1024.

@@ -972,3 +972,26 @@ def test_encoder_dense2(T):
     for j in range(2):
         want = want + (codes[j] == 0).double()[:, None] * (xs[j].double() @ Ws[j].double().t() + bs[j].double())
     assert_close(h, want, 1e-3, 1e-3, "vs double")
+
+
+@pytest.mark.parametrize("T,K", [(4096, 1384), (1000, 1384), (33, 200), (128 * 3 + 5, 128), (300, 1536)])
+def test_dgrad_rows(T, K):
+    """mfp_dgrad_rows: C = A[:, :K] Wt^T with a zero-padded transposed weight copy (decoder heads input gradient),
+    run-time number of 128-column pieces, the last piece reaching past the row end; against a double reference and
+    the LDS-tiled product it replaces."""
+    ops = _ops()
+    D = 256
+    g = torch.Generator().manual_seed(T + K)
+    lda = (K + 7) // 8 * 8
+    ldw = (K + 127) // 128 * 128
+    A = bf16_round(torch.randn(T, lda, generator=g) * 0.5)
+    A[:, K:] = 0          # (pad columns of the logits gradient are zero by construction)
+    W = bf16_round(torch.randn(K, D, generator=g) * 0.05)             # [out = K][in = 256]
+    Wt = torch.zeros(D, ldw)
+    Wt[:, :K] = W.t()
+    Ad, Wtd = A.to(DEV, torch.bfloat16), Wt.to(DEV, torch.bfloat16)
+    C = ops.dgrad_rows(Ad, Wtd, K)
+    want = A[:, :K].double() @ W.double()
+    assert_close(C, want, 2e-3, 2e-3, "vs double")
+    Cu = ops.gemm(Ad, W.to(DEV, torch.bfloat16), T, D, K, a_kmajor=True, b_kmajor=False, lda=lda, out_dtype=torch.float32)
+    assert_close(C, Cu.cpu().double(), 1e-3, 1e-3, "vs the tiled product")
