@@ -492,6 +492,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #include "gemm_ws.h"
 #include "gemm_wg.h"
 #include "gemm_wgg.h"
+#include "gemm_wgg2.h"
 
 int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
   static int ncu_of[MFP_MAX_DEVICES] = {};
@@ -705,6 +706,21 @@ int wgg_tiles(const mfp_wgrad_job* jobs, int njobs) {
   for (int i = 0; i < njobs; ++i) t += ((jobs[i].M + 127) / 128) * ((jobs[i].N + 127) / 128);
   return t;
 }
+// second-generation engine (gemm_wgg2.h: 256 x 128 macro tiles, all eight waves multiply and stream), opt-in with
+// MFP_WGG2=1 for every job that does not mask rows: measured SLOWER than gemm_wgg.h (block group 81 vs 72 us
+// stand-alone; see the header), kept for the A/B
+bool wgg2_on(const mfp_wgrad_job* jobs, int njobs) {
+  static const bool on = getenv("MFP_WGG2") != nullptr && getenv("MFP_WGG2")[0] == '1';
+  if (!on) return false;
+  for (int i = 0; i < njobs; ++i)
+    if (jobs[i].rowcode != nullptr) return false;
+  return true;
+}
+int wgg_mtiles(const mfp_wgrad_job* jobs, int njobs) {
+  int t = 0;
+  for (int i = 0; i < njobs; ++i) t += (((jobs[i].M + 127) / 128 + 1) / 2) * ((jobs[i].N + 127) / 128);
+  return t;
+}
 int wgg_ncu() {
   static int ncu_of[MFP_MAX_DEVICES] = {};
   int& ncu = ncu_of[mfp_device_slot()];
@@ -728,7 +744,8 @@ extern "C" int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs, int32_t njob
 // slabs); slices of at least 256 tokens, at most WG_MAX_KCHUNK when a job masks rows (codes in LDS).
 extern "C" int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K) {
   if (jobs == nullptr || njobs < 1 || K < 1) return 8;
-  const int tiles = wgg_tiles(jobs, njobs), ncu = wgg_ncu();
+  const bool g2 = wgg2_on(jobs, njobs);
+  const int tiles = g2 ? wgg_mtiles(jobs, njobs) : wgg_tiles(jobs, njobs), ncu = wgg_ncu();
   bool rowskip = false;
   for (int i = 0; i < njobs; ++i) rowskip |= jobs[i].rowcode != nullptr;
   int best = 8;
@@ -793,7 +810,24 @@ extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t
   p.trace = g_trace;
 #endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int rc = rowskip ? launch_wgg_t<true>(p, st) : launch_wgg_t<false>(p, st);
+  int rc;
+  if (wgg2_on(jobs, njobs)) {
+    Wgg2Params pp;
+    pp.base = p;
+    int mt0 = 0;
+    for (int i = 0; i < WGG_MAX_JOBS; ++i) {
+      if (i < njobs) {
+        pp.mtile0[i] = mt0;
+        mt0 += (((jobs[i].M + 127) / 128 + 1) / 2) * ((jobs[i].N + 127) / 128);
+      } else {
+        pp.mtile0[i] = 0x7FFFFFFF;
+      }
+    }
+    pp.nmtiles = mt0;
+    rc = launch_wgg2(pp, st);
+  } else {
+    rc = rowskip ? launch_wgg_t<true>(p, st) : launch_wgg_t<false>(p, st);
+  }
   if (rc != MFP_OK) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
