@@ -361,7 +361,7 @@ def main():
                          "algorithmic_gb_per_step": blk[1] / nprof / 1e9,
                          "note": "all kernels of the DeepSVG blocks (LN, QKV/O/FFN GEMMs, attention, their input and "
                                  "weight gradients), all on one stream: sum of event-timed launch durations in EAGER "
-                                 "steps (launch gaps included; the same kernels under hipGraph replay sum to ~1.53 ms: "
+                                 "steps (launch gaps included; the same kernels under hipGraph replay sum to ~1.33 ms: "
                                  "profiles/r02_step_dump.txt)"},
                      "step": {"achieved": step_tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": step_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS},
