@@ -584,7 +584,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   MLP_STAMP(0);
   wload(0);
   wload(1);
-  hload(0);
   // operand fragments of d_o2: lane (li, g) holds row li of the tile, columns 32 ks + 8 g .. + 7
   bf16x8 xf[2][8];
 #pragma unroll
@@ -593,9 +592,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
     for (int ks = 0; ks < 8; ++ks)
       xf[rt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
           rs_do, (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (MLP_D * 2) + g * 16 + ks * 64, 0, 0));
+  // the first h quarter is needed at the END of chunk 0 (its epilogue) only: it stays in flight across this
+  // barrier (first touched since the forward pass: HBM latency) and is waited for in front of that epilogue
+  hload(0);
   MLP_STAMP(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();       // chunks 0, 1 and the first h quarter are in LDS
+  if (wv < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // chunks 0, 1 landed (older than the 16 fragment loads)
+  __builtin_amdgcn_s_barrier();
   MLP_STAMP(2);
 
   f32x4 acc2[8][2];
@@ -633,6 +635,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt)
             acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+      }
+      if (c == 0) {      // the first h quarter (waves 4-7 issued it in the prologue) must be in LDS now
+        if (wv >= 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
