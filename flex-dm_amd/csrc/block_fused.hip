@@ -744,9 +744,10 @@ struct DgradParams {
   unsigned short* C;           // [T][256] bf16
   int T;
 };
-constexpr int DG_K = 768, DG_KQ = DG_K / 128, DG_CHUNKS = 2 * DG_KQ;
-
+// (DG_K = 768: the fused Q | K | V; DG_K = 256: the attention output projection, da = d_o1 Wo)
+template <int DG_K>
 __global__ __launch_bounds__(512) void dgrad_qkv_kernel(DgradParams p) {
+  constexpr int DG_KQ = DG_K / 128, DG_CHUNKS = 2 * DG_KQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const As = smem;                       // two [128][256 B] images of dqkv pieces
   unsigned char* const Ws = smem + 2 * MLP_HS_B;
@@ -853,10 +854,12 @@ __global__ __launch_bounds__(512) void dgrad_qkv_kernel(DgradParams p) {
   };
   chunk(std::integral_constant<int, 0>{});  chunk(std::integral_constant<int, 1>{});
   chunk(std::integral_constant<int, 2>{});  chunk(std::integral_constant<int, 3>{});
-  chunk(std::integral_constant<int, 4>{});  chunk(std::integral_constant<int, 5>{});
-  chunk(std::integral_constant<int, 6>{});  chunk(std::integral_constant<int, 7>{});
-  chunk(std::integral_constant<int, 8>{});  chunk(std::integral_constant<int, 9>{});
-  chunk(std::integral_constant<int, 10>{}); chunk(std::integral_constant<int, 11>{});
+  if constexpr (DG_CHUNKS > 4) {
+    chunk(std::integral_constant<int, 4>{});  chunk(std::integral_constant<int, 5>{});
+    chunk(std::integral_constant<int, 6>{});  chunk(std::integral_constant<int, 7>{});
+    chunk(std::integral_constant<int, 8>{});  chunk(std::integral_constant<int, 9>{});
+    chunk(std::integral_constant<int, 10>{}); chunk(std::integral_constant<int, 11>{});
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1217,24 +1220,43 @@ extern "C" int mfp_qkv_fused_fwd(const float* x, const float* gamma, const float
   return MFP_OK;
 }
 
-extern "C" int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t D, mfp_stream_t stream) {
-  MFP_CHECK_ARG(dqkv && Wt && dy && T > 0 && T <= (1 << 20) && D == MLP_D);
-  MFP_CHECK_ARG(((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)dy % 16) == 0);
-  DgradParams p;
-  p.A = reinterpret_cast<const unsigned short*>(dqkv); p.Wt = reinterpret_cast<const unsigned short*>(Wt);
-  p.C = reinterpret_cast<unsigned short*>(dy); p.T = T;
+template <int K>
+static int launch_dgrad_k(const DgradParams& p, hipStream_t st) {
   constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_qkv_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_dgrad_qkv: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(dgrad_qkv_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(dgrad_qkv_kernel<K>, dim3((p.T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, st, p);
+  return MFP_OK;
+}
+
+extern "C" int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t D, mfp_stream_t stream) {
+  MFP_CHECK_ARG(dqkv && Wt && dy && T > 0 && T <= (1 << 20) && D == MLP_D);
+  MFP_CHECK_ARG(((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)dy % 16) == 0);
+  DgradParams p;
+  p.A = reinterpret_cast<const unsigned short*>(dqkv); p.Wt = reinterpret_cast<const unsigned short*>(Wt);
+  p.C = reinterpret_cast<unsigned short*>(dy); p.T = T;
+  const int rc = launch_dgrad_k<768>(p, reinterpret_cast<hipStream_t>(stream));
+  if (rc != MFP_OK) return rc;
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_dgrad_d256(const void* dy, const void* Wt, void* dx, int32_t T, int32_t D, mfp_stream_t stream) {
+  MFP_CHECK_ARG(dy && Wt && dx && T > 0 && T <= (1 << 20) && D == MLP_D);
+  MFP_CHECK_ARG(((uintptr_t)dy % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)dx % 16) == 0);
+  DgradParams p;
+  p.A = reinterpret_cast<const unsigned short*>(dy); p.Wt = reinterpret_cast<const unsigned short*>(Wt);
+  p.C = reinterpret_cast<unsigned short*>(dx); p.T = T;
+  const int rc = launch_dgrad_k<256>(p, reinterpret_cast<hipStream_t>(stream));
+  if (rc != MFP_OK) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mfp_mlp_fused_fwd": (c_int32, [c_void_p] * 12 + [c_int32, c_int32, c_float, c_float, c_uint64, c_uint64,
                                                    c_void_p, c_void_p]),
     "mfp_qkv_fused_fwd": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_float, c_void_p]),
+    "mfp_dgrad_d256": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_dgrad_qkv": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_encoder_dense2": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_void_p]),
     "mfp_dgrad_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

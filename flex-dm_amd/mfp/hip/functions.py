@@ -399,8 +399,11 @@ class BlockFn(torch.autograd.Function):
                                             ctx.step_ptr), jobs=ctx.ln_jobs)
         # ---- attention: x1 = x + drop(a Wo + bo)
         wt = st.cwt(p + "attn/combine_heads/kernel")
-        da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True,
-                      b_kmajor=wt is not None, out_dtype=cdt)
+        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and wt is not None:
+            da = ops.dgrad_d256(d_o1, wt)      # activation-stationary (csrc/block_fused.hip)
+        else:
+            da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True,
+                          b_kmajor=wt is not None, out_dtype=cdt)
         dqkv = ops.attention_bwd(qkv, ctx.nvalid, a, da, lse, B, S, NUM_HEADS)
 
         def wgrads_attn():

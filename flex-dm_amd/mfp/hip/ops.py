@@ -355,6 +355,16 @@ def encoder_dense2(xs, Ws, biases, codes, h: torch.Tensor) -> torch.Tensor:
     return h
 
 
+def dgrad_d256(dy: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
+    """dx = dy W (bf16 [T,256]) for a 256 -> 256 Dense with Wt = its [256][256] transposed shadow."""
+    lib = load()
+    T, D = dy.shape
+    dx = torch.empty((T, D), dtype=torch.bfloat16, device=dy.device)
+    with _timed("dgrad_qkv_kernel", 2 * T * D * D, T * 2 * D * 2 + D * D * 2):
+        check(lib.mfp_dgrad_d256(_ptr(dy), _ptr(Wt), _ptr(dx), T, D, _stream()), "mfp_dgrad_d256")
+    return dx
+
+
 def dgrad_rows(A: torch.Tensor, Wt: torch.Tensor, K: int) -> torch.Tensor:
     """C f32 [T,256] = A[:, :K] Wt[:, :K]^T; A bf16 [T][lda], Wt bf16 [256][ldw] zero-padded beyond K (ldw % 128 == 0)."""
     lib = load()

@@ -182,6 +182,8 @@ int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2t, const vo
 /* Input gradient of the fused Q | K | V Dense in one activation-stationary launch: dy bf16 [T,256] = dqkv Wqkv,
  * dqkv bf16 [T,768], Wt bf16 [256][768] = the kernel transposed (k-major shadow).  d_model 256 only. */
 int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t D, mfp_stream_t stream);
+/* The same machine for a 256 -> 256 Dense (the attention output projection): dx bf16 [T,256] = dy W, Wt bf16 [256][256]. */
+int mfp_dgrad_d256(const void* dy, const void* Wt, void* dx, int32_t T, int32_t D, mfp_stream_t stream);
 
 /* Encoder, both 512-wide numerical attributes in one launch (encoder.py:156-160,174-175,194-198):
  * h[t] += sum_j [code_j[t] == 0] (x_j[t] W_j^T + b_j), x_j bf16 [T,512], W_j bf16 [256][512], b_j f32 [256],

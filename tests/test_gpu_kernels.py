@@ -995,3 +995,15 @@ def test_dgrad_rows(T, K):
     assert_close(C, want, 2e-3, 2e-3, "vs double")
     Cu = ops.gemm(Ad, W.to(DEV, torch.bfloat16), T, D, K, a_kmajor=True, b_kmajor=False, lda=lda, out_dtype=torch.float32)
     assert_close(C, Cu.cpu().double(), 1e-3, 1e-3, "vs the tiled product")
+
+
+@pytest.mark.parametrize("T", [4096, 1000, 33])
+def test_dgrad_d256(T):
+    """mfp_dgrad_d256: dx = dy W for the 256 -> 256 attention output projection, against a double reference."""
+    ops = _ops()
+    D = 256
+    g = torch.Generator().manual_seed(T + 9)
+    dy = bf16_round(torch.randn(T, D, generator=g) * 0.5)
+    W = bf16_round(torch.randn(D, D, generator=g) * 0.06)             # [out][in]
+    dx = ops.dgrad_d256(dy.to(DEV, torch.bfloat16), W.t().contiguous().to(DEV, torch.bfloat16))
+    assert_close(dx, dy.double() @ W.double(), 2e-2, 1e-2, "vs double")
