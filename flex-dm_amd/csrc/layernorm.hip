@@ -298,7 +298,7 @@ extern "C" int mfp_reduce_partials_batch(const mfp_reduce_job* jobs, int32_t njo
     rj.part[i] = j.part; rj.out0[i] = j.out0; rj.out1[i] = j.out1; rj.out2[i] = j.out2;
     rj.split1[i] = j.split1; rj.split2[i] = j.split2; rj.N[i] = j.N; rj.pstride[i] = j.pstride; rj.P[i] = j.P;
   }
-  hipLaunchKernelGGL(reduce_rows_multi_kernel<8>, dim3((unsigned)((maxn + 7) / 8), (unsigned)njobs), dim3(256), 0,
+  hipLaunchKernelGGL(reduce_rows_multi_kernel<16>, dim3((unsigned)((maxn + 15) / 16), (unsigned)njobs), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), rj);
   MFP_CHECK_LAUNCH();
   return MFP_OK;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) static void reduce_rows_multi_kernel(ReduceJob
 static inline void launch_reduce_rows3(const float* part, float* out0, float* out1, float* out2, long long split1,
                                        long long split2, int P, long long N, long long pstride, hipStream_t st) {
   if (N <= 8192)
-    hipLaunchKernelGGL(reduce_rows_kernel<8>, dim3((unsigned)((N + 7) / 8)), dim3(256), 0, st, part, out0, out1, out2,
+    hipLaunchKernelGGL(reduce_rows_kernel<16>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, st, part, out0, out1, out2,
                        split1, split2, P, N, pstride);
   else
     hipLaunchKernelGGL(reduce_rows_kernel<32>, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, part, out0, out1,
