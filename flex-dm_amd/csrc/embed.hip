@@ -94,29 +94,42 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
 // counts 0..3 in bf16; dh in the compute dtype like every other weight gradient) -- off the
 // critical path on the side stream, instead of the LDS-atomic scatter kernel above (106 us).
 // One wave per token; a lane owns 32-bit words (two adjacent rows) l, l + 64, ...
+constexpr int OH_TOK = 8;     // tokens per wave: their index words are loaded together (one round trip, not eight)
+constexpr int OH_MAXW = 512;  // 32-bit words per row (ROWSP <= 1024)
 __global__ __launch_bounds__(256) void embed_onehot_kernel(const int* __restrict__ idx,
                                                            const int* __restrict__ rowoff,
                                                            unsigned int* __restrict__ P, int T, int NCOL,
                                                            int ROWSP) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
-  int myrow = -1;
-  if (lane < NCOL) {
-    const int r = idx[(long long)t * NCOL + lane];
-    myrow = r < 0 ? -1 : rowoff[lane] + r;
+  // counts per wave in LDS: the NCOL index lanes bump 16-bit halves of their row's word (the compare-and-count
+  // walk over all columns for every output word was 180 VALU instructions per token: 20 us)
+  __shared__ unsigned int cnt[4][OH_MAXW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 4 + wv) * OH_TOK;
+  if (t0 >= T) return;
+  int myrow[OH_TOK];
+  const int ro = lane < NCOL ? rowoff[lane] : 0;
+#pragma unroll
+  for (int u = 0; u < OH_TOK; ++u) {
+    const int t = min(t0 + u, T - 1);
+    const int r = lane < NCOL ? idx[(long long)t * NCOL + lane] : -1;
+    myrow[u] = r < 0 ? -1 : ro + r;
   }
   const int words = ROWSP >> 1;
-  for (int w = lane; w < words; w += 64) {
-    int c0 = 0, c1 = 0;
-    for (int j = 0; j < NCOL; ++j) {
-      const int row = __shfl(myrow, j, 64);
-      c0 += row == 2 * w;
-      c1 += row == 2 * w + 1;
+  unsigned int* c = cnt[wv];
+#pragma unroll
+  for (int u = 0; u < OH_TOK; ++u) {
+    if (t0 + u >= T) break;
+    for (int w = lane; w < words; w += 64) c[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (myrow[u] >= 0) atomicAdd(&c[myrow[u] >> 1], (myrow[u] & 1) ? 0x10000u : 1u);
+    __builtin_amdgcn_wave_barrier();
+    for (int w = lane; w < words; w += 64) {
+      const unsigned int v = c[w];
+      // bf16 bit patterns of 0, 1, 2, 3, ... (small integers are exact)
+      const unsigned int lo = f32_to_bf16((float)(v & 0xFFFFu)), hi = f32_to_bf16((float)(v >> 16));
+      P[(long long)(t0 + u) * words + w] = lo | (hi << 16);
     }
-    // bf16 bit patterns of 0, 1, 2, 3, ... (small integers are exact)
-    const unsigned int lo = f32_to_bf16((float)c0), hi = f32_to_bf16((float)c1);
-    P[(long long)t * words + w] = lo | (hi << 16);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -219,8 +232,8 @@ extern "C" int mfp_row_flags(const float* x, uint8_t* rowcode, int32_t* special_
 
 extern "C" int mfp_embed_onehot(const int32_t* idx, const int32_t* rowoff, uint16_t* P, int32_t T,
                                 int32_t NCOL, int32_t ROWSP, mfp_stream_t stream) {
-  MFP_CHECK_ARG(idx && rowoff && P && T > 0 && NCOL > 0 && NCOL <= 64 && ROWSP > 0 && ROWSP % 8 == 0);
-  hipLaunchKernelGGL(embed_onehot_kernel, dim3((T + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  MFP_CHECK_ARG(idx && rowoff && P && T > 0 && NCOL > 0 && NCOL <= 64 && ROWSP > 0 && ROWSP % 8 == 0 && ROWSP <= 2 * OH_MAXW);
+  hipLaunchKernelGGL(embed_onehot_kernel, dim3((T + 4 * OH_TOK - 1) / (4 * OH_TOK)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      idx, rowoff, reinterpret_cast<unsigned int*>(P), T, NCOL, ROWSP);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
