@@ -157,6 +157,9 @@ def load(path: str = None):
         raise MFPHipUnavailable(
             "%s not found at %s: build it with `python __graft_entry__.py` (or `make -C "
             "flex-dm_amd/csrc`).  The MFP hot path has no CPU fallback." % (LIB_NAME, path))
+    # PyTorch's HIP runtime must be in the process BEFORE this library binds to libamdhip64: loaded the other way
+    # round the two end up on different runtime instances and the first launch fails with "no ROCm-capable device"
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover
