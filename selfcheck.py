@@ -41,3 +41,30 @@ def run_smoke():
     err = (gd[name].double() - grads[name]).abs().max().item()
     assert err < 1e-4, (name, err)
     print("smoke ok: loss %.6f (oracle %.6f), dWq max err %.2e" % (got, want, err))
+
+    # the timed path: bf16, d_model 256 -- the activation-stationary block kernels (csrc/block_fused.hip), the
+    # weight-stationary and grouped weight-gradient GEMMs, bf16 attention -- against the same oracle
+    B, S, D, L = 2, 128, 256, 2
+    params = np_ref.init_params(ic, D, L, seed=-5)
+    batch = synthetic_batch(ic, B, S, seed=2, ragged=True)
+    masks = {k: torch.rand(B, S, generator=g) < 0.3 for k in loss_key_names(ic)}
+    state = torch_ref.TrainState(params, l2=None, clipnorm=None, dtype=torch.float64)
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    info, grads = torch_ref.loss_and_grads(state, ic, b64, b64, masks, L, maxlen=S)
+    model = Model(ic, num_blocks=L, latent_dim=D, dropout=0.0, l2=None, dtype="bf16", device="cuda:0")
+    model.store.load_state_dict(params)
+    model.store.refresh_shadow()
+    dev = {k: v.to("cuda:0") for k, v in batch.items()}
+    dmasks = {k: v.to("cuda:0") for k, v in masks.items()}
+    keys = build_loss_keys(ic, model.layout.head_cols, dev, dmasks)
+    loss, sums, outputs = model.forward_loss(dev, keys, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    want, got = float(info["data_loss"]), float(loss)
+    assert abs(got - want) < 2e-3 * max(1.0, abs(want)), (got, want)          # bf16 operands, f32 accumulation
+    gd = model.store.grads_state_dict()
+    for name in ("blocks/seq2seq_0/mlp/dense_0/kernel", "blocks/seq2seq_1/attn/combine_heads/kernel"):
+        a, b = gd[name].double().flatten(), grads[name].flatten()
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        assert cos > 0.995, (name, cos)
+    print("smoke ok (bf16, d_model 256): loss %.4f (oracle %.4f, rel %.1e)" % (got, want, abs(got - want) / abs(want)))
