@@ -509,6 +509,273 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16(const bf16_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Attention backward, single pass (round 3), head width 32, S <= 128.
+//
+// attn_bwd_bf16 above evaluates every score twice (once per orientation) and runs load -> compute -> store in sequence
+// inside each workgroup: measured at the timed shape 16 us of staging + 25 us of compute + 12 us of stores with little
+// overlap (49 us stand-alone, 57 us in the step, for 129 MB).  This kernel:
+//   * is PERSISTENT: 2 workgroups per CU, each walks a contiguous run of (document, head) items; the Q / dO slices of
+//     item i + 1 stream into the second LDS buffer and its K / V slices into theirs (free as soon as every wave holds its
+//     K / V fragments in registers) by LDS-DMA (buffer_load ... lds, 16 B per lane, no registers) while item i is
+//     computed, and the stores of item i drain under item i + 1;
+//   * evaluates every score ONCE, in the orientation whose accumulator layout has lane = key (S = Q K^T as
+//     D[m = query][n = key]): wave w owns keys 32 w .. + 31 and walks the four 32-query blocks; P and dS feed the
+//     dV / dK products straight from registers (B operands);
+//   * dQ: every wave drops its dS tile (bf16) into a shared [128 keys][32 queries] LDS image (two in rotation: one
+//     barrier per query block), and wave (dt, qt) = (w & 1, w >> 1) computes the 16 x 16 tile dQ^T[d][q] over ALL keys
+//     from transposing reads of that image -- no partial sums, no reduction, 16 accumulator registers;
+//   * dK / dV / dQ leave through LDS as 64-byte row pieces (16 B per lane);
+//   * LDS images are unpadded (64-byte rows: what LDS-DMA writes) with XOR-swizzled 16-byte slots (8-byte pieces in
+//     the dS image) chosen so that the b128 fragment reads, the transposing reads and the 8-byte writes are all
+//     bank-conflict-free (MI355X_MICROARCH.md, LDS lane groups).
+// Rows >= S of an image are zero: their loads are sent out of the buffer's range (the DMA writes zeros).
+namespace sp {
+
+constexpr int ROWB = 64;                       // bytes per image row (32 bf16)
+constexpr int IMG = 128 * ROWB;                // one matrix: 8 KB
+constexpr int QD_OFF = 0;                      // [2] x (Q | dO)
+constexpr int K_OFF = 4 * IMG, V_OFF = 5 * IMG;
+constexpr int DS_OFF = 6 * IMG;                // [2] x dS image [128 keys][32 q]
+constexpr int LSD_OFF = 8 * IMG;               // Ls[128] f32, Dl[128] f32
+constexpr int LDS_BYTES = LSD_OFF + 1024;      // 66 560 B: two workgroups per CU
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }      // 16-byte slot XOR of the Q/K/V/dO images
+// 8-byte piece XOR of the dS image: bijective in (r3, r2, r1) for the writes, bit 2 = r2 for the transposing reads
+__device__ __forceinline__ int hsw(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
+
+__device__ __forceinline__ bf16x8 fragk(const unsigned char* img, int row, int lg) {
+  return *reinterpret_cast<const bf16x8*>(img + row * ROWB + ((lg ^ swz(row)) << 4));
+}
+// for column c0 + li: the rows {kb + 4 lg + j} and {kb + 16 + 4 lg + j}, j = 0..3 (kb a multiple of 32)
+__device__ __forceinline__ bf16x8 fragtr(const unsigned char* img, int kb, int c0, int li, int lg) {
+  const int row = kb + 4 * lg + (li >> 2);
+  const int P = (c0 >> 2) + (li & 3);
+  const unsigned char* ptr = img + row * ROWB + ((((P >> 1) ^ swz(row)) << 4) | ((P & 1) << 3));
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * ROWB));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// the same out of a 32-row block of the dS image (8-byte piece swizzle)
+__device__ __forceinline__ bf16x8 scrtr(const unsigned char* blk, int c0, int li, int lg) {
+  const int row = 4 * lg + (li >> 2);
+  const int P = (c0 >> 2) + (li & 3);
+  const unsigned char* ptr = blk + row * ROWB + ((P ^ hsw(row)) << 3);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * ROWB));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+__global__ __launch_bounds__(256, 2) void attn_bwd1_hd32(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
+                                                         const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                         int B, int S, int H, float scale, int items, int ipw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * 32, D3 = 3 * D;
+  const float c2 = scale * LOG2E;
+  const unsigned int qkv_bytes = (unsigned int)B * (unsigned int)S * (unsigned int)D3 * 2u;
+  const unsigned int o_bytes = (unsigned int)B * (unsigned int)S * (unsigned int)D * 2u;
+  const __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qkv), 0, qkv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dout), 0, o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(out), 0, o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dq = __builtin_amdgcn_make_buffer_rsrc(dqkv, 0, qkv_bytes, 0x00020000);
+  constexpr unsigned int OOB = 0xFFFFFFF0u;
+  const int item0 = xcd_remap(blockIdx.x, gridDim.x) * ipw;
+  const int nit = min(ipw, items - item0);
+  if (nit <= 0) return;
+
+  // wave w stages matrix w of an item (0 Q, 1 K, 2 V from qkv; 3 dO): 8 instructions of 16 rows x 64 B
+  auto issue_dma = [&](int item, int c) {
+    const int b = item / H, h = item - b * H;
+    unsigned char* dst = smem + (wave == 0 ? QD_OFF + c * 2 * IMG : wave == 1 ? K_OFF : wave == 2 ? V_OFF : QD_OFF + c * 2 * IMG + IMG);
+    const unsigned int stride = wave < 3 ? D3 * 2 : D * 2;
+    const unsigned int colb = wave < 3 ? (wave * D + h * 32) * 2 : h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 16 * i + (lane >> 2);
+      const unsigned int voff = row < S ? (unsigned int)(b * S + row) * stride + colb + (((lane & 3) ^ swz(row)) << 4) : OOB;
+      if (wave < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, (lds_u8*)(dst + i * 1024), 16, voff, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, (lds_u8*)(dst + i * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+  // the O row piece (32 B) of thread (row = tid >> 1, half = tid & 1) and the lse of row tid (< 128) for the delta / Ls prologue
+  u32x4 o0, o1;
+  float lse_r;
+  auto issue_olse = [&](int item) {
+    const int b = item / H, h = item - b * H;
+    const int row = tid >> 1;
+    const unsigned int voff = row < S ? (unsigned int)(b * S + row) * (D * 2) + h * 64 + (tid & 1) * 32 : OOB;
+    o0 = __builtin_amdgcn_raw_buffer_load_b128(rs_o, voff, 0, 0);
+    o1 = __builtin_amdgcn_raw_buffer_load_b128(rs_o, voff + 16, 0, 0);
+    lse_r = (tid < S && tid < 128) ? lse[((long long)b * H + h) * S + tid] : 0.f;
+  };
+  issue_dma(item0, 0);
+  issue_olse(item0);
+
+  const int k0 = 32 * wave;
+  const int dt_w = wave & 1, qt_w = wave >> 1;       // this wave's tile of every query block's dQ^T
+  float* const Ls = reinterpret_cast<float*>(smem + LSD_OFF);
+  float* const Dl = Ls + 128;
+  unsigned char* const Ks = smem + K_OFF;
+  unsigned char* const Vs = smem + V_OFF;
+
+  for (int it = 0; it < nit; ++it) {
+    const int c = it & 1;
+    const int item = item0 + it;
+    const int b = item / H, h = item - b * H;
+    unsigned char* const Qs = smem + QD_OFF + c * 2 * IMG;
+    unsigned char* const dOs = Qs + IMG;
+    // ---- (A) this item's images have landed (memory operations retire in order: everything but the six result stores
+    // of the previous item, which are younger than the loads); delta = rowsum(dO * O), Ls = lse * log2(e)
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __syncthreads();
+    {
+      const int row = tid >> 1, hf = tid & 1;
+      const u32x4 d0 = *reinterpret_cast<const u32x4*>(dOs + row * ROWB + (((2 * hf) ^ swz(row)) << 4));
+      const u32x4 d1 = *reinterpret_cast<const u32x4*>(dOs + row * ROWB + (((2 * hf + 1) ^ swz(row)) << 4));
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part += bf16_to_f32((bf16_t)(d0[e] & 0xffff)) * bf16_to_f32((bf16_t)(o0[e] & 0xffff));
+        part += bf16_to_f32((bf16_t)(d0[e] >> 16)) * bf16_to_f32((bf16_t)(o0[e] >> 16));
+        part += bf16_to_f32((bf16_t)(d1[e] & 0xffff)) * bf16_to_f32((bf16_t)(o1[e] & 0xffff));
+        part += bf16_to_f32((bf16_t)(d1[e] >> 16)) * bf16_to_f32((bf16_t)(o1[e] >> 16));
+      }
+      part += __shfl_xor(part, 1, 64);
+      if (hf == 0) Dl[row] = part;
+      if (tid < 128) Ls[tid] = lse_r * LOG2E;
+    }
+    // this wave's K / V fragments: keys k0 .. + 31 as B operands, and K^T (d tile dt_w) of EVERY key block for dQ
+    const int nv = nvalid[b];
+    bf16x8 bk[2], bv[2], kT[4];
+    float madd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = k0 + 16 * t + li;
+      bk[t] = fragk(Ks, j, lg);
+      bv[t] = fragk(Vs, j, lg);
+      madd[t] = j < S ? (j < nv ? 0.f : -1e9f * LOG2E) : -INFINITY;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) kT[kb] = fragtr(Ks, 32 * kb, 16 * dt_w, li, lg);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // K / V reads done before anyone refills those images
+    __syncthreads();
+    // ---- (B) next item on its way: Q / dO into the other buffer, K / V into theirs (every wave holds its fragments)
+    if (it + 1 < nit) {
+      issue_dma(item + 1, c ^ 1);
+      issue_olse(item + 1);
+    }
+    // ---- (C)
+    f32x4 dk[2][2], dv[2][2], dq[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) { dk[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      unsigned char* const dsi = smem + DS_OFF + (qb & 1) * IMG;
+      f32x4 pp[2][2], ds[2][2];     // [query tile][key tile]
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = qb * 32 + qt * 16;
+        const bf16x8 aq = fragk(Qs, q + li, lg), ado = fragk(dOs, q + li, lg);
+        const f32x4 Lr = *reinterpret_cast<const f32x4*>(Ls + q + 4 * lg);
+        const f32x4 Dr = *reinterpret_cast<const f32x4*>(Dl + q + 4 * lg);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bk[t], z, 0, 0, 0);
+          const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado, bv[t], z, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, madd[t]) - Lr[r]);
+            pp[qt][t][r] = p;
+            ds[qt][t][r] = p * (dpacc[r] - Dr[r]);
+          }
+          // dS tile -> image [key k0 + 16 t + li][query 16 qt + 4 lg .. + 3]
+          const int row = k0 + 16 * t + li;
+          const u32x2 pk = {pack_bf16x2(ds[qt][t][0], ds[qt][t][1]), pack_bf16x2(ds[qt][t][2], ds[qt][t][3])};
+          *reinterpret_cast<u32x2*>(dsi + row * ROWB + (((4 * qt + lg) ^ hsw(row)) << 3)) = pk;
+        }
+      }
+      const bf16x8 doT0 = fragtr(dOs, qb * 32, 0, li, lg), doT1 = fragtr(dOs, qb * 32, 16, li, lg);
+      const bf16x8 qT0 = fragtr(Qs, qb * 32, 0, li, lg), qT1 = fragtr(Qs, qb * 32, 16, li, lg);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 bp = pack_p(pp[0][t], pp[1][t]);
+        const bf16x8 bds = pack_p(ds[0][t], ds[1][t]);
+        dv[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT0, bp, dv[t][0], 0, 0, 0);
+        dv[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT1, bp, dv[t][1], 0, 0, 0);
+        dk[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT0, bds, dk[t][0], 0, 0, 0);
+        dk[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT1, bds, dk[t][1], 0, 0, 0);
+      }
+      // every wave's dS tile of this query block is in the image (the image of block qb - 2 was last read before the
+      // barrier of block qb - 1): dQ^T tile (dt_w, qt_w) over all 128 keys
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[kb], scrtr(dsi + kb * 2048, 16 * qt_w, li, lg), acc, 0, 0, 0);
+      dq[qb] = acc;
+    }
+    // ---- dK, dV: through this wave's 32 rows of image 0 (last read before the barrier of query block 3) into 64-byte
+    // row pieces (16 B per lane)
+    const unsigned int rowbase = (unsigned int)(b * S) * (D3 * 2) + h * 64;
+    unsigned char* const scr = smem + DS_OFF + wave * 2048;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {        // 0: dK (scaled), 1: dV
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f32x4 v = m == 0 ? dk[t][dt] * scale : dv[t][dt];
+          const int row = 16 * t + li;
+          const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(scr + row * ROWB + (((4 * dt + lg) ^ hsw(row)) << 3)) = pk;
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + (lane >> 2), s4 = lane & 3;
+        const u32x2 a = *reinterpret_cast<const u32x2*>(scr + row * ROWB + (((2 * s4) ^ hsw(row)) << 3));
+        const u32x2 bb = *reinterpret_cast<const u32x2*>(scr + row * ROWB + (((2 * s4 + 1) ^ hsw(row)) << 3));
+        const int j = k0 + row;
+        const unsigned int voff = j < S ? rowbase + (unsigned int)j * (D3 * 2) + (m + 1) * D * 2 + s4 * 16 : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){a[0], a[1], bb[0], bb[1]}, rs_dq, voff, 0, 0);
+      }
+    }
+    // ---- dQ: tiles -> image 1 as [query][d] rows (every wave is past its reads of image 1), then 64-byte row pieces
+    __syncthreads();
+    {
+      unsigned char* const dqi = smem + DS_OFF + IMG;
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        const int row = 32 * qb + 16 * qt_w + li;
+        const f32x4 v = dq[qb] * scale;
+        const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(dqi + row * ROWB + (((4 * dt_w + lg) ^ hsw(row)) << 3)) = pk;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = k0 + 16 * i + (lane >> 2), s4 = lane & 3;
+        const u32x2 a = *reinterpret_cast<const u32x2*>(dqi + row * ROWB + (((2 * s4) ^ hsw(row)) << 3));
+        const u32x2 bb = *reinterpret_cast<const u32x2*>(dqi + row * ROWB + (((2 * s4 + 1) ^ hsw(row)) << 3));
+        const unsigned int voff = row < S ? rowbase + (unsigned int)row * (D3 * 2) + s4 * 16 : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){a[0], a[1], bb[0], bb[1]}, rs_dq, voff, 0, 0);
+      }
+    }
+  }
+}
+
+}  // namespace sp
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return MFP_OK;
@@ -572,6 +839,26 @@ int bwd_hd(const void* qkv, const int* nvalid, const void* out, const void* dout
     hipLaunchKernelGGL(attn_bwd_dkv_f32<HD>, grid, block, lds2, st, (const float*)qkv, nvalid, (const float*)out,
                        (const float*)dout, lse, (float*)dqkv, S, H, scale);
   } else {
+    static const bool single_pass = !(getenv("MFP_ATTN_BWD_SINGLE") && atoi(getenv("MFP_ATTN_BWD_SINGLE")) == 0);   // A/B switch
+    if (HD == 32 && S <= 128 && single_pass && (long long)B * S * H * 32 * 3 * 2 < 0xFFFFFF00LL) {
+      // persistent single-pass kernel: two workgroups per CU, each a contiguous run of (document, head) items
+      static int ncu_dev[MFP_MAX_DEVICES] = {};
+      int& ncu = ncu_dev[mfp_device_slot()];
+      if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) ncu = 256;
+        else ncu = prop.multiProcessorCount;
+      }
+      const int items = B * H;
+      const int ipw = (items + 2 * ncu - 1) / (2 * ncu);
+      const int nwg = (items + ipw - 1) / ipw;
+      if (int rc = set_lds(sp::attn_bwd1_hd32, sp::LDS_BYTES)) return rc;
+      hipLaunchKernelGGL(sp::attn_bwd1_hd32, dim3(nwg), dim3(256), sp::LDS_BYTES, st, (const bf16_t*)qkv, nvalid, (const bf16_t*)out,
+                         (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, S, H, scale, items, ipw);
+      MFP_CHECK_LAUNCH();
+      return MFP_OK;
+    }
     constexpr int LDH = (HD < 32 ? 32 : HD) + 8;
     const int SP = (S + 31) & ~31;
     size_t lds = (size_t)4 * SP * LDH * sizeof(bf16_t) + (size_t)3 * SP * sizeof(float);

@@ -259,6 +259,10 @@ __global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p)
     const unsigned int ticket = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == (unsigned int)(p.splitk - 1);
     if (last) {
+      // Hand-off form (MI355X_MICROARCH.md, "Valid forms"): producers store the slabs write-through (sc1) and drain
+      // them (vmcnt(0)) before a relaxed agent-scope ticket; the consumer does ONE agent acquire (buffer_inv sc1:
+      // invalidates this CU's whole L1, for every wave of the workgroup) followed by the workgroup barrier below,
+      // then plain loads.  gfx950-specific: the library is built for gfx950 only (Makefile ARCH).
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
     }

@@ -578,9 +578,10 @@ static int loss_fwd_bwd_impl(const float* logits, void* dlogits, int32_t ld, con
     for (int r = 0; r < rg.n; ++r)
       if (rg.beg[r] % 8 != 0 || rg.len[r] % 8 != 0) rg.vec = 0;
     rg.width = (rg.width + 3) / 4 * 4 + 4;   // 16-byte rows; +4 floats: 16-lane groups of different rows hit different banks
-    const int ce_tok = (size_t)32 * rg.width * sizeof(float) <= 64 * 1024 ? 32 : 16;
+    // (the kernel also has ~4 KB of static LDS -- active / isact / ylabel / red -- inside the same 64 KB)
+    const int ce_tok = (size_t)32 * rg.width * sizeof(float) + 4096 <= 64 * 1024 ? 32 : 16;
     const size_t lds = (size_t)ce_tok * rg.width * sizeof(float);
-    MFP_CHECK_ARG(lds <= 64 * 1024);
+    MFP_CHECK_ARG(lds + 4096 <= 64 * 1024);
     rg.nitem = 0;
     for (int i = 0; i < cat.n; ++i) {
       for (int f = 0; f < cat.k[i].n_feat; ++f) {

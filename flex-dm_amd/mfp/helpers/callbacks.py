@@ -59,19 +59,34 @@ class ProfileStep:
         except Exception as exc:   # e.g. an external profiler already owns the tracer
             logger.warning("torch.profiler unavailable (%s); roctx range only", exc)
             self._prof = None
-        torch.cuda.nvtx.range_push("mfp_train_step_%d" % self.profile_batch)   # roctxRangePush on ROCm
+        try:
+            torch.cuda.nvtx.range_push("mfp_train_step_%d" % self.profile_batch)   # roctxRangePush on ROCm
+            self._range = True
+        except Exception as exc:   # a build without roctx: the torch.profiler trace alone
+            logger.warning("roctx range unavailable (%s)", exc)
+            self._range = False
 
     def on_train_batch_end(self, step: int):
         if self.done or step + 1 != self.profile_batch:
             return
         import torch
         torch.cuda.synchronize()
-        torch.cuda.nvtx.range_pop()
         self.done = True
+        if getattr(self, "_range", False):
+            try:
+                torch.cuda.nvtx.range_pop()
+            except Exception as exc:
+                logger.warning("roctx range_pop failed (%s)", exc)
         if self._prof is None:
             return
+        prof, self._prof = self._prof, None
         try:
-            self._prof.__exit__(None, None, None)
+            prof.__exit__(None, None, None)
+        except Exception as exc:
+            logger.warning("could not stop the profiler: %s", exc)
+            return
+        self._prof = prof
+        try:
             base = os.path.join(self.log_dir, "profile_step%d" % self.profile_batch)
             self._prof.export_chrome_trace(base + ".trace.json")
             with open(base + ".kernels.txt", "w") as f:

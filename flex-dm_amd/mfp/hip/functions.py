@@ -31,6 +31,13 @@ LN_FUSE = os.environ.get("MFP_LN_FUSE", "0") == "1"
 # input-gradient products of the same half as one launch (csrc/block_fused.hip); 0 = ln_fwd + two products,
 # two dgrad products (A/B switch)
 MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
+FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
+
+
+def _fused_ok(ctx, D) -> bool:
+    """One predicate for every activation-stationary kernel of csrc/block_fused.hip (bf16, d_model 256,
+    token count inside the kernels' 32-bit row offsets); otherwise the tiled / weight-stationary path runs."""
+    return MLP_FUSE and ctx.cdt == torch.bfloat16 and D == 256 and ctx.T <= FUSE_MAX_T
 # bf16 train step, opt-in (MFP_SPARSE_HEADS=1): the numerical (512-wide regression) heads and their loss / gradients
 # run on the COMPACTED list of tokens that carry a loss for that attribute (~15 % under masked-field prediction;
 # device-side count, static launch shapes).  It removes ~470 MB of logits / d(logits) traffic per step but trades
@@ -140,7 +147,7 @@ def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
             ctx.onehot = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
         ctx.on_side(build, idx_all, which=2)
     h = ops.embed_pool_fwd(idx_all, st.rowoff, st.tables())
-    if (MLP_FUSE and ctx.cdt == torch.bfloat16 and D == 256 and len(L.num_keys) == 2 and not st.fp8
+    if (_fused_ok(ctx, D) and len(L.num_keys) == 2 and not st.fp8
             and all(x.shape[1] == 512 and x.dtype == torch.bfloat16 for x in xs)):
         # both numerical-attribute Dense layers in one activation-stationary launch (csrc/block_fused.hip)
         return ops.encoder_dense2(xs, [st.cw("encoder/input_%s/kernel" % k) for k in L.num_keys],
@@ -155,7 +162,9 @@ def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
 def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     st, L = ctx.store, ctx.store.layout
     T, D = ctx.T, L.D
-    onehot = ctx.cdt == torch.bfloat16   # table gradient as a wgrad GEMM (bf16 path); f32: exact scatter
+    # table gradient as a wgrad GEMM (bf16 path; the one-hot kernel counts in LDS words: <= 1024 padded table rows);
+    # f32 and larger vocabularies: exact scatter
+    onehot = ctx.cdt == torch.bfloat16 and L.table_rows_pad <= 1024
     if L.num_keys or onehot:
         dh_c = ctx.dh_c if (ctx.dh_c is not None and ctx.dh_c.shape == dh.shape) else ctx.to_cdt(dh)
         ctx.dh_c = None
@@ -326,7 +335,7 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x = x.contiguous()
-        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and not st.fp8:      # LN1 + Q|K|V in one launch
+        if _fused_ok(ctx, D) and not st.fp8:      # LN1 + Q|K|V in one launch
             qkv, y1, mean1, rstd1 = ops.qkv_fused_fwd(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
                                                       st.cw(p + "attn/dense_query/kernel", rows=3 * D),
                                                       st.span(st.w, p + "attn/dense_query/bias", 3 * D))
@@ -339,7 +348,7 @@ class BlockFn(torch.autograd.Function):
         x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
                       bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
                       dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
-        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and not st.fp8:
+        if _fused_ok(ctx, D) and not st.fp8:
             x2, y2, mean2, rstd2, h = ops.mlp_fused_fwd(
                 x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"), st.cw(p + "mlp/dense_0/kernel"),
                 st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"), st.weight(p + "mlp/dense_1/bias"),
@@ -373,7 +382,7 @@ class BlockFn(torch.autograd.Function):
             d_o2 = ops.dropout_bwd(dx2, cdt, st.grad(p + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * i + 2, ctx.step_ptr)
         wt = st.cwt(p + "mlp/dense_1/kernel")     # [2D][D]: dgrad as a k-major product when kept
         wt0 = st.cwt(p + "mlp/dense_0/kernel")    # [D][2D]
-        fused_bwd = MLP_FUSE and cdt == torch.bfloat16 and D == 256 and wt is not None and wt0 is not None
+        fused_bwd = _fused_ok(ctx, D) and wt is not None and wt0 is not None
         if fused_bwd:      # both input-gradient products of the half in one launch (csrc/block_fused.hip)
             dh, dy2 = ops.mlp_fused_bwd(d_o2, h, wt, wt0)
         else:
@@ -399,7 +408,7 @@ class BlockFn(torch.autograd.Function):
                                             ctx.step_ptr), jobs=ctx.ln_jobs)
         # ---- attention: x1 = x + drop(a Wo + bo)
         wt = st.cwt(p + "attn/combine_heads/kernel")
-        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and wt is not None:
+        if _fused_ok(ctx, D) and wt is not None:
             da = ops.dgrad_d256(d_o1, wt)      # activation-stationary (csrc/block_fused.hip)
         else:
             da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True,
@@ -425,7 +434,7 @@ class BlockFn(torch.autograd.Function):
         else:
             ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
         wt = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
-        if MLP_FUSE and cdt == torch.bfloat16 and D == 256 and wt is not None:
+        if _fused_ok(ctx, D) and wt is not None:
             dy1 = ops.dgrad_qkv(dqkv, wt)       # activation-stationary (csrc/block_fused.hip)
         else:
             dy1 = ops.gemm(dqkv, wt if wt is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
