@@ -42,6 +42,7 @@ struct MlpParams {
   unsigned short* y2; float* mean; float* rstd;   // saved LN output / statistics
   unsigned short* h;                              // [T][512] bf16
   float* x2;                                      // [T][256] f32
+  unsigned short* x2c;                            // [T][256] bf16 copy of x2 (the decoder heads' operand) or nullptr
   int T; float eps;
   float dropout_p; unsigned long long seed, offset; const int* step_ptr;
 #ifdef MFP_GEMM_TRACE
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpParams p) {
   const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(p.x2, 0, xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, xbytes / 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, hbytes, 0x00020000);
+  // (no copy wanted: a zero-sized buffer -- the stores are issued all the same, so the counted waits do not depend on it)
+  const __amdgpu_buffer_rsrc_t rs_x2c = __builtin_amdgcn_make_buffer_rsrc(p.x2c ? p.x2c : p.y2, 0, p.x2c ? xbytes / 2 : 0u, 0x00020000);
 
   // weight piece i of a chunk (1 KB per wave instruction): W1 chunks are 64 rows x 512 B (2 rows per piece), W2
   // chunks 128 rows x 256 B out of 1 KB rows (4 rows per piece); the source column slot is the destination
@@ -292,6 +295,8 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpParams p) {
             for (int r = 0; r < 4; ++r) o[r] = res[nt][rt][r] + (keep[r] ? (acc2[j * 4 + nt][rt][r] + bb[r]) * inv_keep : 0.f);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_x2,
                                                    (unsigned int)row * (MLP_D * 4) + (nh * 4 * 16 + 4 * g) * 4 + (j * 8 + nt) * 64, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_x2c,
+                                                  (unsigned int)row * (MLP_D * 2) + (nh * 4 * 16 + 4 * g) * 2 + (j * 8 + nt) * 32, 0, 0);
           }
         }
       }
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpParams p) {
     // after the barrier chunk c's buffer is free again
     {
       constexpr int st_prev = (c & 3) == 2 ? 4 : 0;                       // h stores of the previous chunk's tail
-      constexpr int st_this = c == 0 ? 10 : c == 14 ? 16 : 0;             // prologue stores (chunk 1 landed long ago); residual loads + x2 stores
+      constexpr int st_this = c == 0 ? 10 : c == 14 ? 24 : 0;             // prologue stores (chunk 1 landed long ago); residual loads + x2 stores (f32 + bf16 copy)
       constexpr int allowed = st_prev + (c + 2 < MLP_CHUNKS ? 4 : 0) + st_this;
       if (c + 1 < MLP_CHUNKS) {
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
@@ -1017,6 +1022,10 @@ struct DgradRowsParams {
   const unsigned short* Wt;    // [256][ldw] bf16, zero beyond the real columns
   float* C;                    // [T][256] f32
   int T, KQ, lda, ldw;         // lda, ldw in ELEMENTS; KQ = 128-column pieces (ldw >= 128 KQ)
+  // optional second result: the dropout-masked, 1 / keep-scaled bf16 copy of C -- what the backward pass of the Dense
+  // in front of a Dropout consumes (mfp_dropout_bwd fused; same mask as the forward epilogue: seed, offset, step)
+  unsigned short* Cd;
+  float dropout_p; unsigned long long seed, offset; const int* step_ptr;
 };
 
 __global__ __launch_bounds__(512) void dgrad_rows_kernel(DgradRowsParams p) {
@@ -1027,7 +1036,14 @@ __global__ __launch_bounds__(512) void dgrad_rows_kernel(DgradRowsParams p) {
   const int rp = wave & 3, nh = wave >> 2;
   const int row0 = blockIdx.x * MLP_ROWS;
   const int lda2 = p.lda * 2, ldw2 = p.ldw * 2, KQ = p.KQ;
+  // (read first: this load must not sit between the counted waits of the chunk loop)
+  const int step_now = (p.Cd && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wt), 0, (unsigned int)(MLP_D * ldw2), 0x00020000);
+  // (no masked copy wanted: a zero-sized buffer; its stores are issued all the same -- the counted waits stay fixed)
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(p.Cd ? (void*)p.Cd : (void*)p.C, 0, p.Cd ? (unsigned int)p.T * (MLP_D * 2) : 0u, 0x00020000);
+  const float inv_keep = 1.0f / (1.0f - p.dropout_p);
+  const unsigned int dthr = drop_thr16(p.dropout_p);
+  const unsigned int dkey = drop_key(p.seed, p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, (unsigned int)p.T * (unsigned int)lda2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (unsigned int)p.T * (MLP_D * 4), 0x00020000);
   const int wv = __builtin_amdgcn_readfirstlane(wave), wl = wv & 3;
@@ -1099,16 +1115,23 @@ __global__ __launch_bounds__(512) void dgrad_rows_kernel(DgradRowsParams p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc2[j * 4 + nt][rt]), rs_c,
-                                                   (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (MLP_D * 4) + ((j * 8 + nh * 4 + nt) * 16 + 4 * g) * 4, 0, 0);
+          for (int rt = 0; rt < 2; ++rt) {
+            const int row = row0 + rp * 32 + rt * 16 + li, n = (j * 8 + nh * 4 + nt) * 16 + 4 * g;
+            const f32x4 v = acc2[j * 4 + nt][rt];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_c, (unsigned int)row * (MLP_D * 4) + n * 4, 0, 0);
+            bool keep[4] = {true, true, true, true};
+            if (p.dropout_p > 0.f) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
+            const u32x2 pk = {pack_bf16x2(keep[0] ? v[0] * inv_keep : 0.f, keep[1] ? v[1] * inv_keep : 0.f),
+                              pack_bf16x2(keep[2] ? v[2] * inv_keep : 0.f, keep[3] ? v[3] * inv_keep : 0.f)};
+            __builtin_amdgcn_raw_buffer_store_b64(pk, rs_d, (unsigned int)row * (MLP_D * 2) + n * 2, 0, 0);
+          }
       }
       if (c + 1 < nchunks) {
         // weight waves: chunk c + 1 landed when at most the 8 loads of chunk c + 2 (and the 8 result stores of the
         // second to last chunk) are outstanding; activation waves: piece kq + 1 is due at the end of (kq, 1)
         if (wv < 4) {
           if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");       // (here the 8 are the result stores)
+          else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");      // (here: the 8 + 8 result stores of this chunk)
         } else if (j == 1 && kq + 1 < KQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1126,18 +1149,18 @@ extern "C" void mfp_mlp_trace_buffer(void* ptr) { g_mlp_trace = reinterpret_cast
 
 extern "C" int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const float* beta, const void* W1, const float* b1,
                                  const void* W2, const float* b2, void* y2, float* mean, float* rstd, void* h, float* x2,
-                                 int32_t T, int32_t D, float eps, float dropout_p, uint64_t seed, uint64_t offset,
+                                 void* x2c, int32_t T, int32_t D, float eps, float dropout_p, uint64_t seed, uint64_t offset,
                                  const int32_t* step_ptr, mfp_stream_t stream) {
   MFP_CHECK_ARG(x1 && gamma && beta && W1 && b1 && W2 && b2 && y2 && mean && rstd && h && x2);
   MFP_CHECK_ARG(T > 0 && T <= (1 << 21) && D == MLP_D && eps > 0.f && dropout_p >= 0.f && dropout_p < 1.f);
   MFP_CHECK_ARG(((uintptr_t)x1 % 16) == 0 && ((uintptr_t)W1 % 16) == 0 && ((uintptr_t)W2 % 16) == 0 &&
-                ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)x2 % 16) == 0);
+                ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)x2 % 16) == 0 && ((uintptr_t)x2c % 16) == 0);
   MlpParams p;
   p.x1 = x1; p.gamma = gamma; p.beta = beta;
   p.W1 = reinterpret_cast<const unsigned short*>(W1); p.b1 = b1;
   p.W2 = reinterpret_cast<const unsigned short*>(W2); p.b2 = b2;
   p.y2 = reinterpret_cast<unsigned short*>(y2); p.mean = mean; p.rstd = rstd;
-  p.h = reinterpret_cast<unsigned short*>(h); p.x2 = x2;
+  p.h = reinterpret_cast<unsigned short*>(h); p.x2 = x2; p.x2c = reinterpret_cast<unsigned short*>(x2c);
   p.T = T; p.eps = eps; p.dropout_p = dropout_p; p.seed = seed; p.offset = offset; p.step_ptr = step_ptr;
 #ifdef MFP_GEMM_TRACE
   p.trace = g_mlp_trace;
@@ -1289,12 +1312,15 @@ extern "C" int mfp_encoder_dense2(const void* x0, const void* x1, const void* W0
 }
 
 extern "C" int mfp_dgrad_rows(const void* A, int32_t lda, const void* Wt, int32_t ldw, float* C, int32_t T, int32_t D, int32_t K,
+                              void* C_drop, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
                               mfp_stream_t stream) {
   MFP_CHECK_ARG(A && Wt && C && T > 0 && T <= (1 << 19) && D == MLP_D && K > 0 && lda >= K && lda % 8 == 0 && ldw % 128 == 0 && ldw >= K);
-  MFP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)C % 16) == 0);
+  MFP_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)C_drop % 16) == 0);
+  MFP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
   DgradRowsParams p;
   p.A = reinterpret_cast<const unsigned short*>(A); p.Wt = reinterpret_cast<const unsigned short*>(Wt); p.C = C;
   p.T = T; p.KQ = (K + 127) / 128; p.lda = lda; p.ldw = ldw;
+  p.Cd = reinterpret_cast<unsigned short*>(C_drop); p.dropout_p = C_drop ? dropout_p : 0.f; p.seed = seed; p.offset = offset; p.step_ptr = step_ptr;
   constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];

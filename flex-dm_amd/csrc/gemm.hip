@@ -53,7 +53,6 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int kz_xcd;      // 1: 1-D grid, k-chunks grouped per XCD (split-K with splitk % 8 == 0)
   const float* ln_gamma; const float* ln_beta; unsigned short* ln_y; float* ln_mean; float* ln_rstd; float ln_eps;   // MFP_GEMM_LNORM_A
-  const int* m_dev;   // device row count or nullptr: rows >= *m_dev are not computed
 #ifdef MFP_GEMM_TRACE
   unsigned long long* trace;  // [workgroup][16] s_memtime stamps of wave 0
 #endif
@@ -203,7 +202,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmParams p) {
   }
   const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  if (p.m_dev != nullptr && m0 >= *p.m_dev) return;     // row count decided on the device: tiles past it have no work
   const int kbeg = kz * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -492,7 +490,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #include "gemm_ws.h"
 #include "gemm_wg.h"
 #include "gemm_wgg.h"
-#include "gemm_wgg2.h"
 
 int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
   static int ncu_of[MFP_MAX_DEVICES] = {};
@@ -642,7 +639,6 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   if (a->flags & MFP_GEMM_RESIDUAL) MFP_CHECK_ARG(a->residual != nullptr);
   if (a->flags & MFP_GEMM_RELU_BWD) MFP_CHECK_ARG(a->aux != nullptr);
   if (a->flags & MFP_GEMM_ACCUM) MFP_CHECK_ARG(a->out_dtype == MFP_F32);
-  if (a->m_dev != nullptr) MFP_CHECK_ARG(a->a_kmajor == 1 && splitk == 1 && !(a->flags & MFP_GEMM_LNORM_A));
   if (a->flags & MFP_GEMM_DROPOUT) MFP_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f);
   if (a->out_dtype == MFP_BF16) MFP_CHECK_ARG(a->ldc % 8 == 0);
   const bool ws_path = uses_workspace(a);
@@ -666,7 +662,6 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   p.tiles_m = 0; p.tiles_n = 0; p.kz_xcd = 0;  // set per tile configuration in launch_one
   p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_y = reinterpret_cast<unsigned short*>(a->ln_y);
   p.ln_mean = a->ln_mean; p.ln_rstd = a->ln_rstd; p.ln_eps = a->ln_eps;
-  p.m_dev = a->m_dev;
 #ifdef MFP_GEMM_TRACE
   p.trace = g_trace;
 #endif
@@ -706,21 +701,6 @@ int wgg_tiles(const mfp_wgrad_job* jobs, int njobs) {
   for (int i = 0; i < njobs; ++i) t += ((jobs[i].M + 127) / 128) * ((jobs[i].N + 127) / 128);
   return t;
 }
-// second-generation engine (gemm_wgg2.h: 256 x 128 macro tiles, all eight waves multiply and stream), opt-in with
-// MFP_WGG2=1 for every job that does not mask rows: measured SLOWER than gemm_wgg.h (block group 81 vs 72 us
-// stand-alone; see the header), kept for the A/B
-bool wgg2_on(const mfp_wgrad_job* jobs, int njobs) {
-  static const bool on = getenv("MFP_WGG2") != nullptr && getenv("MFP_WGG2")[0] == '1';
-  if (!on) return false;
-  for (int i = 0; i < njobs; ++i)
-    if (jobs[i].rowcode != nullptr) return false;
-  return true;
-}
-int wgg_mtiles(const mfp_wgrad_job* jobs, int njobs) {
-  int t = 0;
-  for (int i = 0; i < njobs; ++i) t += (((jobs[i].M + 127) / 128 + 1) / 2) * ((jobs[i].N + 127) / 128);
-  return t;
-}
 int wgg_ncu() {
   static int ncu_of[MFP_MAX_DEVICES] = {};
   int& ncu = ncu_of[mfp_device_slot()];
@@ -744,8 +724,7 @@ extern "C" int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs, int32_t njob
 // slabs); slices of at least 256 tokens, at most WG_MAX_KCHUNK when a job masks rows (codes in LDS).
 extern "C" int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K) {
   if (jobs == nullptr || njobs < 1 || K < 1) return 8;
-  const bool g2 = wgg2_on(jobs, njobs);
-  const int tiles = g2 ? wgg_mtiles(jobs, njobs) : wgg_tiles(jobs, njobs), ncu = wgg_ncu();
+  const int tiles = wgg_tiles(jobs, njobs), ncu = wgg_ncu();
   bool rowskip = false;
   for (int i = 0; i < njobs; ++i) rowskip |= jobs[i].rowcode != nullptr;
   int best = 8;
@@ -785,7 +764,7 @@ extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t
     WggJob& d = p.job[i];
     d.A = reinterpret_cast<const unsigned short*>(j.A);
     d.B = reinterpret_cast<const unsigned short*>(j.B);
-    d.C = j.C; d.colsum = j.colsum; d.rowcode = j.rowcode; d.k_dev = j.k_dev;
+    d.C = j.C; d.colsum = j.colsum; d.rowcode = j.rowcode;
     d.M = j.M; d.N = j.N; d.lda = j.lda; d.ldb = j.ldb; d.ldc = j.ldc;
     d.tiles_n = (j.N + 127) / 128;
     d.tile0 = tile0; d.pad_ = 0;
@@ -810,24 +789,7 @@ extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t
   p.trace = g_trace;
 #endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int rc;
-  if (wgg2_on(jobs, njobs)) {
-    Wgg2Params pp;
-    pp.base = p;
-    int mt0 = 0;
-    for (int i = 0; i < WGG_MAX_JOBS; ++i) {
-      if (i < njobs) {
-        pp.mtile0[i] = mt0;
-        mt0 += (((jobs[i].M + 127) / 128 + 1) / 2) * ((jobs[i].N + 127) / 128);
-      } else {
-        pp.mtile0[i] = 0x7FFFFFFF;
-      }
-    }
-    pp.nmtiles = mt0;
-    rc = launch_wgg2(pp, st);
-  } else {
-    rc = rowskip ? launch_wgg_t<true>(p, st) : launch_wgg_t<false>(p, st);
-  }
+  const int rc = rowskip ? launch_wgg_t<true>(p, st) : launch_wgg_t<false>(p, st);
   if (rc != MFP_OK) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;

@@ -50,7 +50,6 @@ struct WggJob {
   float* C;                     // f32 [M][ldc]
   float* colsum;                // f32 [M] or nullptr
   const unsigned char* rowcode; // u8 [K] or nullptr: rows of A with a non-zero code count as zero
-  const int* k_dev;             // device or nullptr: this job contracts over min(K, *k_dev) rows
   int M, N, lda, ldb, ldc, tiles_n, tile0, pad_;
 };
 
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p)
   const int bid = tile - jb.tile0;
   const int tm = bid / jb.tiles_n, tn = bid % jb.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int Kj = jb.k_dev != nullptr ? min(p.K, *jb.k_dev) : p.K;     // token count may be decided on the device (compacted rows)
+  const int Kj = p.K;
   const int ktiles = (Kj + BK - 1) / BK;
   const int nk = kz < ktiles ? (ktiles - kz + p.splitk - 1) / p.splitk : 0;      // k-tiles kz, kz + splitk, ...
   const int kend = Kj;

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     s = j % slices;
     g = (j / slices) * 8 + xcd;   // groups % 8 == 0 (host)
   }
-  const int Mrows = p.m_dev != nullptr ? min(p.M, *p.m_dev) : p.M;    // row count may be decided on the device
+  const int Mrows = p.M;
   const int NU = (Mrows + 15) >> 4;
   const int u0 = (int)((long long)NU * g / groups), u1 = (int)((long long)NU * (g + 1) / groups);
   const int row_beg = u0 * 16, row_end = min(Mrows, u1 * 16);

@@ -211,8 +211,7 @@ template <typename TDL, bool VEC>
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, TDL* __restrict__ dpred,
                                                   int ld, LossKeys keys, const int* __restrict__ nvalid,
                                                   float* __restrict__ sums, int T, int S, float inv_B,
-                                                  const int* __restrict__ pred_row, const int* __restrict__ true_row,
-                                                  const int* __restrict__ cidx, const int* __restrict__ ccount) {
+                                                  const int* __restrict__ pred_row, const int* __restrict__ true_row) {
   __shared__ float red[3][4];
   __shared__ float wt[MSE_TOK];
   __shared__ int prow_s[MSE_TOK], trow_s[MSE_TOK];
@@ -221,18 +220,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* target = reinterpret_cast<const float*>(k.target);
   const int t0 = blockIdx.x * MSE_TOK;
-  if (cidx != nullptr) {
-    // compacted rows (mfp_loss_numeric_compact): row i of pred / dpred belongs to token cidx[i], whose weight is
-    // 1 by construction; rows >= *ccount do not exist
-    const int n = *ccount;
-    if (t0 >= n) return;
-    if (threadIdx.x < MSE_TOK) {
-      const int i = t0 + (int)threadIdx.x;
-      prow_s[threadIdx.x] = i;
-      trow_s[threadIdx.x] = i < n ? cidx[i] : 0;
-      wt[threadIdx.x] = i < n ? 1.f : -1.f;
-    }
-  } else if (threadIdx.x < MSE_TOK) {
+  if (threadIdx.x < MSE_TOK) {
     const int t = t0 + (int)threadIdx.x;
     const int tt = (true_row && t < T) ? true_row[t] : t;
     prow_s[threadIdx.x] = (pred_row && t < T) ? pred_row[t] : t;
@@ -308,77 +296,6 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
   if (threadIdx.x < 3) {
     float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
     if (s != 0.f) atomicAdd(&sums[keys.key_slot[blockIdx.y] * 3 + threadIdx.x], s);
-  }
-}
-
-// ------------------------------------------------------------------------- compacted numerical heads
-// Under masked-field prediction only ~15 % of the tokens carry a loss for a given attribute; the 512-wide
-// numerical heads (image / text embedding: 1024 of Crello's 1378 head columns) are therefore evaluated on the
-// COMPACTED list of tokens with a non-zero weight: index list + count on the device (the launch shapes stay
-// static for hipGraph replay; consumers take the count through mfp_gemm_args.m_dev / mfp_wgrad_job.k_dev).
-//
-// idx[0 .. count) = tokens t (ascending) with weight(t) != 0.  One token per thread, 1024 tokens per workgroup;
-// pass 1 leaves the per-workgroup counts, pass 2 re-evaluates the (cheap) weights and writes the list behind the
-// sum of the counts of the workgroups before it.  (A single workgroup walking 32 tokens per thread took 36 us.)
-template <bool WRITE>
-__global__ __launch_bounds__(1024) void compact_tokens_kernel(LossKeys keys, const int* __restrict__ nvalid, int T, int S,
-                                                              int* __restrict__ part, int* __restrict__ idx_all,
-                                                              int* __restrict__ count_all) {
-  __shared__ int wsum[16];
-  const mfp_loss_key k = keys.k[blockIdx.y];
-  const int t = blockIdx.x * 1024 + (int)threadIdx.x;
-  const bool f = t < T && token_weight(k, nvalid, t, t, S) != 0.f;
-  const unsigned long long bal = __ballot(f);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wsum[wave] = __popcll(bal);
-  __syncthreads();
-  int* mypart = part + (long long)blockIdx.y * gridDim.x;
-  if (!WRITE) {
-    if (threadIdx.x == 0) {
-      int s = 0;
-      for (int w = 0; w < 16; ++w) s += wsum[w];
-      mypart[blockIdx.x] = s;
-    }
-    return;
-  }
-  int base = 0;
-  for (int g = 0; g < (int)blockIdx.x; ++g) base += mypart[g];       // <= 64 workgroups (T <= 65536): uniform loads
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  if (f) idx_all[(long long)blockIdx.y * T + base + __popcll(bal & ((1ull << lane) - 1ull))] = t;
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) {
-    int s = 0;
-    for (int w = 0; w < 16; ++w) s += wsum[w];
-    int tot = s;
-    for (int g = 0; g < (int)blockIdx.x; ++g) tot += mypart[g];
-    count_all[blockIdx.y] = tot;
-  }
-}
-
-// dst[i][:] = src[idx[i]][:] for i < *count (rows of `row16` 16-byte pieces), 8 rows per workgroup
-__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
-                                                          const int* __restrict__ idx, const int* __restrict__ count, int row16) {
-  const int n = *count;
-  const int r0 = blockIdx.x * 8;
-  if (r0 >= n) return;
-  for (int e = threadIdx.x; e < 8 * row16; e += 256) {
-    const int r = r0 + e / row16, c = e % row16;
-    if (r < n) dst[(long long)r * row16 + c] = src[(long long)idx[r] * row16 + c];
-  }
-}
-
-// dst[idx[i]][:] += src[i][:] (f32, rows of `row16` float4) for i < *count.  The indices of one list are distinct.
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float4* __restrict__ dst, const float4* __restrict__ src,
-                                                               const int* __restrict__ idx, const int* __restrict__ count, int row16) {
-  const int n = *count;
-  const int r0 = blockIdx.x * 8;
-  if (r0 >= n) return;
-  for (int e = threadIdx.x; e < 8 * row16; e += 256) {
-    const int r = r0 + e / row16, c = e % row16;
-    if (r < n) {
-      float4* d = dst + (long long)idx[r] * row16 + c;
-      const float4 a = *d, b = src[(long long)r * row16 + c];
-      *d = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    }
   }
 }
 
@@ -490,8 +407,8 @@ extern "C" int mfp_loss_fwd_bwd(const float* logits, void* dlogits, int32_t ld, 
 
 static int loss_fwd_bwd_impl(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
                              int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
-                             int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row,
-                             bool skip_numerical, mfp_stream_t stream);
+                             int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row, bool prezeroed,
+                             mfp_stream_t stream);
 
 extern "C" int mfp_loss_fwd_bwd_sorted(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
                                        int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
@@ -500,16 +417,17 @@ extern "C" int mfp_loss_fwd_bwd_sorted(const float* logits, void* dlogits, int32
   return loss_fwd_bwd_impl(logits, dlogits, ld, keys, nkeys, nvalid, sums, B, S, dl_dtype, pred_row, true_row, false, stream);
 }
 
-extern "C" int mfp_loss_fwd_bwd_categorical(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
-                                            int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
-                                            int32_t dl_dtype, mfp_stream_t stream) {
-  return loss_fwd_bwd_impl(logits, dlogits, ld, keys, nkeys, nvalid, sums, B, S, dl_dtype, nullptr, nullptr, true, stream);
+extern "C" int mfp_loss_fwd_bwd_acc(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
+                                    int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
+                                    int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row,
+                                    mfp_stream_t stream) {
+  return loss_fwd_bwd_impl(logits, dlogits, ld, keys, nkeys, nvalid, sums, B, S, dl_dtype, pred_row, true_row, true, stream);
 }
 
 static int loss_fwd_bwd_impl(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys,
                              int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
-                             int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row,
-                             bool skip_numerical, mfp_stream_t stream) {
+                             int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row, bool prezeroed,
+                             mfp_stream_t stream) {
   MFP_CHECK_ARG(logits && keys && nvalid && sums);
   MFP_CHECK_ARG(nkeys > 0 && nkeys <= MFP_MAX_LOSS_KEYS && B > 0 && S > 0 && ld > 0);
   MFP_CHECK_ARG(dl_dtype == MFP_F32 || dl_dtype == MFP_BF16);
@@ -525,8 +443,10 @@ static int loss_fwd_bwd_impl(const float* logits, void* dlogits, int32_t ld, con
       cat.k[cat.n] = keys[i]; cat.key_slot[cat.n] = i; cat.n++;
     }
   }
-  hipLaunchKernelGGL(zero_sums_kernel, dim3(1), dim3(64), 0, st, sums, nkeys * 3);
-  MFP_CHECK_LAUNCH();
+  if (!prezeroed) {      // (mfp_loss_fwd_bwd_acc: the step prologue has zeroed sums)
+    hipLaunchKernelGGL(zero_sums_kernel, dim3(1), dim3(64), 0, st, sums, nkeys * 3);
+    MFP_CHECK_LAUNCH();
+  }
   const float inv_B = 1.0f / (float)B;
   if (cat.n > 0) {
     // Merge the categorical heads' columns into contiguous ranges.  Gaps of < 8 columns between
@@ -602,79 +522,15 @@ static int loss_fwd_bwd_impl(const float* logits, void* dlogits, int32_t ld, con
 #undef CE_LAUNCH
     MFP_CHECK_LAUNCH();
   }
-  if (num.n > 0 && !skip_numerical) {
+  if (num.n > 0) {
     const int bx = (T + MSE_TOK - 1) / MSE_TOK;
     bool vec = ld % 8 == 0;
     for (int i = 0; i < num.n; ++i) vec = vec && num.k[i].col_off % 8 == 0 && num.k[i].n_class % 8 == 0;
-#define MSE_LAUNCH(TT, V) hipLaunchKernelGGL((mse_kernel<TT, V>), dim3(bx, num.n), dim3(256), 0, st, logits, (TT*)dlogits, ld, num, nvalid, sums, T, S, inv_B, pred_row, true_row, nullptr, nullptr)
+#define MSE_LAUNCH(TT, V) hipLaunchKernelGGL((mse_kernel<TT, V>), dim3(bx, num.n), dim3(256), 0, st, logits, (TT*)dlogits, ld, num, nvalid, sums, T, S, inv_B, pred_row, true_row)
     if (dl_dtype == MFP_F32) { if (vec) MSE_LAUNCH(float, true); else MSE_LAUNCH(float, false); }
     else { if (vec) MSE_LAUNCH(unsigned short, true); else MSE_LAUNCH(unsigned short, false); }
 #undef MSE_LAUNCH
     MFP_CHECK_LAUNCH();
   }
-  return MFP_OK;
-}
-
-extern "C" int mfp_compact_tokens(const mfp_loss_key* keys, int32_t nkeys, const int32_t* nvalid, int32_t B, int32_t S,
-                                  int32_t* idx, int32_t* count, mfp_stream_t stream) {
-  MFP_CHECK_ARG(keys && nvalid && idx && count);
-  MFP_CHECK_ARG(nkeys > 0 && nkeys <= MFP_MAX_LOSS_KEYS && B > 0 && S > 0 && (long long)B * S <= 65536);
-  LossKeys lk;
-  lk.n = nkeys;
-  for (int i = 0; i < nkeys; ++i) {
-    MFP_CHECK_ARG(keys[i].mask != nullptr);
-    lk.k[i] = keys[i]; lk.key_slot[i] = i;
-  }
-  const int T = B * S, nwg = (T + 1023) / 1024;
-  // per-workgroup counts: behind the index lists (idx has room for nkeys * T entries; a list is at most T long
-  // and needs the space only after pass 2 has read the counts -- keep them apart anyway: the tail of `count`)
-  int* part = count + nkeys;          // caller allocates count as int32 [nkeys + nkeys * 64]
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(compact_tokens_kernel<false>, dim3(nwg, nkeys), dim3(1024), 0, st, lk, nvalid, T, S, part, idx, count);
-  MFP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(compact_tokens_kernel<true>, dim3(nwg, nkeys), dim3(1024), 0, st, lk, nvalid, T, S, part, idx, count);
-  MFP_CHECK_LAUNCH();
-  return MFP_OK;
-}
-
-extern "C" int mfp_gather_rows(const void* src, void* dst, const int32_t* idx, const int32_t* count, int32_t max_rows,
-                               int32_t row_bytes, mfp_stream_t stream) {
-  MFP_CHECK_ARG(src && dst && idx && count && max_rows > 0 && row_bytes > 0 && row_bytes % 16 == 0);
-  MFP_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((max_rows + 7) / 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const u32x4*>(src), reinterpret_cast<u32x4*>(dst), idx, count, row_bytes / 16);
-  MFP_CHECK_LAUNCH();
-  return MFP_OK;
-}
-
-extern "C" int mfp_scatter_add_rows(float* dst, const float* src, const int32_t* idx, const int32_t* count, int32_t max_rows,
-                                    int32_t row_floats, mfp_stream_t stream) {
-  MFP_CHECK_ARG(src && dst && idx && count && max_rows > 0 && row_floats > 0 && row_floats % 4 == 0);
-  MFP_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0);
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((max_rows + 7) / 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<float4*>(dst), reinterpret_cast<const float4*>(src), idx, count, row_floats / 4);
-  MFP_CHECK_LAUNCH();
-  return MFP_OK;
-}
-
-extern "C" int mfp_loss_numeric_compact(const float* pred, void* dpred, const mfp_loss_key* key, int32_t slot, const int32_t* idx,
-                                        const int32_t* count, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
-                                        int32_t dl_dtype, mfp_stream_t stream) {
-  MFP_CHECK_ARG(pred && key && idx && count && nvalid && sums && slot >= 0 && B > 0 && S > 0);
-  MFP_CHECK_ARG(key->is_numerical && key->target && key->n_class > 0 && key->n_class % 8 == 0);
-  MFP_CHECK_ARG(dl_dtype == MFP_F32 || dl_dtype == MFP_BF16);
-  LossKeys num;
-  num.n = 1; num.k[0] = *key; num.k[0].col_off = 0; num.key_slot[0] = slot;
-  const int T = B * S, ld = key->n_class;
-  const int bx = (T + MSE_TOK - 1) / MSE_TOK;
-  const float inv_B = 1.0f / (float)B;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dl_dtype == MFP_F32)
-    hipLaunchKernelGGL((mse_kernel<float, true>), dim3(bx, 1), dim3(256), 0, st, pred, (float*)dpred, ld, num, nvalid, sums, T, S, inv_B,
-                       nullptr, nullptr, idx, count);
-  else
-    hipLaunchKernelGGL((mse_kernel<unsigned short, true>), dim3(bx, 1), dim3(256), 0, st, pred, (unsigned short*)dpred, ld, num, nvalid, sums,
-                       T, S, inv_B, nullptr, nullptr, idx, count);
-  MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -152,7 +152,47 @@ __global__ void sample_tasks_kernel(TaskProbs tp, int* __restrict__ tasks, int B
   tasks[b] = k;
 }
 
+// The head of a train step in one launch: task ids (as sample_tasks_kernel, same stream), the number of valid
+// positions per document (reference architecture/mask.py: get_seq_mask(length) counts length + 1 elements) and
+// the zeroing of the step's loss accumulators -- three tiny launches of ~4.6 us each otherwise.
+__global__ void step_prologue_kernel(TaskProbs tp, int* __restrict__ tasks, const int* __restrict__ length,
+                                     int* __restrict__ nvalid, int B, unsigned long long seed, unsigned long long offset0,
+                                     const int* __restrict__ step_ptr, float* __restrict__ zero, int nzero) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nzero) zero[b] = 0.f;
+  if (b >= B) return;
+  if (nvalid != nullptr) nvalid[b] = length[b] + 1;
+  const unsigned long long off = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  unsigned int r[4];
+  philox4x32(seed, (unsigned int)b, 0x7A5C7A5Cu, off, r);
+  const float u = u01(r[0]) * tp.cdf[tp.n - 1];
+  int k = 0;
+  while (k < tp.n - 1 && u >= tp.cdf[k]) ++k;
+  tasks[b] = k;
+}
+
 }  // namespace
+
+extern "C" int mfp_step_prologue(const float* probs, int32_t n, int32_t* tasks, const int32_t* length, int32_t* nvalid,
+                                 int32_t B, uint64_t seed, uint64_t offset, const int32_t* step_ptr, float* zero,
+                                 int32_t nzero, mfp_stream_t stream) {
+  MFP_CHECK_ARG(probs && tasks && n > 0 && n <= 16 && B > 0 && nzero >= 0 && (nzero == 0 || zero != nullptr));
+  MFP_CHECK_ARG((nvalid == nullptr) || (length != nullptr));
+  TaskProbs tp;
+  tp.n = n;
+  float c = 0.f;
+  for (int i = 0; i < n; ++i) {
+    MFP_CHECK_ARG(probs[i] >= 0.f);
+    c += probs[i];
+    tp.cdf[i] = c;
+  }
+  MFP_CHECK_ARG(c > 0.f);
+  const int nthr = B > nzero ? B : nzero;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3((nthr + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     tp, tasks, length, nvalid, B, seed, offset, step_ptr, zero, nzero);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
 
 extern "C" int mfp_sample_tasks(const float* probs, int32_t n, int32_t* tasks, int32_t B, uint64_t seed,
                                 uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {

@@ -41,7 +41,7 @@ class GemmArgs(Structure):
         ("in_dtype", c_int32), ("out_dtype", c_int32), ("flags", c_int32), ("splitk", c_int32),
         ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64), ("step_ptr", c_void_p),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_y", c_void_p), ("ln_mean", c_void_p),
-        ("ln_rstd", c_void_p), ("ln_eps", c_float), ("m_dev", c_void_p),
+        ("ln_rstd", c_void_p), ("ln_eps", c_float),
     ]
 
 
@@ -49,7 +49,6 @@ class WgradJob(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("colsum", c_void_p), ("rowcode", c_void_p),
         ("M", c_int32), ("N", c_int32), ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
-        ("k_dev", c_void_p),
     ]
 
 
@@ -92,13 +91,14 @@ SIGNATURES = {
     "mfp_absmax": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "mfp_quantize_fp8": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mfp_gemm_fp8": (c_int32, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p]),
-    "mfp_mlp_fused_fwd": (c_int32, [c_void_p] * 12 + [c_int32, c_int32, c_float, c_float, c_uint64, c_uint64,
+    "mfp_mlp_fused_fwd": (c_int32, [c_void_p] * 13 + [c_int32, c_int32, c_float, c_float, c_uint64, c_uint64,
                                                    c_void_p, c_void_p]),
     "mfp_qkv_fused_fwd": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_float, c_void_p]),
     "mfp_dgrad_d256": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_dgrad_qkv": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_encoder_dense2": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_void_p]),
-    "mfp_dgrad_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mfp_dgrad_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                 c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_mlp_fused_bwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
     "mfp_layernorm_fwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_int32, c_void_p]),
     "mfp_layernorm_bwd": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
@@ -116,13 +116,6 @@ SIGNATURES = {
     "mfp_row_flags": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p]),
     "mfp_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
                                    c_void_p, c_int32, c_int32, c_int32, c_void_p]),
-    "mfp_loss_fwd_bwd_categorical": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
-                                               c_void_p, c_int32, c_int32, c_int32, c_void_p]),
-    "mfp_compact_tokens": (c_int32, [POINTER(LossKey), c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
-    "mfp_gather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "mfp_scatter_add_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "mfp_loss_numeric_compact": (c_int32, [c_void_p, c_void_p, POINTER(LossKey), c_int32, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mfp_loss_fwd_bwd_sorted": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p,
                                           c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "mfp_sort_positions": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_void_p, c_int32, POINTER(c_int32),
@@ -138,6 +131,10 @@ SIGNATURES = {
     "mfp_dropout_bwd": (c_int32, [c_void_p] * 4 + [c_size_t, c_int32, c_int32, c_float, c_uint64,
                                                    c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_colsum": (c_int32, [c_void_p] * 3 + [c_size_t] + [c_int32] * 4 + [c_void_p]),
+    "mfp_step_prologue": (c_int32, [POINTER(c_float), c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_uint64,
+                                    c_void_p, c_void_p, c_int32, c_void_p]),
+    "mfp_loss_fwd_bwd_acc": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p, c_void_p,
+                                       c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "mfp_sample_tasks": (c_int32, [POINTER(c_float), c_int32, c_void_p, c_int32, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_mask_tokens": (c_int32, [POINTER(MaskCol), c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                   c_int32, c_uint64, c_uint64, c_void_p, c_int32, c_void_p]),

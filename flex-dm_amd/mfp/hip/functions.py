@@ -38,13 +38,6 @@ def _fused_ok(ctx, D) -> bool:
     """One predicate for every activation-stationary kernel of csrc/block_fused.hip (bf16, d_model 256,
     token count inside the kernels' 32-bit row offsets); otherwise the tiled / weight-stationary path runs."""
     return MLP_FUSE and ctx.cdt == torch.bfloat16 and D == 256 and ctx.T <= FUSE_MAX_T
-# bf16 train step, opt-in (MFP_SPARSE_HEADS=1): the numerical (512-wide regression) heads and their loss / gradients
-# run on the COMPACTED list of tokens that carry a loss for that attribute (~15 % under masked-field prediction;
-# device-side count, static launch shapes).  It removes ~470 MB of logits / d(logits) traffic per step but trades
-# three T-sized launches for a dozen short ones whose fixed costs (20 us per tiled dgrad launch, the serial slab
-# reduction of a 6-tile weight gradient) eat the saving: 1.93 ms either way at the timed shape (DESIGN.md section 7).
-# Only the train step asks for it (StepCtx.sparse_heads): the predictions of the other tokens are never produced.
-SPARSE_HEADS = os.environ.get("MFP_SPARSE_HEADS", "0") == "1"
 
 
 def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False, w8=None):
@@ -82,8 +75,13 @@ class StepCtx:
         # pending LayerNorm parameter-gradient reductions (flush_ln_jobs); None = reduce in line
         self.ln_jobs = [] if os.environ.get("MFP_LN_BATCH_REDUCE", "1") == "1" else None
         self.loss_sort = None   # RICO position-sorted loss: dict(flag, labels, heads, ignore_sort)
-        self.sparse_heads = False   # train step only: numerical heads on the tokens that carry a loss (DecoderLossFn)
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
+        # train-step tail fusions (shared with the context-token view of this step): "fuse" (set by
+        # Model.forward_loss when the last block feeds the heads directly), "x_c" = (x2, its bf16 copy written by
+        # the last block's MLP kernel), "bias_wgg" = blocks whose dense_1 bias gradient comes from the grouped
+        # weight-gradient launch (their masked gradient was produced without column sums), "sums" = the flat
+        # [3 nkeys + 1] loss accumulator zeroed by the step prologue
+        self.tail = {"fuse": False, "x_c": None, "bias_wgg": set(), "sums": None}
         self.nvalid = nvalid
         self.training = training
         self.p = float(dropout) if training else 0.0
@@ -349,10 +347,14 @@ class BlockFn(torch.autograd.Function):
                       bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
                       dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
         if _fused_ok(ctx, D) and not st.fp8:
+            # the last block also leaves the heads' bf16 operand (saves the cast pass in front of the decoder)
+            x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)
+                    if ctx.tail["fuse"] and i == st.layout.L - 1 else None)
             x2, y2, mean2, rstd2, h = ops.mlp_fused_fwd(
                 x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"), st.cw(p + "mlp/dense_0/kernel"),
                 st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"), st.weight(p + "mlp/dense_1/bias"),
-                (ctx.p, ctx.seed, 2 * i + 2), ctx.step_ptr)
+                (ctx.p, ctx.seed, 2 * i + 2), ctx.step_ptr, x2_c=x2_c)
+            ctx.tail["x_c"] = (x2, x2_c) if x2_c is not None else None
             fctx.ctx, fctx.i = ctx, i
             fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
             return x2
@@ -427,7 +429,8 @@ class BlockFn(torch.autograd.Function):
                      colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D)),
                 dict(A=dh, B=y2, out=st.grad(p + "mlp/dense_0/kernel"), M=2 * D, N=D,
                      colsum=st.grad(p + "mlp/dense_0/bias")),
-                dict(A=d_o2, B=h, out=st.grad(p + "mlp/dense_1/kernel"), M=D, N=2 * D),
+                dict(A=d_o2, B=h, out=st.grad(p + "mlp/dense_1/kernel"), M=D, N=2 * D,
+                     colsum=st.grad(p + "mlp/dense_1/bias") if i in ctx.tail["bias_wgg"] else None),
                 dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)], T)
         if grouped:
             ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1)
@@ -485,6 +488,14 @@ def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Ten
     ctx.on_side(wgrad_heads, dl_c, h_c)
     wt = st.heads_t()
     if MLP_FUSE and wt is not None and dl_c.dtype == torch.bfloat16 and D == 256 and T <= (1 << 19):
+        last = L.L - 1
+        if ctx.tail["fuse"] and WGRAD_GROUP and ctx.training and L.L > 0:
+            # ... and the dropout-masked bf16 copy the last block's backward starts from (mfp_dropout_bwd fused into
+            # the epilogue; that Dense's bias gradient then comes out of the block's grouped weight-gradient launch)
+            dh, d_o2 = ops.dgrad_rows(dl_c, wt, U, drop=(ctx.p, ctx.seed, 2 * last + 2, ctx.step_ptr))
+            ctx.handoff[last] = d_o2
+            ctx.tail["bias_wgg"].add(last)
+            return dh
         return ops.dgrad_rows(dl_c, wt, U)        # activation-stationary (csrc/block_fused.hip)
     dh = ops.gemm(dl_c, st.cw("decoder/decoder_%s/kernel" % first, rows=U), T, D, U, a_kmajor=True,
                   b_kmajor=False, out_dtype=torch.float32)
@@ -521,23 +532,6 @@ def loss_row_maps(sort, logits, nvalid, B, S):
     return pred_row, true_row
 
 
-def _cat_ranges(keys: List[dict], Upad: int):
-    """Contiguous 8-aligned column ranges that hold the categorical heads (the numerical heads between them are
-    evaluated on compacted rows): Crello [0, 320) and [1344, 1384)."""
-    hs = sorted((k["col_off"], k["col_off"] + k["n_feat"] * k["n_class"], bool(k["is_numerical"])) for k in keys)
-    out = []
-    for i, (b, e, num) in enumerate(hs):
-        if num:
-            continue
-        nxt = hs[i + 1][0] if i + 1 < len(hs) else Upad
-        e8 = min((e + 7) // 8 * 8, nxt)
-        if out and not hs[i - 1][2] and b - out[-1][1] < 8:
-            out[-1][1] = e8
-        else:
-            out.append([b // 8 * 8, e8])
-    return [(b, e) for b, e in out]
-
-
 class DecoderLossFn(torch.autograd.Function):
     """Heads + fused LossLayer.  Returns ``(loss_total, sums[nkeys,3], logits)``; the backward
     assumes the conventional unit upstream gradient on ``loss_total``."""
@@ -547,82 +541,39 @@ class DecoderLossFn(torch.autograd.Function):
         # the unused output gradients (sums, logits) must NOT be materialised: autograd would
         # zero-fill a [T, Upad] f32 tensor (181 MB at the Crello config) every step
         fctx.set_materialize_grads(False)
-        h_c = ctx.to_cdt(h.contiguous())
-        num = [(i, k) for i, k in enumerate(keys) if k["is_numerical"]]
-        if (SPARSE_HEADS and ctx.sparse_heads and WGRAD_GROUP and ctx.cdt == torch.bfloat16 and ctx.loss_sort is None and num
-                and ctx.T <= 65536 and all(k["n_class"] % 8 == 0 and k["col_off"] % 8 == 0 for _, k in num)):
-            return DecoderLossFn._forward_sparse(fctx, h_c, ctx, keys, num)
+        h = h.contiguous()
+        xc = ctx.tail["x_c"]
+        if xc is not None and xc[0].data_ptr() == h.data_ptr() and xc[1].shape == h.shape:
+            h_c = xc[1]           # written by the last block's MLP kernel
+        else:
+            h_c = ctx.to_cdt(h)
+        ctx.tail["x_c"] = None
         logits = _heads_fwd(ctx, h_c)
         dl = ctx.store.scratch("dlogits", logits.shape, ctx.cdt)   # zeroed once: pad columns stay 0
         pred_row, true_row = loss_row_maps(ctx.loss_sort, logits, ctx.nvalid, ctx.B, ctx.S)
-        sums, dl = ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt, dlogits=dl,
-                                    pred_row=pred_row, true_row=true_row)
-        fctx.ctx, fctx.saved, fctx.sparse = ctx, (h_c, dl), None
+        flat = ctx.tail["sums"]
+        if flat is not None and flat.numel() == 3 * len(keys) + 1:
+            # the train step (MFP._forward): accumulators zeroed by the step prologue -> no zeroing launch; and the
+            # returned "loss" is only the ROOT of the backward pass (a zero scalar): nothing on the device needs its
+            # value -- the step's loss is the host-side sum of sums[:, 0] (MFP.metrics_dict) -- and both a reduction
+            # launch (4.8 us) and a grand-total atomic in the loss kernels (+33 us: 5 k same-address atomics) cost more
+            sums = flat[:3 * len(keys)].view(len(keys), 3)
+            ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt, sums=sums, dlogits=dl,
+                             pred_row=pred_row, true_row=true_row, prezeroed=True)
+            loss = flat[3 * len(keys):].view(())
+            ctx.tail["sums"] = None
+        else:
+            sums, dl = ops.loss_fwd_bwd(logits, keys, ctx.nvalid, ctx.B, ctx.S, ctx.cdt, dlogits=dl,
+                                        pred_row=pred_row, true_row=true_row)
+            loss = sums[:, 0].sum()
+        fctx.ctx, fctx.saved = ctx, (h_c, dl)
         fctx.mark_non_differentiable(sums, logits)
-        return sums[:, 0].sum(), sums, logits
-
-    @staticmethod
-    def _forward_sparse(fctx, h_c, ctx: StepCtx, keys, num):
-        """Categorical heads on every token (column ranges of the concatenated head matrix); each numerical head on
-        the compacted rows of the tokens whose loss weight is non-zero (decoder.py:39-43, metrics.py:247-267)."""
-        st, L = ctx.store, ctx.store.layout
-        first = L.head_order[0]
-        T, D, U = ctx.T, L.D, L.Upad
-        W = st.cw("decoder/decoder_%s/kernel" % first, rows=U)            # [U][D] bf16
-        bias = st.span(st.w, "decoder/decoder_%s/bias" % first, U)
-        ranges = _cat_ranges(keys, U)
-        logits = st.scratch("logits_cat", (T, U), torch.float32)          # numerical columns: never written, never read
-        for c0, c1 in ranges:
-            ops.gemm(h_c, W[c0:c1], T, c1 - c0, D, a_kmajor=True, b_kmajor=True, out=logits[:, c0:c1], ldc=U,
-                     bias=bias[c0:c1])
-        dl = st.scratch("dlogits", (T, U), ctx.cdt)
-        sums = ops.loss_fwd_bwd_categorical(logits, keys, ctx.nvalid, ctx.B, ctx.S, dl)
-        idx, count = ops.compact_tokens([k for _, k in num], ctx.nvalid, ctx.B, ctx.S)
-        parts = []
-        for j, (slot, k) in enumerate(num):
-            c0, Wd = k["col_off"], k["n_class"]
-            cnt = count[j:j + 1]
-            xc = ops.gather_rows(h_c, idx[j], cnt, out=st.scratch("heads_xc%d" % j, (T, D), ctx.cdt))
-            pred = ops.gemm(xc, W[c0:c0 + Wd], T, Wd, D, a_kmajor=True, b_kmajor=True, bias=bias[c0:c0 + Wd],
-                            out=st.scratch("heads_pred%d" % j, (T, Wd), torch.float32), m_dev=cnt)
-            dpred = ops.loss_numeric_compact(pred, k, slot, idx[j], cnt, ctx.nvalid, sums, ctx.B, ctx.S, ctx.cdt,
-                                             dpred=st.scratch("heads_dpred%d" % j, (T, Wd), ctx.cdt))
-            parts.append((c0, Wd, xc, dpred, idx[j], cnt))
-        fctx.ctx, fctx.saved, fctx.sparse = ctx, (h_c, dl), (ranges, parts)
-        fctx.mark_non_differentiable(sums, logits)
-        return sums[:, 0].sum(), sums, logits
+        return loss, sums, logits
 
     @staticmethod
     def backward(fctx, dloss, dsums, dlogits):
         ctx = fctx.ctx
         h_c, dl = fctx.saved
-        if fctx.sparse is None:
-            dh = _heads_bwd(ctx, dl, h_c)
-            fctx.saved = None
-            return dh, None, None
-        ranges, parts = fctx.sparse
-        st, L = ctx.store, ctx.store.layout
-        first = L.head_order[0]
-        T, D, U = ctx.T, L.D, L.Upad
-        W = st.cw("decoder/decoder_%s/kernel" % first, rows=U)
-        gW = st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D)      # [U][D] f32
-        gb = st.span(st.g, "decoder/decoder_%s/bias" % first, U)
-
-        def wgrad_heads():
-            # two grouped launches, each with the split-K that fits its contraction length: the categorical ranges
-            # over all tokens, the numerical heads over their (short) token lists
-            ops.wgrad_group([dict(A=dl[:, c0:c1], B=h_c, out=gW[c0:c1], M=c1 - c0, N=D, colsum=gb[c0:c1])
-                             for c0, c1 in ranges], T)
-            ops.wgrad_group([dict(A=dpred, B=xc, out=gW[c0:c0 + Wd], M=Wd, N=D, colsum=gb[c0:c0 + Wd], k_dev=cnt)
-                             for c0, Wd, xc, dpred, _, cnt in parts], T, splitk=8)
-        ctx.on_side(wgrad_heads, dl, h_c)
-        dh = None
-        for c0, c1 in ranges:
-            dh = ops.gemm(dl[:, c0:c1], W[c0:c1], T, D, c1 - c0, a_kmajor=True, b_kmajor=False, lda=U, out=dh,
-                          out_dtype=torch.float32, accum=dh is not None)
-        for j, (c0, Wd, xc, dpred, idx, cnt) in enumerate(parts):
-            dxc = ops.gemm(dpred, W[c0:c0 + Wd], T, D, Wd, a_kmajor=True, b_kmajor=False,
-                           out=st.scratch("heads_dxc%d" % j, (T, D), torch.float32), m_dev=cnt)
-            ops.scatter_add_rows(dh, dxc, idx, cnt)
-        fctx.saved = fctx.sparse = None
+        dh = _heads_bwd(ctx, dl, h_c)
+        fctx.saved = None
         return dh, None, None

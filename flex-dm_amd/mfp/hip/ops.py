@@ -119,11 +119,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
          rowskip_a: Optional[torch.Tensor] = None, splitk: int = 1,
          step_ptr: Optional[torch.Tensor] = None,
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
-         ln: Optional[tuple] = None, m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+         ln: Optional[tuple] = None) -> torch.Tensor:
     """``out[M,N] = epilogue(op(A) @ op(B))`` -- see ``mfp_gemm`` in include/mfp_hip.h.
     ``ln`` = (gamma, beta, y_out bf16 [M,K], mean_out [M], rstd_out [M]): A is the f32 input of a
-    LayerNormalization; the kernel multiplies LN(A) and also writes y / mean / rstd (MFP_GEMM_LNORM_A).
-    ``m_dev`` (int32 [1] on the device): only the first min(M, m_dev) rows are computed (compacted rows)."""
+    LayerNormalization; the kernel multiplies LN(A) and also writes y / mean / rstd (MFP_GEMM_LNORM_A)."""
     lib = load()
     assert ln is not None or A.dtype == B.dtype, (A.dtype, B.dtype)
     if out is None:
@@ -169,7 +168,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
         flags |= GEMM_ROWSKIP_A
         a.rowcode = _ptr(rowskip_a)
     a.flags, a.splitk = flags, splitk
-    a.m_dev = _ptr(m_dev)
     nbytes = lib.mfp_gemm_workspace_bytes(ctypes.byref(a))
     if nbytes:
         ws = workspace(nbytes, A.device)
@@ -268,7 +266,6 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None) -> N
         a = arr[i]
         a.A, a.B, a.C = _ptr(A), _ptr(B), _ptr(out)
         a.colsum, a.rowcode = _ptr(j.get("colsum")), _ptr(j.get("rowskip"))
-        a.k_dev = _ptr(j.get("k_dev"))      # int32 [1] on the device: this job contracts over min(K, k_dev) rows
         a.M, a.N = j["M"], j["N"]
         a.lda, a.ldb = A.stride(0), B.stride(0)
         a.ldc = out.stride(0) if out.dim() == 2 else j["N"]
@@ -297,9 +294,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
     return y, mean, rstd
 
 
-def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2, b2, dropout: Tuple[float, int, int], step_ptr=None):
+def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2, b2, dropout: Tuple[float, int, int], step_ptr=None, x2_c=None):
     """x2 = x1 + Dropout(relu(LN(x1) W1^T + b1) W2^T + b2) in one launch (d_model 256, bf16 weights).
-    Returns (x2, y2, mean, rstd, h) -- the tensors the three-launch path saves for backward."""
+    Returns (x2, y2, mean, rstd, h) -- the tensors the three-launch path saves for backward.
+    ``x2_c`` (bf16 [T, D], optional): also receives a bf16 copy of x2."""
     lib = load()
     T, D = x1.shape
     F = 2 * D
@@ -311,7 +309,7 @@ def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2, b2, dropout: Tuple[float, int, in
     x2 = torch.empty((T, D), dtype=torch.float32, device=dev)
     with _timed("mlp_fused_kernel", 2 * 2 * T * D * F, T * (D * 4 * 3 + D * 2 + F * 2) + 2 * D * F * 2):
         check(lib.mfp_mlp_fused_fwd(_ptr(x1), _ptr(gamma), _ptr(beta), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2),
-                                    _ptr(y2), _ptr(mean), _ptr(rstd), _ptr(h), _ptr(x2), T, D, LN_EPS,
+                                    _ptr(y2), _ptr(mean), _ptr(rstd), _ptr(h), _ptr(x2), _ptr(x2_c), T, D, LN_EPS,
                                     float(dropout[0]), int(dropout[1]), int(dropout[2]),
                                     _ptr(step_ptr) if step_ptr is not None else None, _stream()),
               "mfp_mlp_fused_fwd")
@@ -365,15 +363,19 @@ def dgrad_d256(dy: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def dgrad_rows(A: torch.Tensor, Wt: torch.Tensor, K: int) -> torch.Tensor:
-    """C f32 [T,256] = A[:, :K] Wt[:, :K]^T; A bf16 [T][lda], Wt bf16 [256][ldw] zero-padded beyond K (ldw % 128 == 0)."""
+def dgrad_rows(A: torch.Tensor, Wt: torch.Tensor, K: int, drop: Optional[tuple] = None):
+    """C f32 [T,256] = A[:, :K] Wt[:, :K]^T; A bf16 [T][lda], Wt bf16 [256][ldw] zero-padded beyond K (ldw % 128 == 0).
+    ``drop`` = (p, seed, offset, step_ptr): also returns the dropout-masked, 1/keep-scaled bf16 copy of C (what
+    :func:`dropout_bwd` would produce from it) -> (C, C_drop)."""
     lib = load()
     T = A.shape[0]
     out = torch.empty((T, Wt.shape[0]), dtype=torch.float32, device=A.device)
-    with _timed("dgrad_rows_kernel", 2 * T * K * Wt.shape[0], T * (K * 2 + Wt.shape[0] * 4) + Wt.numel() * 2):
-        check(lib.mfp_dgrad_rows(_ptr(A), A.stride(0), _ptr(Wt), Wt.stride(0), _ptr(out), T, Wt.shape[0], K, _stream()),
-              "mfp_dgrad_rows")
-    return out
+    out_d = torch.empty((T, Wt.shape[0]), dtype=torch.bfloat16, device=A.device) if drop is not None else None
+    p_, seed_, off_, sp_ = drop if drop is not None else (0.0, 0, 0, None)
+    with _timed("dgrad_rows_kernel", 2 * T * K * Wt.shape[0], T * (K * 2 + Wt.shape[0] * (4 + (2 if drop else 0))) + Wt.numel() * 2):
+        check(lib.mfp_dgrad_rows(_ptr(A), A.stride(0), _ptr(Wt), Wt.stride(0), _ptr(out), T, Wt.shape[0], K,
+                                 _ptr(out_d), float(p_), int(seed_), int(off_), _ptr(sp_), _stream()), "mfp_dgrad_rows")
+    return out if drop is None else (out, out_d)
 
 
 def mlp_fused_bwd(d_o2, h, W2t, W1t):
@@ -517,11 +519,12 @@ def row_flags(x: torch.Tensor, rowcode: torch.Tensor, special_idx: Optional[torc
 def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tensor, B: int, S: int,
                  dl_dtype: Optional[torch.dtype], sums: Optional[torch.Tensor] = None,
                  dlogits: Optional[torch.Tensor] = None, pred_row: Optional[torch.Tensor] = None,
-                 true_row: Optional[torch.Tensor] = None):
+                 true_row: Optional[torch.Tensor] = None, prezeroed: bool = False):
     """keys: dicts with col_off, n_feat, n_class, is_numerical, target, mask, cond_idx,
     cond_stride, cond_bits.  Returns (sums [nkeys,3], dlogits or None).  ``pred_row`` /
     ``true_row`` (int32 [B*S] permutations from :func:`sort_positions`) select the RICO
-    position-sorted loss (reference metrics.py:180-211)."""
+    position-sorted loss (reference metrics.py:180-211).  ``prezeroed``: ``sums`` was zeroed by
+    :func:`step_prologue`; accumulate into it without a zeroing launch."""
     lib = load()
     ld = logits.shape[1]
     arr = (LossKey * len(keys))()
@@ -539,7 +542,10 @@ def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tenso
     code = dt_code(dlogits.dtype) if dlogits is not None else MFP_F32
     nb = logits.numel() * (4 + (_esz(dlogits) if dlogits is not None else 0))
     with _timed("loss_kernels(ce+mse)", 0, nb):
-        if pred_row is None and true_row is None:
+        if prezeroed:
+            check(lib.mfp_loss_fwd_bwd_acc(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid), _ptr(sums),
+                                           B, S, code, _ptr(pred_row), _ptr(true_row), _stream()), "mfp_loss_fwd_bwd_acc")
+        elif pred_row is None and true_row is None:
             check(lib.mfp_loss_fwd_bwd(_ptr(logits), _ptr(dlogits), ld, arr, len(keys), _ptr(nvalid), _ptr(sums),
                                        B, S, code, _stream()), "mfp_loss_fwd_bwd")
         else:
@@ -549,78 +555,6 @@ def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tenso
                                               _ptr(sums), B, S, code, _ptr(pred_row), _ptr(true_row), _stream()),
                   "mfp_loss_fwd_bwd_sorted")
     return sums, dlogits
-
-
-def _loss_keys(keys: Sequence[dict]):
-    arr = (LossKey * len(keys))()
-    for i, k in enumerate(keys):
-        arr[i].col_off, arr[i].n_feat, arr[i].n_class = k["col_off"], k["n_feat"], k["n_class"]
-        arr[i].is_numerical = int(k["is_numerical"])
-        arr[i].target, arr[i].mask = _ptr(k["target"]), _ptr(k["mask"])
-        arr[i].cond_idx = _ptr(k.get("cond_idx"))
-        arr[i].cond_stride = k.get("cond_stride", 1)
-        arr[i].cond_bits = k.get("cond_bits", 0xFFFFFFFF)
-    return arr
-
-
-def loss_fwd_bwd_categorical(logits, keys: Sequence[dict], nvalid, B: int, S: int, dlogits, sums=None):
-    """:func:`loss_fwd_bwd` restricted to the categorical keys of ``keys``; every row of ``sums`` is zeroed, the
-    numerical keys' rows are then filled by :func:`loss_numeric_compact`."""
-    lib = load()
-    if sums is None:
-        sums = torch.empty((len(keys), 3), dtype=torch.float32, device=logits.device)
-    ncat = sum(k["n_feat"] * k["n_class"] for k in keys if not k["is_numerical"])
-    with _timed("loss_kernels(ce+mse)", 0, logits.shape[0] * ncat * (4 + _esz(dlogits))):
-        check(lib.mfp_loss_fwd_bwd_categorical(_ptr(logits), _ptr(dlogits), logits.shape[1], _loss_keys(keys), len(keys),
-                                               _ptr(nvalid), _ptr(sums), B, S, dt_code(dlogits.dtype), _stream()),
-              "mfp_loss_fwd_bwd_categorical")
-    return sums
-
-
-def compact_tokens(keys: Sequence[dict], nvalid, B: int, S: int):
-    """Per key: the ascending list of tokens with a non-zero loss weight.  Returns (idx int32 [nkeys, B*S], count
-    int32 [nkeys]) -- both on the device; nothing is read back."""
-    lib = load()
-    idx = torch.empty((len(keys), B * S), dtype=torch.int32, device=nvalid.device)
-    count = torch.empty((len(keys) * 65,), dtype=torch.int32, device=nvalid.device)   # lengths | scan scratch
-    with _timed("compact_tokens_kernel", 0, len(keys) * B * S * 8):
-        check(lib.mfp_compact_tokens(_loss_keys(keys), len(keys), _ptr(nvalid), B, S, _ptr(idx), _ptr(count), _stream()),
-              "mfp_compact_tokens")
-    return idx, count[:len(keys)]
-
-
-def gather_rows(src: torch.Tensor, idx: torch.Tensor, count: torch.Tensor, out: Optional[torch.Tensor] = None):
-    """out[i] = src[idx[i]] for i < count (rows beyond are left untouched)."""
-    lib = load()
-    T, D = src.shape
-    if out is None:
-        out = torch.empty_like(src)
-    with _timed("gather_rows_kernel", 0, 0):
-        check(lib.mfp_gather_rows(_ptr(src), _ptr(out), _ptr(idx), _ptr(count), T, D * _esz(src), _stream()), "mfp_gather_rows")
-    return out
-
-
-def scatter_add_rows(dst: torch.Tensor, src: torch.Tensor, idx: torch.Tensor, count: torch.Tensor) -> None:
-    """dst[idx[i]] += src[i] for i < count (f32 rows; the indices are distinct)."""
-    lib = load()
-    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.shape[1] == src.shape[1]
-    with _timed("scatter_add_rows_kernel", 0, 0):
-        check(lib.mfp_scatter_add_rows(_ptr(dst), _ptr(src), _ptr(idx), _ptr(count), src.shape[0], dst.shape[1], _stream()),
-              "mfp_scatter_add_rows")
-
-
-def loss_numeric_compact(pred: torch.Tensor, key: dict, slot: int, idx, count, nvalid, sums, B: int, S: int,
-                         dl_dtype: torch.dtype, dpred: Optional[torch.Tensor] = None):
-    """Numerical key on compacted rows (row i of ``pred`` = token idx[i], i < count): accumulates into sums[slot]
-    and returns d(loss)/d(pred) in ``dl_dtype`` (same compact rows)."""
-    lib = load()
-    if dpred is None:
-        dpred = torch.empty(pred.shape, dtype=dl_dtype, device=pred.device)
-    with _timed("loss_kernels(ce+mse)", 0, 0):
-        check(lib.mfp_loss_numeric_compact(_ptr(pred), _ptr(dpred), _loss_keys([key]), slot, _ptr(idx), _ptr(count),
-                                           _ptr(nvalid), _ptr(sums), B, S, dt_code(dpred.dtype), _stream()),
-              "mfp_loss_numeric_compact")
-    return dpred
 
 
 def sort_positions(nvalid: torch.Tensor, flag: torch.Tensor, B: int, S: int, labels: Sequence[torch.Tensor] = None,
@@ -743,6 +677,22 @@ def sample_tasks(probs: Sequence[float], B: int, seed: int, offset: int, step_pt
     check(lib.mfp_sample_tasks(arr, len(probs), _ptr(tasks), B, int(seed), int(offset), _ptr(step_ptr), _stream()),
           "mfp_sample_tasks")
     return tasks
+
+
+def step_prologue(probs: Sequence[float], length: torch.Tensor, seed: int, offset: int, step_ptr: Optional[torch.Tensor],
+                  zero: Optional[torch.Tensor]):
+    """(tasks int32 [B] ~ Categorical(probs), nvalid int32 [B] = length + 1) and ``zero[:] = 0`` in ONE launch
+    (:func:`sample_tasks` + the ``length + 1`` element-wise op + the loss kernels' zeroing launch)."""
+    lib = load()
+    assert length.dtype == torch.int32 and length.is_contiguous()
+    B = length.numel()
+    tasks = torch.empty((B,), dtype=torch.int32, device=length.device)
+    nvalid = torch.empty((B,), dtype=torch.int32, device=length.device)
+    arr = (ctypes.c_float * len(probs))(*[float(x) for x in probs])
+    check(lib.mfp_step_prologue(arr, len(probs), _ptr(tasks), _ptr(length), _ptr(nvalid), B, int(seed), int(offset),
+                                _ptr(step_ptr), _ptr(zero), zero.numel() if zero is not None else 0, _stream()),
+          "mfp_step_prologue")
+    return tasks, nvalid
 
 
 def mask_tokens(cols: Sequence[dict], idx_all: torch.Tensor, nvalid: torch.Tensor, tasks: torch.Tensor,

@@ -258,10 +258,19 @@ class MFP:
         """masking -> encoder -> blocks -> heads + losses.  Returns (loss, sums, ctx or None)."""
         B = batch["left"].shape[0]
         ctx = None
+        nvalid = sums_flat = None
         if self.fast_masking and self.input_dtype == "set" and self.model.store.device.type == "cuda":
-            # one launch on the step's counter-based stream (torch.multinomial is ~8 tiny kernels)
-            tasks = ops_hip().sample_tasks(self.task_probs, B, self._masker.seed, 1, self.model.step_ptr,
-                                           self.model.store.device)
+            length = batch["length"].reshape(-1)
+            if length.dtype == torch.int32 and length.is_contiguous():
+                # the head of the step in ONE launch on its counter-based stream: task ids (torch.multinomial is ~8
+                # tiny kernels), nvalid = length + 1, and the loss accumulators zeroed
+                sums_flat = torch.empty(3 * len(loss_key_names(self._all_input_columns)) + 1, dtype=torch.float32,
+                                        device=length.device)
+                tasks, nvalid = ops_hip().step_prologue(self.task_probs, length, self._masker.seed, 1,
+                                                        self.model.step_ptr, sums_flat)
+            else:
+                tasks = ops_hip().sample_tasks(self.task_probs, B, self._masker.seed, 1, self.model.step_ptr,
+                                               self.model.store.device)
         else:
             tasks = self.sample_tasks(B)
         # RICO: documents drawn for the "pos" task are scored order-free (mfp.py:336-338)
@@ -273,8 +282,8 @@ class MFP:
             return build_loss_sort(self._all_input_columns, self.model.layout.head_cols, targets,
                                    tasks == self.task_names.index("pos"))
         if self.fast_masking and self.input_dtype == "set":
-            ctx = self.model.make_ctx(batch, True)
-            ctx.sparse_heads = True     # the step only needs the loss: numerical heads on the masked tokens only
+            ctx = self.model.make_ctx(batch, True, nvalid=nvalid)
+            ctx.tail["sums"] = sums_flat
             idx_all, codes, xs, masks = self._masker(batch, tasks, ctx.nvalid, ctx.B, ctx.S, self.model.step_ptr)
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, batch, masks)
             cin = {"task": tasks[..., None], "length": batch["length"]} if self.context is not None else None
@@ -344,15 +353,17 @@ class MFP:
         # thread-local capture checks: with a process group alive its watchdog thread polls events,
         # which a "global"-mode capture would treat as an illegal call and abort
         mode = "thread_local" if multi else "global"
+        # capture on the stream the warm-up ran on: the per-stream scratch (weight-gradient tickets, workspaces) then
+        # exists already -- created inside the capture, the tickets' zero-fill became a kernel node of every replay
         if not multi:
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, stream=side):
                 static_sums = self._forward_backward(static)
                 self._apply()
         else:
             # N > 1: the backward pass is cut at the input of block L/2.  Graph 1 = forward + upper
             # half of the backward; its gradients [split, end) (upper blocks + heads) are all-reduced
             # ASYNCHRONOUSLY while graph 2 runs the lower half; then [0, split); graph 3 = Adam.
-            with torch.cuda.graph(g1, capture_error_mode=mode):
+            with torch.cuda.graph(g1, stream=side, capture_error_mode=mode):
                 loss, static_sums, ctx = self._forward(static)
                 cut = ctx.mid if (ctx is not None and split > 0) else None
                 if cut is not None:
@@ -363,11 +374,11 @@ class MFP:
                 self._join_sides()
             if cut is not None:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode=mode):
+                with torch.cuda.graph(g2, pool=g1.pool(), stream=side, capture_error_mode=mode):
                     cut.backward(dcut)
                     self._join_sides()
             g3 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g3, pool=g1.pool(), capture_error_mode=mode):
+            with torch.cuda.graph(g3, pool=g1.pool(), stream=side, capture_error_mode=mode):
                 self.optimizer.step(grad_scale=1.0 / dp.world_size())
 
         def replay(batch):

@@ -54,9 +54,10 @@ class Model:
         self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=self.store.device) for _ in range(2)] if cuda else []
         self._first = _first_seq_key(input_columns)
 
-    def make_ctx(self, inputs: Dict, training: bool) -> StepCtx:
+    def make_ctx(self, inputs: Dict, training: bool, nvalid: Optional[torch.Tensor] = None) -> StepCtx:
         B, S = inputs[self._first].shape[:2]
-        nvalid = (inputs["length"].reshape(-1) + 1).to(torch.int32)
+        if nvalid is None:      # (the train step gets it from the step prologue kernel)
+            nvalid = (inputs["length"].reshape(-1) + 1).to(torch.int32)
         return StepCtx(self.store, B, S, nvalid, training, self.dropout, dp.rank_seed(self.seed), self.step_ptr,
                        self.side_streams if training and self.side_streams else None)
 
@@ -78,6 +79,9 @@ class Model:
         """Train-step path: heads + LossLayer fused.  Returns (loss_total, sums, outputs).
         ``premasked`` = (idx_all, codes, xs) from the fused masking kernel replaces ``inputs``."""
         if premasked is not None:
+            # the last block feeds the heads directly (no context token to strip): its MLP kernel writes the heads'
+            # bf16 operand and the heads' input-gradient kernel the masked gradient it starts its backward from
+            ctx.tail["fuse"] = self.context is None and training
             h = EncoderPreFn.apply(self.store.anchor, ctx, *premasked).view(ctx.B, ctx.S, self.layout.D)
             bctx = ctx
             if self.context is not None:

@@ -98,8 +98,6 @@ typedef struct mfp_gemm_args {
   float* ln_mean;
   float* ln_rstd;
   float ln_eps;
-  const int32_t* m_dev;    /* device or NULL: the launch covers min(M, *m_dev) rows (a_kmajor = 1, splitk = 1): row count
-                            * decided on the device (compacted rows), launch configuration still static */
 } mfp_gemm_args;
 
 int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);
@@ -131,7 +129,6 @@ typedef struct mfp_wgrad_job {
   float* colsum;
   const uint8_t* rowcode;
   int32_t M, N, lda, ldb, ldc;
-  const int32_t* k_dev;    /* device or NULL: this job contracts over min(K, *k_dev) rows */
 } mfp_wgrad_job;
 int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs /*host*/, int32_t njobs);
 int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K);
@@ -160,10 +157,12 @@ int mfp_gemm_fp8(const void* X, const uint8_t* Wq, const float* x_parts, const f
  * d_model 256 / dim_feedforward 512 only.  x1, x2 f32 [T,256]; W1 bf16 [512][256], W2 bf16 [256][512]
  * (out, in); saved for the backward pass: y2 = LN(x1) bf16 [T,256], mean/rstd f32 [T], h bf16 [T,512].
  * Dropout stream identical to MFP_GEMM_DROPOUT of mfp_gemm (same seed / offset / step_ptr meaning).
+ * x2_bf16 (may be NULL): a bf16 copy of x2, written by the same epilogue -- the last block hands the decoder
+ * heads (decoder.py:95-111) their MFMA operand without a cast pass.
  */
 int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const float* beta, const void* W1,
                       const float* b1, const void* W2, const float* b2, void* y2, float* mean,
-                      float* rstd, void* h, float* x2, int32_t T, int32_t D, float eps, float dropout_p,
+                      float* rstd, void* h, float* x2, void* x2_bf16, int32_t T, int32_t D, float eps, float dropout_p,
                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
 /* LayerNormalization + the fused Q | K | V Dense of a block in one launch (transformer.py:216-217,85-90):
@@ -195,8 +194,12 @@ int mfp_encoder_dense2(const void* x0, const void* x1, const void* W0, const voi
 
 /* Input gradient of a wide Dense in one activation-stationary launch: C f32 [T,256] = A[T][:K] Wt^T with A bf16
  * [T][lda] and Wt bf16 [256][ldw] = the kernel transposed, ZERO beyond column K (ldw a multiple of 128, >= K): the
- * decoder heads (decoder.py:39-43; K = 1384 at Crello).  d_model 256 only. */
+ * decoder heads (decoder.py:39-43; K = 1384 at Crello).  d_model 256 only.
+ * C_drop (may be NULL): bf16 [T,256] = C with the Dropout mask (dropout_p, seed, offset, step_ptr as in
+ * MFP_GEMM_DROPOUT) and the 1 / keep scale applied -- the gradient entering the last block's second Dense
+ * (transformer.py:225: x + dropout(mlp(...)) under Keras autodiff), i.e. mfp_dropout_bwd without its launch. */
 int mfp_dgrad_rows(const void* A, int32_t lda, const void* Wt, int32_t ldw, float* C, int32_t T, int32_t D, int32_t K,
+                   void* C_drop, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
                    mfp_stream_t stream);
 
 /* --------------------------------------------------------------------------- LayerNorm
@@ -311,32 +314,12 @@ int mfp_loss_fwd_bwd_sorted(const float* logits, void* dlogits, int32_t ld, cons
                             int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row,
                             mfp_stream_t stream);
 
-/* Compacted numerical heads.  Under masked-field prediction only the masked tokens of an attribute carry a
- * loss (metrics.py:251-267: weight 0 elsewhere, so neither the loss nor any gradient depends on the other
- * rows); the 512-wide regression heads (decoder.py:39-43 on image / text embeddings) are therefore evaluated
- * on the compacted token list only.  Launch shapes stay static (hipGraph): the list length lives on the device
- * and is consumed through mfp_gemm_args.m_dev / mfp_wgrad_job.k_dev.
- *   mfp_loss_fwd_bwd_categorical: mfp_loss_fwd_bwd restricted to the categorical keys (all sums rows are zeroed,
- *     the numerical keys' rows are filled by mfp_loss_numeric_compact afterwards);
- *   mfp_compact_tokens: per key k (only mask / cond_* are read): idx[k*T .. k*T + count[k]) = tokens with a
- *     non-zero weight, ascending; T = B*S <= 65536; count is int32 [nkeys + 64 * nkeys] (the lengths, then
- *     scratch for the per-workgroup counts of the two-pass scan);
- *   mfp_gather_rows / mfp_scatter_add_rows: dst[i] = src[idx[i]] (rows of row_bytes bytes) / dst[idx[i]] += src[i]
- *     (f32 rows) for i < *count; max_rows bounds the launch;
- *   mfp_loss_numeric_compact: pred f32 [>= *count][n_class] (row i = token idx[i]), dpred cdt same shape;
- *     accumulates {loss / B, score, count} into sums[slot] exactly as mfp_loss_fwd_bwd does for that key. */
-int mfp_loss_fwd_bwd_categorical(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys /*host*/,
-                                 int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
-                                 int32_t dl_dtype, mfp_stream_t stream);
-int mfp_compact_tokens(const mfp_loss_key* keys /*host*/, int32_t nkeys, const int32_t* nvalid, int32_t B, int32_t S,
-                       int32_t* idx, int32_t* count, mfp_stream_t stream);
-int mfp_gather_rows(const void* src, void* dst, const int32_t* idx, const int32_t* count, int32_t max_rows,
-                    int32_t row_bytes, mfp_stream_t stream);
-int mfp_scatter_add_rows(float* dst, const float* src, const int32_t* idx, const int32_t* count, int32_t max_rows,
-                         int32_t row_floats, mfp_stream_t stream);
-int mfp_loss_numeric_compact(const float* pred, void* dpred, const mfp_loss_key* key /*host*/, int32_t slot,
-                             const int32_t* idx, const int32_t* count, const int32_t* nvalid, float* sums,
-                             int32_t B, int32_t S, int32_t dl_dtype, mfp_stream_t stream);
+/* The same, ACCUMULATING: sums [nkeys][3] must be zero on entry (mfp_step_prologue) -- no zeroing launch.
+ * pred_row / true_row may be NULL.  (A grand total is deliberately not accumulated here: one more same-address
+ * atomic per workgroup cost the two loss kernels +33 us; the step's loss is the host-side sum of sums[:, 0].) */
+int mfp_loss_fwd_bwd_acc(const float* logits, void* dlogits, int32_t ld, const mfp_loss_key* keys /*host*/,
+                         int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
+                         int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row, mfp_stream_t stream);
 
 /* sort_inputs (reference models/tensor_utils.py:14-44) as a row map.  Per document b with flag[b]:
  *   priority(s) = sum_k v_k(s) * 100^(4-k) + [s >= nvalid[b]] * 100^5   (k over type, left, top,
@@ -432,6 +415,13 @@ int mfp_mask_tokens(const mfp_mask_col* cols /*host*/, int32_t ncols, int32_t* i
  * uniform per document, offset as in mfp_mask_tokens.  probs: HOST array of n <= 16 weights. */
 int mfp_sample_tasks(const float* probs /*host*/, int32_t n, int32_t* tasks, int32_t B, uint64_t seed,
                      uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
+
+/* The head of a train step in one launch: mfp_sample_tasks (same stream of draws) + nvalid[b] = length[b] + 1
+ * (reference architecture/mask.py get_seq_mask under mfp.py:101; nvalid may be NULL) + zero[0 .. nzero) = 0 (the
+ * loss accumulators consumed by mfp_loss_fwd_bwd_acc; zero may be NULL with nzero = 0). */
+int mfp_step_prologue(const float* probs /*host*/, int32_t n, int32_t* tasks, const int32_t* length, int32_t* nvalid,
+                      int32_t B, uint64_t seed, uint64_t offset, const int32_t* step_ptr, float* zero, int32_t nzero,
+                      mfp_stream_t stream);
 
 /* Hardware probe (tests only): lane mapping of ds_read_b64_tr_b16.  byte_addr int32 [64]
  * (8-byte aligned offsets into a 4 KiB LDS image whose b16 element e holds e); out u16 [64][4]. */

@@ -842,67 +842,6 @@ def test_mlp_fused_bwd(T):
     assert_close(dy2, want, 2e-2, 1e-2, "dy2 vs double")
 
 
-def test_compact_gather_scatter_and_device_row_counts():
-    """Compacted-row primitives of the numerical heads: token list + count on the device (mfp_compact_tokens),
-    row gather / scatter-add, and products that take their row count from the device (mfp_gemm m_dev on the
-    weight-stationary and the tiled kernel, mfp_wgrad_group k_dev) -- against torch on the host-known count."""
-    ops = _ops()
-    B, S, D, N = 24, 100, 256, 512
-    T = B * S
-    g = torch.Generator().manual_seed(11)
-    mask = (torch.rand(T, generator=g) < 0.15).to(torch.uint8)
-    nvalid = torch.randint(40, S + 1, (B,), generator=g, dtype=torch.int32)
-    cond = torch.randint(0, 7, (T,), generator=g, dtype=torch.int32)
-    bits = 0b0101101
-    key = dict(col_off=0, n_feat=1, n_class=N, is_numerical=True, target=torch.zeros(T, N, device=DEV), mask=mask.to(DEV),
-               cond_idx=cond.to(DEV), cond_stride=1, cond_bits=bits)
-    key2 = dict(key, cond_idx=None, cond_bits=0xFFFFFFFF)
-    idx, count = ops.compact_tokens([key, key2], nvalid.to(DEV), B, S)
-    s = torch.arange(T) % S
-    live = (mask != 0) & (s < nvalid[torch.arange(T) // S])
-    want = [torch.nonzero(live & (((bits >> cond) & 1) != 0)).flatten(), torch.nonzero(live).flatten()]
-    for j in range(2):
-        n = int(count[j])
-        assert n == want[j].numel() and n > 0
-        assert torch.equal(idx[j, :n].cpu().long(), want[j])
-    n, ix, cnt = int(count[0]), idx[0], count[0:1]
-    X = bf16_round(torch.randn(T, D, generator=g)).to(DEV, torch.bfloat16)
-    xc = ops.gather_rows(X, ix, cnt, out=torch.full((T, D), 7.0, dtype=torch.bfloat16, device=DEV))
-    assert torch.equal(xc[:n], X[ix[:n].long()]) and bool((xc[n:] == 7.0).all())
-    # weight-stationary product on min(M, count) rows
-    W = bf16_round(torch.randn(N, D, generator=g) * 0.05).to(DEV, torch.bfloat16)
-    out = torch.full((T, N), 3.0, device=DEV)
-    ops.gemm(xc, W, T, N, D, a_kmajor=True, b_kmajor=True, out=out, m_dev=cnt)
-    assert_close(out[:n], xc[:n].float().cpu().double() @ W.float().cpu().double().t(), 2e-3, 2e-3, "m_dev ws product")
-    tail = (n + 127) // 128 * 128
-    assert bool((out[tail:] == 3.0).all())                      # tiles past the count are not touched
-    # tiled kernel (k-major A, n-major B) on min(M, count) rows
-    dY = bf16_round(torch.randn(T, N, generator=g)).to(DEV, torch.bfloat16)
-    dx = torch.full((T, D), 3.0, device=DEV)
-    ops.gemm(dY, W, T, D, N, a_kmajor=True, b_kmajor=False, out=dx, m_dev=cnt)
-    assert_close(dx[:n], dY[:n].float().cpu().double() @ W.float().cpu().double(), 2e-3, 2e-3, "m_dev tiled product")
-    assert bool((dx[tail:] == 3.0).all())
-    # scatter-add
-    dst = torch.randn(T, D, generator=g).to(DEV)
-    ref = dst.clone()
-    ref[ix[:n].long()] += dx[:n]
-    ops.scatter_add_rows(dst, dx, ix, cnt)
-    assert torch.equal(dst, ref)
-    # grouped weight gradient over min(K, count) rows (rows past the count hold garbage on purpose)
-    dY2 = dY.clone()
-    dY2[n:] = float("nan")
-    gW, gb = torch.full((N, D), 9.0, device=DEV), torch.full((N,), 9.0, device=DEV)
-    gW2 = torch.full((D, D), 9.0, device=DEV)
-    ops.wgrad_group([dict(A=dY2, B=xc, out=gW, M=N, N=D, colsum=gb, k_dev=cnt),
-                     dict(A=X, B=X, out=gW2, M=D, N=D)], T)
-    a, b = dY[:n].float().cpu().double(), xc[:n].float().cpu().double()
-    assert_close(gW, a.t() @ b, 2e-3, 2e-3, "k_dev weight gradient")
-    assert_close(gb, a.sum(0), 2e-3, 2e-3, "k_dev bias gradient")
-    xx = X.float().cpu().double()
-    assert_close(gW2, xx.t() @ xx, 2e-3, 2e-3, "static-K job in the same launch")
-    assert int(ops._wgrad_tickets(DEV).abs().sum()) == 0
-
-
 @pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
 def test_qkv_fused_fwd(T):
     """mfp_qkv_fused_fwd: qkv = LN(x) Wqkv^T + b in one launch (transformer.py:216-217,85-90) against ln_fwd + the

@@ -536,7 +536,10 @@ def test_grouped_wgrad_equals_per_product_path():
         assert torch.isfinite(b).all(), name
         scale = a.abs().max().item()
         err = (a - b).abs().max().item()
-        assert err <= 2e-5 * scale + 1e-7, (name, err, scale)
+        # the last block's second-Dense bias gradient: column sums of the bf16 gradient inside the grouped launch
+        # (its masked gradient comes out of the heads' input-gradient kernel) vs f32 column sums in mfp_dropout_bwd
+        tol = 1e-3 if name.endswith("seq2seq_3/mlp/dense_1/bias") else 2e-5
+        assert err <= tol * scale + 1e-7, (name, err, scale)
 
 
 # ------------------------------------------------------------------ BASELINE config c5 shape (D=512, 8 blocks, S=256)
@@ -688,46 +691,3 @@ def test_c5_fp8_deviation_and_training():
     assert np.isfinite(first) and float(sums[:, 0].sum()) < first
 
 
-@pytest.mark.parametrize("masking_method", ["random", "elem_pos_attr_img_txt"])
-def test_sparse_numerical_heads_equal_dense_path(masking_method):
-    """bf16 train step: the numerical heads evaluated on the compacted list of loss-carrying tokens (device-side
-    count: mfp_gemm_args.m_dev, mfp_wgrad_job.k_dev) against every head on every token -- same batch, masks and
-    dropout streams.  Loss sums per key and every parameter gradient must agree up to f32 summation order (the
-    rows that are skipped have zero weight: reference metrics.py:251-267)."""
-    from mfp.data.spec import make_input_columns, synthetic_batch
-    from mfp.hip import functions
-    from mfp.models.mfp import MFP
-    ic = make_input_columns("crello")
-    B, S = 48, 128
-    batch = synthetic_batch(ic, B, S, seed=5, ragged=True, device=DEV)
-    res = []
-    old = functions.SPARSE_HEADS
-    try:
-        for sparse in (False, True):
-            functions.SPARSE_HEADS = sparse
-            model = MFP(ic, num_blocks=2, latent_dim=256, dropout=0.1, l2=1e-2, masking_method=masking_method,
-                        dtype="bf16", device=DEV)
-            model.compile(learning_rate=1e-3)
-            model.model.store.g.fill_(float("nan"))
-            sums = model._forward_backward(batch)
-            torch.cuda.synchronize()
-            res.append((model.model.store.grads_state_dict(), sums.clone()))
-    finally:
-        functions.SPARSE_HEADS = old
-    (g0, s0), (g1, s1) = res
-    assert torch.isfinite(s1).all()
-    assert torch.equal(s0[:, 2], s1[:, 2])                              # same tokens counted
-    assert torch.allclose(s0, s1, rtol=2e-5, atol=1e-5), (s0, s1)
-    gmax = max(a.abs().max().item() for a in g0.values())
-    for name, a in g0.items():
-        b = g1[name]
-        assert torch.isfinite(b).all(), name
-        # the head gradients differ by f32 summation order only; everything below the heads sees d(hidden) with
-        # different last bits, re-rounded to bf16 along the backward chain (isolated one-ulp flips, 2^-8 relative,
-        # on a fraction of the activations): bounded by a small multiple of that, relative to the variable's scale
-        scale = a.abs().max().item()
-        err = (a - b).abs().max().item()
-        assert err <= 4e-3 * scale + 1e-5 * gmax, (name, err, scale)
-        if scale > 1e-3 * gmax:      # (variables with a structurally zero gradient hold rounding noise only)
-            cos = torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
-            assert cos > 0.9999, (name, cos)
