@@ -30,6 +30,8 @@
 // average: the kernel is within 25 % of what HBM delivers for its byte count; every workgroup is in the same
 // phase at the same time (one per CU), which is what keeps it from overlapping the prologue / epilogue traffic
 // with the products.  A first attempt in round 1 kept 64 rows per workgroup and lost to the three launches.
+#include <stdlib.h>
+
 #include "common.h"
 #include <type_traits>
 
@@ -49,6 +51,14 @@ struct MlpParams {
   unsigned long long* trace;   // [workgroup][24] s_memrealtime stamps (100 MHz) of thread 0
 #endif
 };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void wgg_free_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    wgg_free_static_for<I + 1, N>(f);
+  }
+}
 
 constexpr int MLP_D = 256, MLP_F = 512, MLP_ROWS = 128;
 // LDS images have 512- or 256-byte rows with the 16-byte slot index XORed with (row & 15): a ds_read_b128 of 16
@@ -868,6 +878,136 @@ __global__ __launch_bounds__(512) void dgrad_qkv_kernel(DgradParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same product with HALF-SIZE workgroups: 64 rows, 4 waves, 80 KB of LDS -- two workgroups per CU -- for launches
+// whose 128-row grid would leave CUs idle: a batch of 128 documents x 128 elements (BASELINE config c4 per GPU) is 256
+// workgroups instead of 128.  Measured (MI355X, stand-alone): T = 16 384: 13.7 vs 15.4 us (K = 768), 7.3 vs 7.9 us
+// (K = 256); T = 32 768: 20.8 vs 19.7 us -- two co-resident workgroups in different phases do NOT lift the full-size
+// launch: what bounds these kernels is the weight stream out of L2 (two 32 KB chunks in flight per CU against ~2 us of
+// loaded L2 latency = 32 GB/s per CU, about a chunk per us whatever the split), so the half-size form is selected only
+// when T / 128 < #CUs.
+// Wave (rp, nh) = (wave & 1, wave >> 1) owns rows 32 rp .. + 31 and half of the 64 output columns of every weight
+// chunk (16 KB: Wt rows 64 j .. + 63, columns 128 kq .. + 127); waves 0-1 stream the weights, waves 2-3 the activation
+// pieces; the bf16 result leaves through the activation images (free during the last piece) in whole 256-byte rows.
+constexpr int H_ROWS = 64;
+constexpr int H_AS_B = H_ROWS * 256;     // one [64][256 B] activation piece
+constexpr int H_WS_B = 16384;            // one weight chunk
+constexpr int H_LDS = 2 * H_AS_B + 3 * H_WS_B;      // 80 KB
+
+template <int DG_K>
+__global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
+  constexpr int DG_KQ = DG_K / 128, DG_CHUNKS = 4 * DG_KQ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const As = smem;
+  unsigned char* const Ws = smem + 2 * H_AS_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int rp = wave & 1, nh = wave >> 1;
+  const int row0 = blockIdx.x * H_ROWS;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wt), 0, MLP_D * DG_K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, (unsigned int)p.T * (DG_K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (unsigned int)p.T * (MLP_D * 2), 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave), wl = wv & 1;
+  // both streams: 32 rows of 256 B per wave out of (2 DG_K)-byte rows, 4 rows per 1 KB instruction, source slot =
+  // destination slot ^ (row & 15); 8 instructions per wave
+  const unsigned int poff = (unsigned int)((wl * 32 + (lane >> 4)) * (DG_K * 2) + (((lane & 15) ^ (lane >> 4)) << 4));
+  auto wload = [&](int c) {          // chunk c = (kq, j): Wt rows 64 j .. + 63, columns 128 kq .. + 127
+    if (wv >= 2) return;
+    unsigned char* dst = Ws + (c % 3) * H_WS_B + wl * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6),
+                                               (c & 3) * 64 * (DG_K * 2) + (c >> 2) * 256 + i * 4 * (DG_K * 2), 0, 0);
+  };
+  auto aload = [&](int kq) {
+    if (wv < 2) return;
+    unsigned char* dst = As + (kq & 1) * H_AS_B + wl * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_u8*)(dst + i * 1024), 16, poff ^ ((i & 3) << 6),
+                                               row0 * (DG_K * 2) + kq * 256 + i * 4 * (DG_K * 2), 0, 0);
+  };
+  wload(0);
+  wload(1);
+  aload(0);
+  if (DG_KQ > 1) aload(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 acc2[4][2][2];
+  bf16x8 hf[2][4];
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+  // result image of column half jh (columns 128 jh .. + 127 of 64 rows, bf16): [64][256 B], slot ^ (row & 15); half 0
+  // in the activation buffer the last piece does not use, half 1 in the last piece's own buffer (its fragments are in
+  // registers two barriers earlier)
+  auto out_store = [&](int jh) {
+    const unsigned char* img = As + ((DG_KQ + jh) & 1) * H_AS_B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 4, c16 = idx & 15;
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(img + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_c,
+                                             (unsigned int)(row0 + r) * (MLP_D * 2) + c16 * 16 + jh * 256, 0, 0);
+    }
+  };
+
+  auto chunk = [&](auto cc_) {
+    constexpr int c = decltype(cc_)::value;
+    constexpr int kq = c >> 2, j = c & 3;
+    constexpr bool lastq = kq == DG_KQ - 1;
+    if (c + 2 < DG_CHUNKS) wload(c + 2);
+    if (lastq && j == 2) out_store(0);        // behind the barrier that ended (last, 1); AFTER the weight loads (counted waits)
+    if (j == 0 && kq >= 1 && kq + 1 < DG_KQ) aload(kq + 1);
+    if (j == 0) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          hf[rt][ks] = *reinterpret_cast<const bf16x8*>(As + (kq & 1) * H_AS_B + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
+    }
+    const unsigned char* wa = Ws + (c % 3) * H_WS_B + ((nh * 2) * 16 + li) * 256;
+    bf16x8 wf[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs[ks + 1]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          acc2[j][nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
+                                                                    (kq == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j][nt][rt], 0, 0, 0);
+    }
+    if (lastq) {
+      // columns 64 j .. + 63 of the result are final: bf16 into the image of their column half
+      unsigned char* img = As + ((DG_KQ + (j >> 1)) & 1) * H_AS_B;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const u32x2 pk = {pack_bf16x2(acc2[j][nt][rt][0], acc2[j][nt][rt][1]), pack_bf16x2(acc2[j][nt][rt][2], acc2[j][nt][rt][3])};
+          *reinterpret_cast<u32x2*>(img + (rp * 32 + rt * 16 + li) * 256 +
+                                    (((((j & 1) * 4 + nh * 2 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = pk;
+        }
+    }
+    {
+      // weight waves: chunk c + 1 landed when at most the 8 loads of chunk c + 2 (and the 4 stores of result half 0,
+      // issued at the head of (last, 2)) are younger; activation waves: piece kq + 1 is due at the end of (kq, 3)
+      constexpr int allowed_w = (c + 2 < DG_CHUNKS ? 8 : 0) + ((lastq && j == 2) ? 4 : 0);
+      if (wv < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
+      else if (j == 3 && kq + 1 < DG_KQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  wgg_free_static_for<0, DG_CHUNKS>(chunk);
+  out_store(1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Encoder: both numerical-attribute Dense layers in one launch (reference encoder.py:156-160,174-175,194-198):
 //
 //     h[t] += sum_j [code_j[t] == 0] * (x_j[t] W_j^T + b_j)        j = image embedding, text embedding (512-wide)
@@ -1243,8 +1383,37 @@ extern "C" int mfp_qkv_fused_fwd(const float* x, const float* gamma, const float
   return MFP_OK;
 }
 
+// 1: the half-size workgroups (two per CU); 0: 128-row workgroups; unset: half-size when the 128-row grid would leave
+// CUs idle (T / 128 < #CUs)
+static int half_mode(int T) {
+  const char* env = getenv("MFP_FUSED_HALF");      // (read per call: the tests flip it)
+  if (env != nullptr && env[0] != 0) return atoi(env) != 0;
+  static int ncu_of[MFP_MAX_DEVICES] = {};
+  int& ncu = ncu_of[mfp_device_slot()];
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu = n;
+  }
+  return (T + MLP_ROWS - 1) / MLP_ROWS < ncu;
+}
+
 template <int K>
 static int launch_dgrad_k(const DgradParams& p, hipStream_t st) {
+  if (half_mode(p.T)) {
+    static bool attr_done_h[MFP_MAX_DEVICES] = {};
+    bool& attr_set_h = attr_done_h[mfp_device_slot()];
+    if (!attr_set_h) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_half_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS);
+      if (e != hipSuccess) {
+        mfp_set_error("mfp_dgrad_qkv: cannot raise dynamic LDS to %d: %s", H_LDS, hipGetErrorString(e));
+        return MFP_ELAUNCH;
+      }
+      attr_set_h = true;
+    }
+    hipLaunchKernelGGL(dgrad_half_kernel<K>, dim3((p.T + H_ROWS - 1) / H_ROWS), dim3(256), H_LDS, st, p);
+    return MFP_OK;
+  }
   constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];

@@ -28,7 +28,7 @@ def _model(dtype):
     return ic, model
 
 
-def _masked_batch(ic, seed=0, ragged=True):
+def _masked_batch(ic, seed=0, ragged=True, B=B):
     """Crello-shaped batch + (modified inputs, masks) from the reference-shaped torch masking."""
     from mfp.data.spec import synthetic_batch
     from mfp.models import masking
@@ -88,6 +88,49 @@ def test_batch_equals_its_halves(dtype):
     err = (g - want).abs().max().item()
     scale = want.abs().max().item()
     assert err <= (2e-4 if dtype == "fp32" else 2e-2) * scale, (err, scale)
+
+
+def test_c4_per_gpu_shape_equals_its_halves_and_the_c2_batch():
+    """BASELINE config c4 (batch 1024 over 8 GPUs): the per-GPU shard, 128 documents x 128 elements, on the bf16 path.
+    T / 128 = 128 workgroups < 256 CUs: the launches that have a half-size form take it (mfp_dgrad_qkv / _d256).  The
+    shard's logits equal, bit for bit, those of the same documents inside a c2 batch of 256 (other workgroup sizes,
+    other grid) and inside shards of 64; its gradients are the mean of its halves' (linearity of the batch mean)."""
+    ic, model = _model("bf16")
+    batch, modified, masks, _ = _masked_batch(ic, seed=4)
+    _, logits_full, _ = _loss_grads(model, ic, batch, modified, masks)
+    n = B // 2
+    sl = slice(0, n)
+    sums, logits, g = _loss_grads(model, ic, _take(batch, sl), _take(modified, sl), _take(masks, sl))
+    assert torch.equal(logits, logits_full[:n * S])
+    parts = [_loss_grads(model, ic, _take(batch, q), _take(modified, q), _take(masks, q))
+             for q in (slice(0, n // 2), slice(n // 2, n))]
+    assert torch.equal(logits, torch.cat([p[1] for p in parts]))
+    assert torch.equal(sums[:, 2], parts[0][0][:, 2] + parts[1][0][:, 2])
+    assert torch.allclose(sums[:, 0], 0.5 * (parts[0][0][:, 0] + parts[1][0][:, 0]), rtol=2e-5, atol=1e-5)
+    want = 0.5 * (parts[0][2] + parts[1][2])
+    err, scale = (g - want).abs().max().item(), want.abs().max().item()
+    assert err <= 2e-2 * scale, (err, scale)
+
+
+def test_c4_per_gpu_shape_captured_step_equals_eager_step():
+    """c4's per-GPU shard through the product's own train step: the hipGraph replay (what bench.py --config c4 times)
+    leaves exactly the parameters the eager step leaves -- same kernels, same counter-based masks and dropout."""
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    batch = synthetic_batch(ic, 128, S, seed=6, ragged=True, device=DEV)
+    ws = []
+    for graph in (False, True):
+        m = MFP(ic, num_blocks=L, latent_dim=D, dropout=0.1, l2=1e-2, masking_method="random", dtype="bf16", device=DEV, seed=5)
+        m.compile(learning_rate=1e-3)
+        if graph:
+            m.capture_train_step(batch, warmup=0)
+        for _ in range(3):
+            m.train_step(batch)
+        torch.cuda.synchronize()
+        ws.append(m.model.store.w.clone())
+    assert torch.isfinite(ws[0]).all()
+    assert torch.equal(ws[0], ws[1])
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

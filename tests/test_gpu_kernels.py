@@ -884,6 +884,28 @@ def test_dgrad_qkv(T):
     assert_close(dy, dq.double() @ W.double(), 2e-2, 1e-2, "vs double")
 
 
+@pytest.mark.parametrize("half", ["0", "1"])
+@pytest.mark.parametrize("K", [768, 256])
+def test_dgrad_workgroup_sizes(K, half, monkeypatch):
+    """The 128-row and the half-size (64 rows, two workgroups per CU: the form a 128-document batch -- BASELINE config
+    c4 per GPU -- selects) kernels of mfp_dgrad_qkv / mfp_dgrad_d256 against a double reference, and against each
+    other BIT FOR BIT (same k order inside every accumulator); ragged last row group."""
+    ops = _ops()
+    D, T = 256, 128 * 5 + 37
+    g = torch.Generator().manual_seed(K)
+    dq = bf16_round(torch.randn(T, K, generator=g) * 0.5)
+    W = bf16_round(torch.randn(K, D, generator=g) * 0.05)
+    Wt = W.t().contiguous().to(DEV, torch.bfloat16)
+    dqd = dq.to(DEV, torch.bfloat16)
+    fn = ops.dgrad_qkv if K == 768 else ops.dgrad_d256
+    monkeypatch.setenv("MFP_FUSED_HALF", half)
+    dy = fn(dqd, Wt)
+    assert_close(dy, dq.double() @ W.double(), 2e-2, 1e-2, "vs double")
+    monkeypatch.setenv("MFP_FUSED_HALF", "1" if half == "0" else "0")
+    other = fn(dqd, Wt)
+    assert torch.equal(dy.view(torch.int16), other.view(torch.int16))
+
+
 @pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
 def test_encoder_dense2(T):
     """mfp_encoder_dense2: h += sum_j [code_j == 0] (x_j W_j^T + b_j) in one launch (encoder.py:156-160,174-175)

@@ -1,0 +1,44 @@
+"""Stand-alone timing (hipGraph replay) of the activation-stationary block kernels at T tokens (default 32768).
+MFP_FUSED_HALF=0/1 selects the 128-row / half-size workgroups."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "flex-dm_amd")]
+import torch
+from mfp.hip import ops
+T, D = int(os.environ.get("T", 32768)), 256
+dev = "cuda"
+rnd = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)
+
+
+def timeit(name, fn, nbytes, reps=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps): fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print("%-22s T=%d half=%s  %6.1f us  %5.2f TB/s" % (name, T, os.environ.get("MFP_FUSED_HALF", "auto"), us, nbytes / us / 1e6))
+
+
+which = os.environ.get("WHICH", "dgrad768,dgrad256,qkv,mlp,mlpbwd,enc,rows").split(",")
+if "dgrad768" in which:
+    dqkv, wt = rnd(T, 768), rnd(256, 768)
+    timeit("dgrad_qkv<768>", lambda: ops.dgrad_qkv(dqkv, wt), T * (768 + 256) * 2)
+if "dgrad256" in which:
+    dy, wt2 = rnd(T, 256), rnd(256, 256)
+    timeit("dgrad_qkv<256>", lambda: ops.dgrad_d256(dy, wt2), T * 512 * 2)
+x = torch.randn(T, D, device=dev)
+gam, bet = torch.rand(D, device=dev) + 0.5, torch.randn(D, device=dev)
+if "qkv" in which:
+    W, b = rnd(768, 256), torch.randn(768, device=dev)
+    timeit("qkv_fused", lambda: ops.qkv_fused_fwd(x, gam, bet, W, b), T * (256 * 4 + 256 * 2 + 768 * 2))
+if "mlp" in which:
+    W1, b1, W2, b2 = rnd(512, 256), torch.randn(512, device=dev), rnd(256, 512), torch.randn(256, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    timeit("mlp_fused", lambda: ops.mlp_fused_fwd(x, gam, bet, W1, b1, W2, b2, (0.1, 5, 3), step), T * (256 * 4 * 3 + 256 * 2 + 512 * 2))
+if "mlpbwd" in which:
+    d_o2, h, W2t, W1t = rnd(T, 256), rnd(T, 512), rnd(512, 256), rnd(256, 512)
+    timeit("mlp_bwd", lambda: ops.mlp_fused_bwd(d_o2, h, W2t, W1t), T * (256 * 2 * 2 + 512 * 2 * 2))
