@@ -12,7 +12,7 @@ per step.  Semantics match the single-GPU step on the global ba
 * metric numerators/denominators and loss sums are all-reduced for reporting.
 """
 import os
-from typing import Optional
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
@@ -53,6 +53,63 @@ def allreduce_gradients(flat_grad: torch.Tensor, async_op: bool = False):
     if world_size() == 1:
         return None
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def bucket_cut_blocks(num_blocks: int, mode: Optional[str] = None) -> List[int]:
+    """Blocks at whose INPUT the data-parallel step cuts its backward pass, in the order the backward pass
+    reaches them.  ``"blocks"`` (default): every block > 0 -> buckets {heads + block L-1}, {block L-2}, ...,
+    {block 0 + encoder}, each all-reduced while the next segment of the backward pass runs (only the last one and
+    Adam are exposed); ``"halves"``: one cut at block L/2 (rounds 1-2); ``"none"``: one all-reduce after the backward
+    pass.  MFP_DP_BUCKETS overrides."""
+    mode = mode or os.environ.get("MFP_DP_BUCKETS", "blocks")
+    if mode == "none" or num_blocks < 2:
+        return []
+    if mode == "halves":
+        return [num_blocks // 2]
+    if mode != "blocks":
+        raise ValueError("MFP_DP_BUCKETS=%r (blocks | halves | none)" % mode)
+    return list(range(num_blocks - 1, 0, -1))
+
+
+def bucket_slices(offsets: List[int], numel: int) -> List[slice]:
+    """Flat-gradient slices of the buckets for descending cut offsets: [off_0, numel), [off_1, off_0), ..., [0, off_last)."""
+    out, hi = [], numel
+    for off in offsets:
+        assert 0 <= off <= hi
+        out.append(slice(off, hi))
+        hi = off
+    out.append(slice(0, hi))
+    return out
+
+
+class BucketReducer:
+    """Sum all-reduce of one gradient bucket, optionally carried as bf16 (MFP_DP_GRAD_DTYPE=bf16: half the xGMI bytes;
+    every rank receives the same bf16 sums, so the replicas stay bit-identical; default f32).  ``launch`` is
+    asynchronous (the collective runs on the communication stream under whatever the caller enqueues next);
+    ``finish`` waits and, for bf16, writes the sums back into the f32 bucket."""
+
+    def __init__(self, grad_dtype: Optional[str] = None):
+        name = grad_dtype or os.environ.get("MFP_DP_GRAD_DTYPE", "f32")
+        if name not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError("MFP_DP_GRAD_DTYPE=%r (f32 | bf16)" % name)
+        self.bf16 = name in ("bf16", "bfloat16")
+        self.pending = []
+
+    def launch(self, bucket: torch.Tensor):
+        if world_size() == 1 or bucket.numel() == 0:
+            return
+        if self.bf16:
+            tmp = bucket.to(torch.bfloat16)
+            self.pending.append((dist.all_reduce(tmp, op=dist.ReduceOp.SUM, async_op=True), tmp, bucket))
+        else:
+            self.pending.append((dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True), None, bucket))
+
+    def finish(self):
+        for work, tmp, bucket in self.pending:
+            work.wait()
+            if tmp is not None:
+                bucket.copy_(tmp)
+        self.pending = []
 
 
 def allreduce_sums(sums: torch.Tensor) -> torch.Tensor:

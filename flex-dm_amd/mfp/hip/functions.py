@@ -72,6 +72,8 @@ class StepCtx:
         self.dh_c = None    # compute-dtype copy of the encoder output gradient (block 0's LN1 backward)
         self.onehot = None  # one-hot count matrix of the index columns (built during the forward pass)
         self.mid = None     # activation entering block L/2 (set by Blocks; see MFP.capture_train_step)
+        self.cuts = {}      # block index -> the activation entering that block (every block > 0; the data-parallel
+                            # step cuts its backward pass at some of them, MFP.capture_train_step)
         # pending LayerNorm parameter-gradient reductions (flush_ln_jobs); None = reduce in line
         self.ln_jobs = [] if os.environ.get("MFP_LN_BATCH_REDUCE", "1") == "1" else None
         self.loss_sort = None   # RICO position-sorted loss: dict(flag, labels, heads, ignore_sort)
@@ -121,6 +123,7 @@ class StepCtx:
         in the data-parallel split step, before the upper bucket is all-reduced."""
         if self.ln_jobs:
             ops.reduce_partials_batch(self.ln_jobs)
+            self.ln_jobs.clear()      # (in place: the context-token view of the step shares the list)
 
     def join_side(self):
         for side in self.sides:

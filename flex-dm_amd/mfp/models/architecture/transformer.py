@@ -49,5 +49,7 @@ class Blocks:
         for i, layer in enumerate(self.seq2seq.values()):
             if i == self.num_blocks // 2 and i > 0:
                 ctx.mid = seq
+            if i > 0:
+                ctx.cuts[i] = seq
             seq = layer(seq, ctx)
         return seq

@@ -333,8 +333,9 @@ class MFP:
 
     def capture_train_step(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2):
         """Capture the whole train step into hipGraphs (launch-bound inner loop: ~10^2 kernels of
-        ~10 us).  With world_size > 1 the step is three graphs with the RCCL all-reduce of the upper
-        gradient bucket overlapping the lower half of the backward pass."""
+        ~10 us).  With world_size > 1 the step is one graph per segment of the backward pass (cut at the block
+        inputs, dp.bucket_cut_blocks) plus one for Adam, with the RCCL all-reduce of each segment's gradient bucket
+        running under the next segment."""
         assert self.optimizer is not None, "call compile() first"
         static = {k: v.clone() for k, v in example_batch.items()}
         side = torch.cuda.Stream()
@@ -347,9 +348,10 @@ class MFP:
         torch.cuda.synchronize()
         multi = dp.world_size() > 1
         g1 = torch.cuda.CUDAGraph()
-        g2 = g3 = None
-        split = self.model.layout.bucket_split()
+        segs = []           # (graph, gradient bucket completed by it) in backward order; N > 1 only
+        g3 = None
         grad = self.model.store.g
+        layout = self.model.layout
         # thread-local capture checks: with a process group alive its watchdog thread polls events,
         # which a "global"-mode capture would treat as an illegal call and abort
         mode = "thread_local" if multi else "global"
@@ -360,26 +362,39 @@ class MFP:
                 static_sums = self._forward_backward(static)
                 self._apply()
         else:
-            # N > 1: the backward pass is cut at the input of block L/2.  Graph 1 = forward + upper
-            # half of the backward; its gradients [split, end) (upper blocks + heads) are all-reduced
-            # ASYNCHRONOUSLY while graph 2 runs the lower half; then [0, split); graph 3 = Adam.
+            # N > 1: the backward pass is cut at block inputs (dp.bucket_cut_blocks: by default every block).  Graph 0 =
+            # forward + heads + the last block; every further graph one more segment of the backward pass.  The flat
+            # gradient buffer is laid out encoder | block 0 | ... | block L-1 | heads, so what a segment completes is a
+            # contiguous bucket: its RCCL all-reduce is launched ASYNCHRONOUSLY behind the segment and runs under the
+            # next one; only the last bucket (block 0 + encoder) and Adam (its own graph) are exposed.
             with torch.cuda.graph(g1, stream=side, capture_error_mode=mode):
                 loss, static_sums, ctx = self._forward(static)
-                cut = ctx.mid if (ctx is not None and split > 0) else None
-                if cut is not None:
-                    dcut = torch.autograd.grad(loss, cut, grad_outputs=self._unit_grad(loss))[0]
-                    ctx.flush_ln_jobs()   # upper blocks' LayerNorm gradients must be final before their all-reduce
+                cut_blocks = [i for i in dp.bucket_cut_blocks(layout.L) if ctx is not None and i in ctx.cuts]
+                if cut_blocks:
+                    x_prev = ctx.cuts[cut_blocks[0]]
+                    d_prev = torch.autograd.grad(loss, x_prev, grad_outputs=self._unit_grad(loss))[0]
+                    ctx.flush_ln_jobs()   # the segment's LayerNorm gradients must be final before its all-reduce
                 else:
                     loss.backward(self._unit_grad(loss))
                 self._join_sides()
-            if cut is not None:
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g1.pool(), stream=side, capture_error_mode=mode):
-                    cut.backward(dcut)
+            slices = dp.bucket_slices([layout.block_offset(i) for i in cut_blocks], grad.numel())
+            segs.append((g1, slices[0]))
+            for k in range(1, len(cut_blocks) + 1):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=g1.pool(), stream=side, capture_error_mode=mode):
+                    if k < len(cut_blocks):
+                        x_k = ctx.cuts[cut_blocks[k]]
+                        d_k = torch.autograd.grad(x_prev, x_k, grad_outputs=d_prev)[0]
+                        ctx.flush_ln_jobs()
+                        x_prev, d_prev = x_k, d_k
+                    else:
+                        x_prev.backward(d_prev)
                     self._join_sides()
+                segs.append((gk, slices[k]))
             g3 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g3, pool=g1.pool(), stream=side, capture_error_mode=mode):
                 self.optimizer.step(grad_scale=1.0 / dp.world_size())
+        reducer = dp.BucketReducer() if multi else None
 
         def replay(batch):
             if any(k in static and tuple(v.shape) != tuple(static[k].shape) for k, v in batch.items()):
@@ -392,22 +407,19 @@ class MFP:
             for k, v in batch.items():
                 if k in static and v.data_ptr() != static[k].data_ptr():
                     static[k].copy_(v, non_blocking=True)
-            g1.replay()
-            if multi:
-                if g2 is not None:
-                    w_hi = dp.allreduce_gradients(grad[split:], async_op=True)   # overlaps graph 2
-                    g2.replay()
-                    w_lo = dp.allreduce_gradients(grad[:split], async_op=True)
-                    w_hi.wait()
-                    w_lo.wait()
-                else:
-                    dp.allreduce_gradients(grad)
+            if not multi:
+                g1.replay()
+            else:
+                for gk, sl in segs:
+                    gk.replay()
+                    reducer.launch(grad[sl])      # overlaps the next segment's graph
+                reducer.finish()
                 g3.replay()
             self.last_sums = static_sums
             return static_sums
 
         self._graph = replay
-        self._graph_objs = (g1, g2, g3, static, static_sums)
+        self._graph_objs = (g1, segs, g3, static, static_sums)
         self.static_batch = static   # a loader that writes the next batch here avoids the copy
         return replay
 

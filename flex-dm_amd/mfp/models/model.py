@@ -66,7 +66,7 @@ class Model:
         h, mask = self.encoder(inputs, ctx)
         bctx = ctx.with_context_token() if self.context is not None else ctx    # the blocks see S + 1 positions
         h = self.blocks(h, mask, bctx)
-        ctx.mid = bctx.mid
+        ctx.mid, ctx.cuts = bctx.mid, bctx.cuts
         return h, ctx
 
     def __call__(self, inputs: Dict, training: bool = False) -> Dict[str, torch.Tensor]:
@@ -88,7 +88,7 @@ class Model:
                 h = self.encoder.add_context_token(h, inputs, ctx)
                 bctx = ctx.with_context_token()
             h = self.blocks(h, None, bctx)
-            ctx.mid = bctx.mid
+            ctx.mid, ctx.cuts = bctx.mid, bctx.cuts
         else:
             h, ctx = self.hidden(inputs, training)
         if self.context is not None:      # decoder.py:74-76

@@ -169,6 +169,10 @@ class ModelLayout:
             return 0
         return self.segments["blocks/seq2seq_%d/attn/dense_query/kernel" % (self.L // 2)].offset
 
+    def block_offset(self, i: int) -> int:
+        """Flat offset of block i's first variable (its variables, then the later blocks', then the heads' follow)."""
+        return self.segments["blocks/seq2seq_%d/attn/dense_query/kernel" % i].offset
+
     def seg_offsets(self) -> List[int]:
         return [s.offset for s in self.segments.values()] + [self.numel]
 

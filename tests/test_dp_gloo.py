@@ -172,3 +172,59 @@ def test_evaluation_sums_over_uneven_shards_equal_the_global_batch(world, B):
     for i, k in enumerate(keys):
         assert abs(got[i, 0] - float(losses[k])) < 1e-5 * max(1.0, abs(float(losses[k]))), k
         assert abs(got[i, 1] - float(scores[k + "_score_num"])) < 1e-5 and abs(got[i, 2] - float(scores[k + "_score_den"])) < 1e-6
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "flex-dm_amd")]
+    from mfp import dp
+    assert dp.init_from_env("gloo") == world
+    gen = torch.Generator().manual_seed(100 + rank)          # every rank its own gradients
+    n = 10007
+    g = torch.randn(n, generator=gen)
+    ref = g.clone()
+    dp.allreduce_gradients(ref)                               # the single all-reduce of the whole buffer
+    # the bucketed form: descending cut offsets as the backward pass completes them, asynchronous launches
+    offsets = [9000, 4097, 4096, 13]
+    slices = dp.bucket_slices(offsets, n)
+    out = {}
+    for name in ("f32", "bf16"):
+        buf = g.clone()
+        red = dp.BucketReducer(name)
+        for sl in slices:
+            red.launch(buf[sl])
+        red.finish()
+        out[name] = buf
+    gathered = [torch.empty_like(out["bf16"]) for _ in range(world)]
+    dist.all_gather(gathered, out["bf16"])
+    if rank == 0:
+        q.put((ref.numpy(), out["f32"].numpy(), out["bf16"].numpy(), [t.numpy() for t in gathered],
+               [(s.start, s.stop) for s in slices]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_single_allreduce():
+    """mfp.dp.BucketReducer over per-segment buckets (what the captured data-parallel step launches behind every
+    segment of its backward pass) against ONE all-reduce of the flat buffer: bit for bit in f32 (a sum all-reduce is
+    element-wise); the bf16 carrier (MFP_DP_GRAD_DTYPE=bf16) gives every rank the SAME values, within bf16 rounding
+    of the f32 sums."""
+    from mfp import dp
+    assert dp.bucket_cut_blocks(4, "blocks") == [3, 2, 1] and dp.bucket_cut_blocks(4, "halves") == [2]
+    assert dp.bucket_cut_blocks(1, "blocks") == [] and dp.bucket_cut_blocks(8, "none") == []
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ref, f32, bf16, gathered, slices = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert slices[0] == (9000, 10007) and slices[-1] == (0, 13) and sum(b - a for a, b in slices) == 10007
+    assert np.array_equal(ref, f32)
+    assert all(np.array_equal(gathered[0], t) for t in gathered)
+    assert np.allclose(bf16, ref, rtol=2 ** -7, atol=1e-2)

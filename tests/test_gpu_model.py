@@ -313,9 +313,11 @@ def test_two_rank_step_on_one_gpu_over_gloo(tmp_path):
 
 
 def test_split_backward_equals_single_backward():
-    """The data-parallel step cuts the backward pass at the input of block L/2 (gradients of the upper
-    half are all-reduced while the lower half runs): autograd.grad(loss, cut) followed by
-    cut.backward(dcut) must leave exactly the gradients of one loss.backward()."""
+    """The data-parallel step cuts the backward pass at block inputs (gradients of the segments already done are
+    all-reduced while the next segment runs; mfp.dp.bucket_cut_blocks): the chain autograd.grad(loss, x_3),
+    autograd.grad(x_3, x_2, d_3), ..., x_1.backward(d_1) must leave exactly the gradients of one loss.backward(),
+    and after every segment exactly that segment's bucket of the flat buffer is final."""
+    from mfp import dp
     from mfp.data.spec import make_input_columns, synthetic_batch
     from mfp.models.mfp import MFP
     ic = make_input_columns("crello")
@@ -325,30 +327,40 @@ def test_split_backward_equals_single_backward():
                 dtype="bf16", device=DEV)
     model.compile(learning_rate=1e-3)
     g = model.model.store.g
-    split = model.model.layout.bucket_split()
-    assert 0 < split < g.numel()
+    layout = model.model.layout
     g.fill_(float("nan"))
     loss, sums, ctx = model._forward(batch)     # the step counter does not move: same masks / dropout
     loss.backward()
     model._join_sides()
     torch.cuda.synchronize()
     ref, ref_sums = g.clone(), sums.clone()
-    g.fill_(float("nan"))
-    loss, sums, ctx = model._forward(batch)
-    assert ctx.mid is not None
-    dcut = torch.autograd.grad(loss, ctx.mid)[0]
-    ctx.flush_ln_jobs()          # as capture_train_step does before the upper bucket's all-reduce
-    model._join_sides()
-    torch.cuda.synchronize()
-    # upper bucket complete; the lower one is still (almost) untouched -- only the bias gradient that
-    # the fused LayerNorm backward of block L/2 emits for block L/2-1 has landed
-    assert torch.equal(g[split:], ref[split:])
-    assert torch.isnan(g[:split]).float().mean() > 0.99
-    ctx.mid.backward(dcut)
-    model._join_sides()
-    torch.cuda.synchronize()
-    assert torch.allclose(sums, ref_sums, rtol=1e-5, atol=1e-5)   # loss sums: float atomics across workgroups
-    assert torch.equal(g, ref)
+    for mode in ("blocks", "halves"):
+        cuts = dp.bucket_cut_blocks(layout.L, mode)
+        assert cuts == ([3, 2, 1] if mode == "blocks" else [2])
+        slices = dp.bucket_slices([layout.block_offset(i) for i in cuts], g.numel())
+        assert slices[0].stop == g.numel() and slices[-1].start == 0 and all(a.start == b.stop for a, b in zip(slices, slices[1:]))
+        g.fill_(float("nan"))
+        loss, sums, ctx = model._forward(batch)
+        assert all(i in ctx.cuts for i in cuts)
+        x_prev = ctx.cuts[cuts[0]]
+        d_prev = torch.autograd.grad(loss, x_prev)[0]
+        for k in range(len(cuts)):
+            ctx.flush_ln_jobs()          # as capture_train_step does before a bucket's all-reduce
+            model._join_sides()
+            torch.cuda.synchronize()
+            # this segment's bucket is complete; the next one is still (almost) untouched -- only the bias gradient
+            # that the fused LayerNorm backward of the cut block emits for the block below has landed
+            assert torch.equal(g[slices[k]], ref[slices[k]]), (mode, k)
+            assert torch.isnan(g[slices[k + 1]]).float().mean() > 0.98, (mode, k)
+            if k + 1 < len(cuts):
+                x_k = ctx.cuts[cuts[k + 1]]
+                d_prev = torch.autograd.grad(x_prev, x_k, grad_outputs=d_prev)[0]
+                x_prev = x_k
+        x_prev.backward(d_prev)
+        model._join_sides()
+        torch.cuda.synchronize()
+        assert torch.allclose(sums, ref_sums, rtol=1e-5, atol=1e-5)   # loss sums: float atomics across workgroups
+        assert torch.equal(g, ref), mode
 
 
 def test_shuffled_set_position_token_parity_and_training():
