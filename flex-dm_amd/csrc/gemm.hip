@@ -52,7 +52,6 @@ struct GemmParams {
   const int* step_ptr;
   int tiles_m, tiles_n;
   int kz_xcd;      // 1: 1-D grid, k-chunks grouped per XCD (split-K with splitk % 8 == 0)
-  const float* ln_gamma; const float* ln_beta; unsigned short* ln_y; float* ln_mean; float* ln_rstd; float ln_eps;   // MFP_GEMM_LNORM_A
 #ifdef MFP_GEMM_TRACE
   unsigned long long* trace;  // [workgroup][16] s_memtime stamps of wave 0
 #endif
@@ -506,9 +505,6 @@ int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
   static const char* nv = getenv("MFP_WS_NARROW");   // experiment switch: 0 never, 1 N <= 256, 2 always
   const int narrow_mode = nv ? nv[0] - '0' : 1;
   const bool narrow = narrow_mode == 2 || (narrow_mode == 1 && a->N <= 256);
-  if (a->flags & MFP_GEMM_LNORM_A)   // LayerNorm fused into the X staging (ws_eligible: K 256 / 512, plain bf16)
-    return a->K == 256 ? launch_ws<8, 2, WS_EPI_PLAIN, false, true, false, true>(p, ncu, st)
-                       : launch_ws<16, 2, WS_EPI_PLAIN, false, true, false, true>(p, ncu, st);
   if (a->K == 256) {
     if (narrow) return launch_ws_epi<8, 2, true>(a, p, ncu, st);
     return launch_ws_epi<8, 2>(a, p, ncu, st);
@@ -608,24 +604,14 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   MFP_CHECK_ARG(a->in_dtype == MFP_F32 || a->in_dtype == MFP_BF16);
   MFP_CHECK_ARG(a->out_dtype == MFP_F32 || a->out_dtype == MFP_BF16);
   const int epc = a->in_dtype == MFP_BF16 ? 8 : 4;
-  const bool lnorm = (a->flags & MFP_GEMM_LNORM_A) != 0;
-  if (lnorm) {
-    MFP_CHECK_ARG(a->ln_gamma && a->ln_beta && a->ln_y && a->ln_mean && a->ln_rstd && a->ln_eps > 0.f);
-    MFP_CHECK_ARG(a->lda % 4 == 0 && ((uintptr_t)a->ln_y % 16) == 0);
-    if (!ws_eligible(a, a->splitk < 1 ? 1 : a->splitk)) {
-      mfp_set_error("mfp_gemm: MFP_GEMM_LNORM_A needs the weight-stationary kernel (bf16 weights, both operands "
-                    "k-major, K in {256, 512}, bias/ReLU epilogue, bf16 output)");
-      return MFP_EINVAL;
-    }
-  }
-  MFP_CHECK_ARG((lnorm || a->lda % epc == 0) && a->ldb % epc == 0 && a->ldc % 4 == 0 && a->N % 4 == 0);
+  MFP_CHECK_ARG(a->lda % epc == 0 && a->ldb % epc == 0 && a->ldc % 4 == 0 && a->N % 4 == 0);
   MFP_CHECK_ARG(((uintptr_t)a->C % 16) == 0);
   MFP_CHECK_ARG(a->N % epc == 0 || a->b_kmajor);
   if (a->a_kmajor) MFP_CHECK_ARG(a->K % epc == 0); else MFP_CHECK_ARG(a->M % epc == 0);
   if (a->b_kmajor) MFP_CHECK_ARG(a->K % epc == 0);
   MFP_CHECK_ARG(((uintptr_t)a->A % 16) == 0 && ((uintptr_t)a->B % 16) == 0);
   {  // staging loads use 32-bit byte offsets (raw buffer loads)
-    const long long esz = (a->in_dtype == MFP_BF16 && !lnorm) ? 2 : 4;
+    const long long esz = a->in_dtype == MFP_BF16 ? 2 : 4;
     const long long rows_a = a->a_kmajor ? a->M : a->K, rows_b = a->b_kmajor ? a->N : a->K;
     MFP_CHECK_ARG(rows_a * a->lda * esz < 0x7FFFFFF0ll && rows_b * a->ldb * esz < 0x7FFFFFF0ll);
   }
@@ -660,8 +646,6 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   p.out_bf16 = a->out_dtype == MFP_BF16; p.flags = a->flags;
   p.dropout_p = a->dropout_p; p.seed = a->seed; p.offset = a->offset; p.step_ptr = a->step_ptr;
   p.tiles_m = 0; p.tiles_n = 0; p.kz_xcd = 0;  // set per tile configuration in launch_one
-  p.ln_gamma = a->ln_gamma; p.ln_beta = a->ln_beta; p.ln_y = reinterpret_cast<unsigned short*>(a->ln_y);
-  p.ln_mean = a->ln_mean; p.ln_rstd = a->ln_rstd; p.ln_eps = a->ln_eps;
 #ifdef MFP_GEMM_TRACE
   p.trace = g_trace;
 #endif

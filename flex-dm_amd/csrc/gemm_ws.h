@@ -36,12 +36,7 @@ enum { WS_EPI_PLAIN = 0, WS_EPI_F32X = 1, WS_EPI_RELUBWD = 2 };
 // NARROW halves the workgroup's column slice (K = 256: 128 instead of 256 columns): half the weight
 // prologue per CU and twice the row tiles per workgroup -- for the N = 256 layers, whose 128 rows per
 // workgroup at full width are only 4 pipeline steps behind a 4 us prologue.
-// LNX (MFP_GEMM_LNORM_A): X is the f32 LAYER INPUT; the memory waves normalise each row while it sits
-// in their registers (a row's K/8 chunks are held by K/8 consecutive lanes of one wave: two shuffle
-// reductions, as csrc/layernorm.hip: mean, then the centred sum of squares), write bf16 LN(x) into the
-// LDS stage for the math waves and -- the workgroup of column slice 0 only -- to HBM for the backward
-// pass (y, mean, rstd).  Replaces the stand-alone ln_fwd launch in front of the QKV / FFN1 products.
-template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16, bool NARROW = false, bool LNX = false>
+template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16, bool NARROW = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, int slices) {
   constexpr int NQ = (KS == 8 ? 4 : (KS == 16 ? 2 : 1)) >> (NARROW ? 1 : 0), BM = 16 * MT, WBN = 16 * NQ, BN = 4 * WBN;
   constexpr int ROWB = 64 * KS, CPR = ROWB / 16, XSTAGE = BM * ROWB;      // X stage: [BM][K] bf16
@@ -49,9 +44,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
   constexpr int OS = OUT_BF16 ? 2 : 4, OROWB = BN * OS, OCPR = OROWB / 16, OSTAGE = BM * OROWB;
   constexpr int O_CH = BM * OCPR / 256;                                   // output chunks per memory thread
   constexpr bool PAIRED = OUT_BF16 && NQ >= 2;   // bf16 quads b, b+1 adjacent: one 16-byte stage unit
-  constexpr int XD = LNX ? 2 : (KS == 8 ? 4 : (KS <= 24 ? 2 : 1));   // X tiles in flight in registers (16 / 32-48 / 64 KB each; f32 rows: twice that)
-  constexpr int XR = LNX ? 2 : 1;       // 16-byte registers per staged chunk (8 f32 instead of 8 bf16)
-  static_assert(!LNX || (EPI == WS_EPI_PLAIN && OUT_BF16 && !NARROW && !DROPOUT && CPR <= 64), "LayerNorm-fused variant");
+  constexpr int XD = KS == 8 ? 4 : (KS <= 24 ? 2 : 1);   // X tiles in flight in registers (16 / 32-48 / 64 KB each)
   constexpr int ED = 4;                 // rotating epilogue-operand sets (3 live: in use + two in flight)
   static_assert((BM * CPR) % 256 == 0 && (BM * OCPR) % 256 == 0 && NQ >= 1, "tile/thread mismatch");
   constexpr unsigned int OOB = 0xFFFFFFF0u;
@@ -250,79 +243,32 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     // row's 16-byte chunk (slot ^ (row & 15)): the swizzle is applied on the SOURCE address so
     // the ds_write stays linear and the fragment ds_read_b128 (16 rows x one chunk per lane
     // group) is conflict-free.
-    // LNX: the thread keeps its LOGICAL chunk pc (its gamma / beta never change) and the swizzle moves to
-    // the LDS write address instead.
     unsigned int voa[A_CH];
     int lsa[A_CH], xrow[A_CH];
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) {
       const int ch = mt + c * 256, row = ch / CPR, pc = ch % CPR, sc = pc ^ (row & 15);
       xrow[c] = row;
-      voa[c] = LNX ? (unsigned int)((row * p.lda + pc * 8) * 4) : (unsigned int)((row * p.lda + sc * 8) * 2);
-      lsa[c] = row * ROWB + (LNX ? sc : pc) * 16;
+      voa[c] = (unsigned int)((row * p.lda + sc * 8) * 2);
+      lsa[c] = row * ROWB + pc * 16;
     }
-    u32x4 xa[XD][A_CH * XR];
-    auto gload = [&](u32x4 (&dst)[A_CH * XR], int t) {
+    u32x4 xa[XD][A_CH];
+    auto gload = [&](u32x4 (&dst)[A_CH], int t) {
       // branch-free: a dead tile / row past M turns the offset into 0xFFFFFFFF (out of range ->
       // zeros, no access); pure integer arithmetic so the step stays one basic block.
       const int row0 = row_beg + t * BM;
       const int live = (t - ntiles) >> 31;                 // -1 while t < ntiles
-      const int so = (row0 * p.lda * (LNX ? 4 : 2)) & live;
+      const int so = (row0 * p.lda * 2) & live;
 #pragma unroll
       for (int c = 0; c < A_CH; ++c) {
         const int ok = live & ((row0 + xrow[c] - p.M) >> 31);
         const unsigned int vo = voa[c] | ~(unsigned int)ok;
-        dst[c * XR] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, vo, so, 0));
-        if (LNX) dst[c * XR + XR - 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, vo | (ok ? 16u : 0u), so, 0));
+        dst[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, vo, so, 0));
       }
     };
-    // LNX constants: gamma / beta of the thread's 8 columns; y / mean / rstd go out from column slice 0 only
-    const int lpc = mt % CPR;
-    f32x4 lng[2], lnb[2];
-    if (LNX) {
-      lng[0] = *reinterpret_cast<const f32x4*>(p.ln_gamma + lpc * 8); lng[1] = *reinterpret_cast<const f32x4*>(p.ln_gamma + lpc * 8 + 4);
-      lnb[0] = *reinterpret_cast<const f32x4*>(p.ln_beta + lpc * 8);  lnb[1] = *reinterpret_cast<const f32x4*>(p.ln_beta + lpc * 8 + 4);
-    }
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(LNX ? (void*)p.ln_y : p.C, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc(LNX ? (void*)p.ln_mean : p.C, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(LNX ? (void*)p.ln_rstd : p.C, 0, 0x7FFFFFFF, 0x00020000);
-    const unsigned int ln_out_off = (LNX && s == 0) ? 0u : 0xFFFFFFFFu;
-    constexpr float INV_K = 1.0f / (float)(32 * KS);
-    auto lstore = [&](const u32x4 (&src)[A_CH * XR], int stage, int t) {
-      if constexpr (!LNX) {
+    auto lstore = [&](const u32x4 (&src)[A_CH], int stage) {
 #pragma unroll
-        for (int c = 0; c < A_CH; ++c) *reinterpret_cast<u32x4*>(xst + stage * XSTAGE + lsa[c]) = src[c];
-      } else {
-        const int row0 = row_beg + t * BM;
-        const int live = (t - ntiles) >> 31;
-#pragma unroll
-        for (int c = 0; c < A_CH; ++c) {
-          const f32x4 lo = __builtin_bit_cast(f32x4, src[c * XR]), hi = __builtin_bit_cast(f32x4, src[c * XR + XR - 1]);
-          float sum = (lo[0] + lo[1]) + (lo[2] + lo[3]) + (hi[0] + hi[1]) + (hi[2] + hi[3]);
-#pragma unroll
-          for (int o = CPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-          const float mu = sum * INV_K;
-          float d[8], q = 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { d[e] = lo[e] - mu; d[4 + e] = hi[e] - mu; }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) q += d[e] * d[e];
-#pragma unroll
-          for (int o = CPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-          const float rs = rsqrtf(q * INV_K + p.ln_eps);
-          float y[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { y[e] = d[e] * rs * lng[0][e] + lnb[0][e]; y[4 + e] = d[4 + e] * rs * lng[1][e] + lnb[1][e]; }
-          const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-          *reinterpret_cast<u32x4*>(xst + stage * XSTAGE + lsa[c]) = pk;
-          const int row = row0 + xrow[c];
-          const unsigned int bad = ln_out_off | ~(unsigned int)(live & ((row - p.M) >> 31));
-          __builtin_amdgcn_raw_buffer_store_b128(pk, rsy, ((unsigned int)(row * (32 * KS) + lpc * 8) * 2u) | bad, 0, 0);
-          const unsigned int sbad = bad | (lpc == 0 ? 0u : 0xFFFFFFFFu);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, mu), rsm, ((unsigned int)row * 4u) | sbad, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, rs), rsr, ((unsigned int)row * 4u) | sbad, 0, 0);
-        }
-      }
+      for (int c = 0; c < A_CH; ++c) *reinterpret_cast<u32x4*>(xst + stage * XSTAGE + lsa[c]) = src[c];
     };
 
     // ---- output plan: chunk ch = mt + 256 i -> stage row ch / OCPR, logical chunk ch % OCPR: a
@@ -374,7 +320,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
       }
     }
     if (EPI != WS_EPI_PLAIN) xload(0, 0);
-    lstore(xa[0], 0, 0);
+    lstore(xa[0], 0);
     gload(xa[0], XD);
     const float inv_keep = DROPOUT ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
     const unsigned long long rng_off =
@@ -388,7 +334,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(GemmParams p, int groups, 
     auto step = [&](auto tc, int t) {
       constexpr int cur = decltype(tc)::value & 1, xi = (decltype(tc)::value + 1) % XD;
       constexpr int eset = (decltype(tc)::value + ED - 1) % ED, pset = (decltype(tc)::value + 1) % ED;
-      lstore(xa[xi], cur ^ 1, t + 1);   // X(t+1): loaded XD steps ago
+      lstore(xa[xi], cur ^ 1);   // X(t+1): loaded XD steps ago
       gload(xa[xi], t + 1 + XD);
       const int row0 = row_beg + (t - 1) * BM + orow0;
       const int tok = ~((t - 1) >> 31);            // 0 at step 0 (no tile -1)
@@ -452,10 +398,6 @@ inline bool ws_eligible(const mfp_gemm_args* a, int splitk) {
   if (a->K != 256 && a->K != 512 && a->K != 768) return false;
   if (a->K == 768 && (a->flags & ~(MFP_GEMM_BIAS | MFP_GEMM_RELU))) return false;   // plain epilogue only
   const int f = a->flags;
-  if (f & MFP_GEMM_LNORM_A) {   // LayerNorm-fused X staging: bias / ReLU epilogue, bf16 out, a full row per 32 / 64 lanes
-    if ((a->K != 256 && a->K != 512) || (f & ~(MFP_GEMM_LNORM_A | MFP_GEMM_BIAS | MFP_GEMM_RELU)) || a->out_dtype != MFP_BF16) return false;
-    if ((long long)a->M * a->K * 2 >= 0x7FFFFFF0ll) return false;
-  }
   if (f & (MFP_GEMM_COLSUM_A | MFP_GEMM_ROWSKIP_A)) return false;
   const bool f32x = (f & (MFP_GEMM_RESIDUAL | MFP_GEMM_ACCUM)) != 0;
   if ((f & MFP_GEMM_RESIDUAL) && (f & MFP_GEMM_ACCUM)) return false;
@@ -469,14 +411,14 @@ inline bool ws_eligible(const mfp_gemm_args* a, int splitk) {
   return true;
 }
 
-template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16, bool NARROW = false, bool LNX = false>
+template <int KS, int MT, int EPI, bool DROPOUT, bool OUT_BF16, bool NARROW = false>
 int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
   constexpr int NQ = (KS == 8 ? 4 : (KS == 16 ? 2 : 1)) >> (NARROW ? 1 : 0), BN = 64 * NQ, XSTAGE = 16 * MT * 64 * KS, OSTAGE = 16 * MT * BN * (OUT_BF16 ? 2 : 4);
   constexpr int lds = 2 * XSTAGE + 2 * OSTAGE;
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16, NARROW, LNX>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16, NARROW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_gemm: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
@@ -493,7 +435,7 @@ int launch_ws(const GemmParams& p, int ncu, hipStream_t st) {
     groups = (ncu / slices) / 8 * 8;
     if (groups < 8) groups = 8;
   }
-  hipLaunchKernelGGL((gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16, NARROW, LNX>), dim3(groups * slices), dim3(512), lds, st, p,
+  hipLaunchKernelGGL((gemm_ws_kernel<KS, MT, EPI, DROPOUT, OUT_BF16, NARROW>), dim3(groups * slices), dim3(512), lds, st, p,
                      groups, slices);
   return MFP_OK;
 }

@@ -15,7 +15,6 @@ MFP_F32, MFP_BF16 = 0, 1
 
 GEMM_BIAS, GEMM_RELU, GEMM_RESIDUAL, GEMM_DROPOUT = 1, 2, 4, 8
 GEMM_ACCUM, GEMM_ROWSKIP, GEMM_RELU_BWD, GEMM_COLSUM_A, GEMM_ROWSKIP_A = 16, 32, 64, 128, 256
-GEMM_LNORM_A = 512
 MAX_LOSS_KEYS = 16
 
 LIB_NAME = "libmfp_hip.so"
@@ -40,8 +39,6 @@ class GemmArgs(Structure):
         ("a_kmajor", c_int32), ("b_kmajor", c_int32),
         ("in_dtype", c_int32), ("out_dtype", c_int32), ("flags", c_int32), ("splitk", c_int32),
         ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64), ("step_ptr", c_void_p),
-        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_y", c_void_p), ("ln_mean", c_void_p),
-        ("ln_rstd", c_void_p), ("ln_eps", c_float),
     ]
 
 

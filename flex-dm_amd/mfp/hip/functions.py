@@ -24,9 +24,6 @@ NUM_HEADS = 8
 # bf16 path: the weight gradients of a block (of the heads, of the encoder) as ONE grouped launch with the
 # split-K reduction inside it (csrc/gemm_wgg.h); 0 = one mfp_gemm + reduce kernel per product (A/B switch)
 WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
-# bf16 path, d_model 256 / 512: LayerNorm forward fused into the X staging of the product behind it (QKV,
-# FFN1: MFP_GEMM_LNORM_A, csrc/gemm_ws.h); 0 = stand-alone ln_fwd launch + product (A/B switch)
-LN_FUSE = os.environ.get("MFP_LN_FUSE", "0") == "1"
 # bf16 path, d_model 256: LN2 + FFN1 + ReLU + FFN2 + dropout + residual of a block as ONE launch, and the two
 # input-gradient products of the same half as one launch (csrc/block_fused.hip); 0 = ln_fwd + two products,
 # two dgrad products (A/B switch)
@@ -47,13 +44,6 @@ def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False, w8=None):
     if w8 is not None:      # e4m3 operands, per-tensor scales (csrc/gemm_fp8.hip); y stays bf16 for the backward pass
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, cdt)
         return ops.gemm_fp8(y, w8[0], w8[1], T, N, D, bias=bias, relu=relu), y, mean, rstd
-    if LN_FUSE and cdt == torch.bfloat16 and D in (256, 512) and T * D * 2 < 0x7FFFFFF0:
-        y = torch.empty((T, D), dtype=cdt, device=x.device)
-        mean = torch.empty((T,), dtype=torch.float32, device=x.device)
-        rstd = torch.empty((T,), dtype=torch.float32, device=x.device)
-        out = ops.gemm(x, W, T, N, D, a_kmajor=True, b_kmajor=True, bias=bias, relu=relu, out_dtype=cdt,
-                       ln=(gamma, beta, y, mean, rstd))
-        return out, y, mean, rstd
     y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, cdt)
     out = ops.gemm(y, W, T, N, D, a_kmajor=True, b_kmajor=True, bias=bias, relu=relu, out_dtype=cdt)
     return out, y, mean, rstd

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_A, GEMM_DROPOUT, GEMM_LNORM_A, GEMM_RELU, GEMM_RELU_BWD,
+from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_A, GEMM_DROPOUT, GEMM_RELU, GEMM_RELU_BWD,
                GEMM_RESIDUAL, GEMM_ROWSKIP, GEMM_ROWSKIP_A, MFP_BF16, MFP_F32, GemmArgs, LossKey,
                MaskCol, WgradJob, check, load)
 
@@ -118,13 +118,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
          relu_bwd_aux: Optional[torch.Tensor] = None, colsum: Optional[torch.Tensor] = None,
          rowskip_a: Optional[torch.Tensor] = None, splitk: int = 1,
          step_ptr: Optional[torch.Tensor] = None,
-         lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
-         ln: Optional[tuple] = None) -> torch.Tensor:
-    """``out[M,N] = epilogue(op(A) @ op(B))`` -- see ``mfp_gemm`` in include/mfp_hip.h.
-    ``ln`` = (gamma, beta, y_out bf16 [M,K], mean_out [M], rstd_out [M]): A is the f32 input of a
-    LayerNormalization; the kernel multiplies LN(A) and also writes y / mean / rstd (MFP_GEMM_LNORM_A)."""
+         lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None) -> torch.Tensor:
+    """``out[M,N] = epilogue(op(A) @ op(B))`` -- see ``mfp_gemm`` in include/mfp_hip.h."""
     lib = load()
-    assert ln is not None or A.dtype == B.dtype, (A.dtype, B.dtype)
+    assert A.dtype == B.dtype, (A.dtype, B.dtype)
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
     a = GemmArgs()
@@ -136,11 +133,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
     a.a_kmajor, a.b_kmajor = int(a_kmajor), int(b_kmajor)
     a.in_dtype, a.out_dtype = dt_code(B.dtype), dt_code(out.dtype)
     flags = 0
-    if ln is not None:
-        assert A.dtype == torch.float32 and B.dtype == torch.bfloat16 and a_kmajor and b_kmajor
-        flags |= GEMM_LNORM_A
-        a.ln_gamma, a.ln_beta, a.ln_y, a.ln_mean, a.ln_rstd = (_ptr(t) for t in ln)
-        a.ln_eps = LN_EPS
     if bias is not None:
         flags |= GEMM_BIAS
         a.bias = _ptr(bias)
@@ -179,7 +171,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
             name = "gemm_kernel<%s,%s,%s>" % ("bf16" if A.dtype == torch.bfloat16 else "f32", "Ak" if a_kmajor else "Am",
                                               "Bk" if b_kmajor else "Bn")
     # algorithmic bytes: both operands once, the result once, plus the epilogue operands it reads
-    nbytes = M * K * _esz(A) + N * K * _esz(B) + M * N * _esz(out) + (M * K * 2 if ln is not None else 0)
+    nbytes = M * K * _esz(A) + N * K * _esz(B) + M * N * _esz(out)
     nbytes += M * N * 4 * ((residual is not None) + bool(accum)) + (M * N * _esz(relu_bwd_aux) if relu_bwd_aux is not None else 0)
     with _timed(name, 2 * M * N * K, nbytes):
         check(lib.mfp_gemm(ctypes.byref(a), _stream()), "mfp_gemm")

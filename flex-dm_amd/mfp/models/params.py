@@ -30,6 +30,8 @@ WS_K = (256, 512)   # contraction lengths the weight-stationary GEMM takes with 
 NUM_HEADS = 8  # transformer.py:147, never overridden by Blocks (transformer.py:263-270)
 
 
+from mfp.models.architecture.utils import variable_l2
+
 class Segment:
     __slots__ = ("name", "offset", "shape", "l2", "transposed", "size")
 
@@ -230,7 +232,8 @@ class ParamStore:
                 self._fp8_tensors += [(q.offset, 3 * D * D), (f.offset, f.size)]
             self.scale8 = torch.ones(len(self._fp8_tensors), dtype=torch.float32, device=device)
         self.l2 = l2
-        self.seg_l2 = torch.tensor([(l2 or 0.0) if s.l2 else 0.0 for s in layout.segments.values()],
+        # (s.l2 is False for the zero pad rows / special rows that are not Keras variables)
+        self.seg_l2 = torch.tensor([variable_l2(s.name, l2) if s.l2 else 0.0 for s in layout.segments.values()],
                                    dtype=torch.float32, device=device)
         self.rowoff = torch.tensor(layout.rowoff, dtype=torch.int32, device=device)
         # autograd anchor: the custom Functions need one differentiable input even when the data

@@ -62,12 +62,7 @@ enum {
   MFP_GEMM_ROWSKIP = 32,    /* rows with rowcode[m]!=0 contribute 0 (encoder.py:174-175) */
   MFP_GEMM_RELU_BWD = 64,   /* result *= (aux[m][n] > 0), aux in cdt, ld = ldc */
   MFP_GEMM_COLSUM_A = 128,  /* wgrad only: also colsum[m] = sum_k A[k][m] (bias grad of dY) */
-  MFP_GEMM_ROWSKIP_A = 256, /* wgrad only: rows k of A with rowcode[k]!=0 count as zero */
-  MFP_GEMM_LNORM_A = 512    /* forward Dense behind a LayerNormalization (transformer.py:216-217,222-223):
-                             * A is the f32 layer input x [M][lda]; the kernel normalises each row on the fly
-                             * (eps ln_eps, ln_gamma / ln_beta f32 [K]), multiplies LN(x) rounded to bf16, and
-                             * also writes ln_y = bf16 LN(x) [M][K], ln_mean / ln_rstd f32 [M] for the backward
-                             * pass.  bf16 weights, K in {256, 512}, bias / ReLU epilogue only, bf16 output. */
+  MFP_GEMM_ROWSKIP_A = 256  /* wgrad only: rows k of A with rowcode[k]!=0 count as zero */
 };
 
 typedef struct mfp_gemm_args {
@@ -92,12 +87,6 @@ typedef struct mfp_gemm_args {
   uint64_t seed;
   uint64_t offset;
   const int32_t* step_ptr; /* device; RNG offset += *step_ptr * MFP_RNG_STEP_STRIDE (graph replay) */
-  const float* ln_gamma;   /* MFP_GEMM_LNORM_A */
-  const float* ln_beta;
-  void* ln_y;
-  float* ln_mean;
-  float* ln_rstd;
-  float ln_eps;
 } mfp_gemm_args;
 
 int mfp_gemm(const mfp_gemm_args* args /*host*/, mfp_stream_t stream);

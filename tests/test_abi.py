@@ -37,8 +37,8 @@ def test_struct_layouts_match_header():
     from mfp import hip
     assert ctypes.sizeof(hip.LossKey) == 48
     assert ctypes.sizeof(hip.MaskCol) == 72
-    # pointers, size_t, ints, float(+pad), u64 x2, ptr, then the MFP_GEMM_LNORM_A block: 5 pointers + float(+pad)
-    assert ctypes.sizeof(hip.GemmArgs) == 8 * 9 + 8 + 4 * 12 + 4 + 4 + 8 + 8 + 8 + 5 * 8 + 8
+    # pointers, size_t, ints, float(+pad), u64 x2, ptr
+    assert ctypes.sizeof(hip.GemmArgs) == 8 * 9 + 8 + 4 * 12 + 4 + 4 + 8 + 8 + 8
     assert ctypes.sizeof(hip.WgradJob) == 5 * 8 + 5 * 4 + 4
     assert hip.GemmArgs.M.offset == 80 and hip.GemmArgs.seed.offset % 8 == 0
 

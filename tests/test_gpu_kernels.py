@@ -708,40 +708,6 @@ def test_wgrad_group(T, splitk):
     assert int(ops._wgrad_tickets(DEV).abs().sum()) == 0
 
 
-@pytest.mark.parametrize("T,K,N,relu", [(4096, 256, 768, False), (3000, 256, 512, True), (2100, 512, 1536, False),
-                                        (1030, 512, 1024, True), (50, 256, 768, False)])
-def test_gemm_layernorm_fused(T, K, N, relu):
-    """MFP_GEMM_LNORM_A: Dense(LayerNormalization(x)) in one launch (transformer.py:216-217,222-223) -- the
-    product, the saved bf16 LN(x) and the row statistics against a double reference, and against the
-    stand-alone ln_fwd + product pair (same bf16 rounding point: y is rounded before the product)."""
-    ops = _ops()
-    g = torch.Generator().manual_seed(T + N)
-    x = (torch.randn(T, K, generator=g) * (1.0 + torch.rand(T, 1, generator=g)) + 0.5 * torch.randn(T, 1, generator=g))
-    gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
-    W = bf16_round(torch.randn(N, K, generator=g) * 0.06)
-    bias = torch.randn(N, generator=g) * 0.1
-    xd, Wd = x.to(DEV), W.to(DEV, torch.bfloat16)
-    y = torch.full((T, K), 9.0, dtype=torch.bfloat16, device=DEV)
-    mean, rstd = torch.full((T,), 9.0, device=DEV), torch.full((T,), 9.0, device=DEV)
-    out = ops.gemm(xd, Wd, T, N, K, a_kmajor=True, b_kmajor=True, bias=bias.to(DEV), relu=relu, out_dtype=torch.bfloat16,
-                   ln=(gamma.to(DEV), beta.to(DEV), y, mean, rstd))
-    mu = x.double().mean(1, keepdim=True)
-    var = ((x.double() - mu) ** 2).mean(1, keepdim=True)
-    yd = (x.double() - mu) / torch.sqrt(var + 1e-3) * gamma.double() + beta.double()
-    assert_close(mean, mu[:, 0], 1e-5, 1e-5, "mean")
-    assert_close(rstd, 1.0 / torch.sqrt(var[:, 0] + 1e-3), 1e-5, 1e-5, "rstd")
-    assert_close(y, yd, 1e-2, 8e-3, "saved LN(x)")               # one bf16 rounding
-    want = y.float().cpu().double() @ W.double().t() + bias.double()   # the product of the ROUNDED y, as the unfused pair
-    if relu:
-        want = want.clamp(min=0)
-    assert_close(out, want, 2e-2, 1e-2, "fused product")
-    y2, mean2, rstd2 = ops.layernorm_fwd(xd, gamma.to(DEV), beta.to(DEV), torch.bfloat16)
-    out2 = ops.gemm(y2, Wd, T, N, K, a_kmajor=True, b_kmajor=True, bias=bias.to(DEV), relu=relu, out_dtype=torch.bfloat16)
-    assert (y.float() - y2.float()).abs().max().item() <= 0.04     # at most one bf16 ulp apart at |y| <= 4
-    assert (y != y2).float().mean().item() < 0.01
-    assert_close(out, out2.float().cpu().double(), 3e-2, 2e-2, "fused vs unfused pair")
-
-
 @pytest.mark.parametrize("M,N,K,relu", [(1000, 1536, 512, False), (2050, 1024, 512, True), (300, 768, 256, False), (64, 8, 16, True)])
 def test_gemm_fp8(M, N, K, relu):
     """mfp_gemm_fp8 (BASELINE config c5): e4m3 operands with per-tensor scales 448 / amax, activations

@@ -141,6 +141,16 @@ def test_param_layout_and_state_dict_roundtrip():
     for name, v in params.items():
         np.testing.assert_array_equal(back[name].numpy(), v)
     assert float(st.seg_l2.max()) == pytest.approx(1e-2) and float(st.seg_l2.min()) == 0.0   # LN gamma/beta unregularised
+    # the coefficient table comes from the reference-shaped regulariser options (architecture/utils.py:8-22): Dense
+    # kernels and biases and embedding tables are regularised, LayerNormalization variables and pad rows are not
+    from mfp.models.architecture.utils import make_dense_options, make_emb_options, variable_l2
+    assert make_dense_options(None) == {} and make_emb_options(None) == {}
+    assert make_dense_options(0.5) == {"kernel": 0.5, "bias": 0.5} and make_emb_options(0.5) == {"embeddings": 0.5}
+    for seg, c in zip(st.layout.segments.values(), st.seg_l2.tolist()):
+        kind = seg.name.rsplit("/", 1)[-1]
+        want = 1e-2 if (seg.l2 and kind in ("kernel", "bias", "embeddings")) else 0.0
+        assert c == pytest.approx(want), seg.name
+        assert variable_l2(seg.name, None) == 0.0
 
 
 def test_task_probabilities():
