@@ -129,7 +129,7 @@ def test_bf16_deviation_from_oracle():
     want = float(info["data_loss"])
     rel = abs(float(loss) - want) / want
     print("bf16 loss %.5f vs f64 oracle %.5f (rel %.2e)" % (float(loss), want, rel))
-    assert rel < 5e-3
+    assert rel < BF16_LOSS_BUDGET       # north_star's 1e-3 on the total loss; measured 1.5e-4 here
     for k in keys:
         err = (outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item()
         assert err < 0.1, (k, err)
@@ -413,7 +413,10 @@ def test_shuffled_set_position_token_parity_and_training():
 # rounds every MFMA operand to 8 mantissa bits; its loss deviation is MEASURED here, recorded under
 # gpurun_out/parity_timed_shape.json, and bounded by BF16_LOSS_BUDGET.
 F32_LOSS_TOL = 1e-5      # measured 5e-8 (gpurun_out/parity_timed_shape.json, r02)
-BF16_LOSS_BUDGET = 1e-3  # north_star's bound, on the TOTAL loss; measured 4e-4 (c2 mix) / 6e-4 (c3 mix)
+BF16_LOSS_BUDGET = 1e-3  # north_star's bound, on the TOTAL loss; measured 4.7e-4 (c2 mix) / 5.6e-4 (c3 mix)
+# Single keys: a key's loss is the mean of a few hundred masked fields at B = 4-5, and its bf16
+# deviation is dominated by a handful of near-tie logits; measured worst key 1.85e-3 (c2) / 2.42e-3 (c3), budget 3e-3
+BF16_KEY_BUDGET = 3e-3
 
 
 def _timed_shape_case(mix, B, S=128, D=256, L=4):
@@ -513,7 +516,7 @@ def test_timed_shape_parity_vs_oracle(dtype, mix, B):
         assert logit_err < 5e-4 and worst_cos > 0.99999
     else:
         assert rel <= BF16_LOSS_BUDGET, rel
-        assert max(key_rel.values()) <= 5e-3, key_rel          # single keys (few masked fields each): measured <= 2.4e-3
+        assert max(key_rel.values()) <= BF16_KEY_BUDGET, key_rel
         assert worst_cos > 0.98 and excess <= 1.0, (worst_cos, excess)
 
 

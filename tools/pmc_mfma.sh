@@ -28,7 +28,7 @@ for k, c in agg.items():
     rows.append((clk, k, cnt[k], 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / clk, 100.0 * c["SQ_LDS_IDX_ACTIVE"] / 256.0 / clk,
                  100.0 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0)))
 tot = sum(r[0] for r in rows)
-with open("gpurun_out/r02_pmc_mfma_lds.txt", "w") as f:
+with open("gpurun_out/${TAG:-r03}_pmc_mfma_lds.txt", "w") as f:
     f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE over bench.py (c2, bf16)\n")
     f.write("# mfma_busy%% = matrix-pipe busy cycles / (1024 SIMDs x kernel clocks); lds_busy%% = LDS-array cycles / (256 CUs x kernel clocks)\n")
     f.write("%-66s %7s %9s %10s %9s %11s\n" % ("kernel", "calls", "time%", "mfma_busy%", "lds_busy%", "lds_confl%"))
@@ -36,5 +36,5 @@ with open("gpurun_out/r02_pmc_mfma_lds.txt", "w") as f:
         f.write("%-66s %7d %9.2f %10.1f %9.1f %11.1f\n" % (k, n, 100 * clk / tot, m, l, b))
     wm = sum(r[0] * r[3] for r in rows) / tot
     f.write("# time-weighted matrix-pipe busy over the whole step: %.1f %%\n" % wm)
-print(open("gpurun_out/r02_pmc_mfma_lds.txt").read())
+print(open("gpurun_out/${TAG:-r03}_pmc_mfma_lds.txt").read())
 PY
