@@ -1,0 +1,430 @@
+// Attention half of a DeepSVG block, forward, in ONE launch (reference architecture/transformer.py:211-221, 60-99):
+//
+//     x1 = x + Dropout( MHSA( LN1(x) ) Wo^T + bo )            MHSA: 8 heads of 32, key-padding mask
+//
+// for d_model 256 and documents of exactly 128 positions: a 128-row tile IS a document, so its attention is local to
+// the workgroup that owns the tile.  Saved for the backward pass exactly as the three launches it replaces save them
+// (qkv_fused_kernel, attn_fwd_bf16, the output projection on gemm_ws_kernel): y1 = LN1(x) (bf16), mean / rstd,
+// qkv (bf16 [T][768]), a = softmax(QK^T / sqrt(32)) V (bf16 [T][256]), lse (f32 [B][8][128]).
+//
+// Bytes per token: x 1024 read (+ 1024 re-read for the residual, a hit in the memory-side cache), y1 512, qkv 1536,
+// a 512, x1 1024 written = 5.6 KB against 7.7 KB for the three launches (qkv and a are not read back); one launch
+// boundary instead of three, and the three kernels' prologue / epilogue phases overlap with products of other stages.
+//
+// Machine = csrc/block_fused.hip's (activation-stationary, 8 waves, one 128-row tile per workgroup):
+//   * LN1 in the MFMA operand layout, y1 through a swizzled LDS image, fragments of this wave's two row tiles in 64
+//     registers for the whole kernel;
+//   * the 512 KB of Wq | Wk | Wv | Wo stream L2 -> LDS (LDS-DMA, counted waits) in 16 chunks of 32 KB through three
+//     buffers, ordered q_p, k_p, v_p, o_p for the head pairs p = 0..3: a q / k / v chunk = 64 output columns = TWO
+//     heads; its bf16 result goes into an LDS image [128 rows][128 B] (and from there to HBM as qkv);
+//   * after v_p: attention of heads 2p, 2p + 1 straight out of the three images -- wave w owns queries 16 w .. + 15:
+//     S^T = K Q^T in registers (lane = query), softmax = registers + two cross-lane steps, O^T = V^T P^T with P from
+//     registers and V^T by transposing reads; the output tile overwrites the wave's own rows of the q image;
+//   * o_p = Wo[:, 64 p .. + 63] ([256][128 B]): x1 accumulators (64 registers, the layout of mlp_fused_kernel's second
+//     product) += a_p Wo_p^T; after o_3: x1 = x + dropout(acc + bo), 16-byte stores.
+// Images with 128-byte rows are swizzled by ((row >> 1) & 7) on the 16-byte slot: b128 fragment reads, the
+// transposing reads and the 8-byte accumulator-layout writes are all bank-conflict-free.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+struct AttnBlockParams {
+  const float* x; const float* gamma; const float* beta;
+  const unsigned short* Wqkv; const float* bqkv;       // [768][256] bf16 (out, in), f32 [768]
+  const unsigned short* Wo; const float* bo;           // [256][256] bf16 (out, in), f32 [256]
+  const int* nvalid;                                   // [B]
+  unsigned short* y1; float* mean; float* rstd;
+  unsigned short* qkv; unsigned short* a; float* lse; float* x1;
+  int T, H; float eps, scale;
+  float dropout_p; unsigned long long seed, offset; const int* step_ptr;
+};
+
+constexpr int AB_D = 256, AB_ROWS = 128, AB_CHUNKS = 16;
+constexpr int AB_IMG = AB_ROWS * 128;                  // [128][128 B]: 16 KB
+constexpr int AB_WS_OFF = 3 * AB_IMG;                  // q | k | v images first: the LN image spans them + half of ring buffer 0
+constexpr int AB_WS_B = 32768;
+constexpr int AB_VEC_OFF = AB_WS_OFF + 3 * AB_WS_B;    // bqkv (3 KB) | gamma (1 KB) | beta (1 KB) | bo (1 KB) | Mb (512 B)
+constexpr int AB_LDS = AB_VEC_OFF + (768 + 3 * 256 + 128) * 4;
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void ab_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ab_static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }      // slot XOR of the 128-byte-row images
+
+__device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
+  const u32x4 r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const Im = smem;                      // Im + t * AB_IMG, t = 0 (q, then a), 1 (k), 2 (v)
+  unsigned char* const Ws = smem + AB_WS_OFF;
+  const float* const Bq = reinterpret_cast<const float*>(smem + AB_VEC_OFF);
+  const float* const Gs = Bq + 768;
+  const float* const Bs = Gs + AB_D;
+  const float* const Bo = Bs + AB_D;
+  float* const Mb = reinterpret_cast<float*>(smem + AB_VEC_OFF + (768 + 3 * 256) * 4);
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rp = wave & 3, nh = wave >> 2;
+  const int doc = blockIdx.x, row0 = doc * AB_ROWS;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  // (the step counter and the document's length are read first: their loads must not sit between the counted waits)
+  const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
+  const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[doc]);
+
+  const unsigned int xbytes = (unsigned int)p.T * (AB_D * 4);
+  const __amdgpu_buffer_rsrc_t rs_wq = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wqkv), 0, 768 * AB_D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wo), 0, AB_D * AB_D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(p.x1, 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y1, 0, xbytes / 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(p.qkv, 0, (unsigned int)p.T * (768 * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(p.a, 0, xbytes / 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(p.lse, 0, (unsigned int)(p.T / AB_ROWS) * (unsigned int)p.H * AB_ROWS * 4u, 0x00020000);
+
+  // ---- weight chunk c = 4 p + t.  t = 0, 1, 2 (q, k, v): Wqkv rows t * 256 + 64 p .. + 63, all 256 k -> image [64][512 B],
+  // slot ^ (row & 15) (2 rows per 1 KB piece).  t = 3 (o): Wo rows 0 .. 255, k = 64 p .. + 63 -> image [256][128 B],
+  // slot ^ ((row >> 1) & 7) (8 rows per piece).  Four pieces per wave and chunk.
+  const unsigned int w1off = (unsigned int)((wave * 8 + (lane >> 5)) * 512 + (((lane & 31) ^ ((wave & 1) * 8 + (lane >> 5))) << 4));
+  auto wload = [&](int c) {
+    const int pr = c >> 2, t = c & 3;
+    unsigned char* dst = Ws + ((c + 1) % 3) * AB_WS_B + wave * 4096;
+    if (t < 3) {
+      const int base = (t * 256 + pr * 64) * (AB_D * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wq, (lds_u8*)(dst + i * 1024), 16, w1off ^ (i << 5), base + i * 1024, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const unsigned int vo = (unsigned int)(row * (AB_D * 2) + (((lane & 7) ^ isw(row)) << 4));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wo, (lds_u8*)(dst + i * 1024), 16, vo, pr * 128, 0, 0);
+      }
+    }
+  };
+  wload(0);
+  wload(1);
+  if (tid < (768 + 3 * 256) / 4) {     // per-column vectors -> LDS
+    const float* src = tid < 192 ? p.bqkv + tid * 4 : tid < 256 ? p.gamma + (tid - 192) * 4
+                     : tid < 320 ? p.beta + (tid - 256) * 4 : p.bo + (tid - 320) * 4;
+    *reinterpret_cast<f32x4*>(smem + AB_VEC_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(src);
+  }
+  if (tid < 128) Mb[tid] = tid < nv ? 0.f : -1e9f * LOG2E;      // additive key term (exp2 domain); S = 128: no row past S
+
+  // ---- LN1 (as qkv_fused_kernel): wave w normalises rows 16 w .. + 15 in the MFMA operand layout
+  bf16x8 xf[2][8];
+  {
+    const int lrow = wave * 16 + li, row = row0 + lrow;
+    float v[8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const unsigned int vo = (unsigned int)row * (AB_D * 4) + g * 32;
+      const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + ks * 128, 0, 0));
+      const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + ks * 128 + 16, 0, 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[ks][e] = a[e]; v[ks][4 + e] = b[e]; s += a[e] + b[e]; }
+    }
+    __syncthreads();      // gamma / beta are in LDS
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mu = s * (1.0f / AB_D);
+    float qq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[ks][e] -= mu; qq += v[ks][e] * v[ks][e]; }
+    qq += __shfl_xor(qq, 16, 64);
+    qq += __shfl_xor(qq, 32, 64);
+    const float rs = rsqrtf(qq * (1.0f / AB_D) + p.eps);
+    if (g == 0) { p.mean[row] = mu; p.rstd[row] = rs; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int col = ks * 32 + 8 * g;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gs + col), g1 = *reinterpret_cast<const f32x4*>(Gs + col + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + col), b1 = *reinterpret_cast<const f32x4*>(Bs + col + 4);
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] = v[ks][e] * rs * g0[e] + b0[e]; y[4 + e] = v[ks][4 + e] * rs * g1[e] + b1[e]; }
+      const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+      *reinterpret_cast<u32x4*>(smem + lrow * 512 + (((ks * 4 + g) ^ li) << 4)) = pk;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 512 * i, r = idx >> 5, c16 = idx & 31;
+    const u32x4 yv = *reinterpret_cast<const u32x4*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4));
+    __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y, (unsigned int)(row0 + r) * (AB_D * 2) + c16 * 16, 0, 0);
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rp * 32 + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();       // chunks 0, 1 are in LDS (first memory operations of the kernel); the LN image has been read
+
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+  // an image's rows -> HBM in 128-byte pieces: t = 0, 1, 2 -> qkv columns t * 256 + 64 pr .. ; t = 3 -> a columns 64 pr ..
+  auto stash = [&](int pr, int t) {
+    const unsigned char* img = Im + (t == 3 ? 0 : t) * AB_IMG;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, r = idx >> 3, c16 = idx & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * 128 + ((c16 ^ isw(r)) << 4));
+      if (t < 3) __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, (unsigned int)(row0 + r) * (768 * 2) + t * 512 + pr * 128 + c16 * 16, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(v, rs_a, (unsigned int)(row0 + r) * (AB_D * 2) + pr * 128 + c16 * 16, 0, 0);
+    }
+  };
+
+  f32x4 acc2[8][2];      // x1 accumulators: column tile T = (ct >> 2) * 8 + nh * 4 + (ct & 3), rows 32 rp + 16 rt + li
+  const float c2 = p.scale * LOG2E;
+
+  auto chunk = [&](auto cc_) {
+    constexpr int c = decltype(cc_)::value;
+    constexpr int pr = c >> 2, t = c & 3;
+    if (c + 2 < AB_CHUNKS) wload(c + 2);
+    // stores of finished images, AFTER the weight loads (counted waits): q at the head of k, k at the head of v, v and a
+    // at the head of o (behind the barrier that ended the attention of the pair)
+    if (t == 1) stash(pr, 0);
+    if (t == 2) stash(pr, 1);
+    if (t == 3) { stash(pr, 2); stash(pr, 3); }
+    const unsigned char* wb = Ws + ((c + 1) % 3) * AB_WS_B;
+    if (t < 3) {
+      // 64 columns of q / k / v: acc[nt][rt], wave (rp, nh) owns column tiles 2 nh + nt of the chunk
+      const unsigned char* wa = wb + ((nh * 2) * 16 + li) * 512;
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 wf[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[0]);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+      }
+      unsigned char* img = Im + t * AB_IMG;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(Bq + t * 256 + pr * 64 + (nh * 2 + nt) * 16 + 4 * g);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = rp * 32 + rt * 16 + li;
+          const u32x2 pk = {pack_bf16x2(acc[nt][rt][0] + bb[0], acc[nt][rt][1] + bb[1]), pack_bf16x2(acc[nt][rt][2] + bb[2], acc[nt][rt][3] + bb[3])};
+          *reinterpret_cast<u32x2*>(img + row * 128 + ((((nh * 2 + nt) * 2 + (g >> 1)) ^ isw(row)) << 4) + (g & 1) * 8) = pk;
+        }
+      }
+    } else {
+      // x1 accumulators += a_pair (image 0) Wo[:, 64 pr .. + 63]^T: K = 64, two k-steps
+      const unsigned char* ai = Im;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 hf[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = rp * 32 + rt * 16 + li;
+          hf[rt] = *reinterpret_cast<const bf16x8*>(ai + row * 128 + (((ks * 4 + g) ^ isw(row)) << 4));
+        }
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const int wrow = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + li;
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + wrow * 128 + (((ks * 4 + g) ^ isw(wrow)) << 4));
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf[rt], (pr == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[ct][rt], 0, 0, 0);
+        }
+      }
+    }
+    // chunk c + 1 has landed when no more operations are outstanding than were issued after its loads (memory
+    // operations retire in order): the stores at the head of chunk c - 1 (k, v: 2; o: 4), the two lse stores of an
+    // attention phase behind chunk c - 1 (v), the 4 loads of chunk c + 2, the stores at the head of this chunk; chunk 0:
+    // the 10 stores of the prologue (chunk 1 landed there: every x load issued after it has been consumed)
+    if (c + 1 < AB_CHUNKS) {
+      constexpr int tp = (c - 1) & 3;
+      constexpr int st_prev = c == 0 ? 0 : (tp == 1 || tp == 2) ? 2 : tp == 3 ? 4 : 0;
+      constexpr int at_prev = (c >= 1 && tp == 2) ? 2 : 0;
+      constexpr int st_this = (t == 1 || t == 2) ? 2 : t == 3 ? 4 : 0;
+      constexpr int allowed = c == 0 ? 14 : st_prev + at_prev + (c + 2 < AB_CHUNKS ? 4 : 0) + st_this;
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (t == 2) {
+      // ---- attention of heads 2 pr, 2 pr + 1: wave `wave` owns queries 16 wave .. + 15 (rows of all three images)
+      const unsigned char* qi = Im;
+      const unsigned char* ki = Im + AB_IMG;
+      const unsigned char* vi = Im + 2 * AB_IMG;
+      const int qrow = 16 * wave + li;
+      // (the output tile of a head overwrites this wave's own rows of the q image: nobody else reads these rows -- their q
+      //  columns left for HBM at the head of the k chunk)
+      unsigned char* ai = Im;
+#pragma nounroll
+      for (int hh = 0; hh < 2; ++hh) {
+        // (head 0's output goes over the head-0 columns of this wave's q rows; head 1's q columns are still intact)
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(qi + qrow * 128 + (((hh * 4 + g) ^ isw(qrow)) << 4));
+        // two key blocks of 64 with a running maximum (16 score registers live instead of 32: the kernel sits at the
+        // 256-register limit, and a spill is a scratch access on the in-order memory counter)
+        float m = -INFINITY, l = 0.f;
+        f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma nounroll
+        for (int kb = 0; kb < 2; ++kb) {
+          f32x4 sc[4];
+          float mb = -INFINITY;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            const int krow = (kb * 4 + kt) * 16 + li;
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ki + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
+            const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mb + (kb * 4 + kt) * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              sa[r] = __builtin_fmaf(sa[r], c2, mb4[r]);
+              mb = fmaxf(mb, sa[r]);
+            }
+            sc[kt] = sa;
+          }
+          mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+          mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+          const float mn = fmaxf(m, mb);
+          const float alpha = __builtin_amdgcn_exp2f(m - mn);      // first block: exp2(-inf) = 0
+          m = mn;
+          float lb = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pe = __builtin_amdgcn_exp2f(sc[kt][r] - mn);
+              sc[kt][r] = pe;
+              lb += pe;
+            }
+          lb += __shfl_xor(lb, 16, 64);
+          lb += __shfl_xor(lb, 32, 64);
+          l = l * alpha + lb;
+          oo[0] *= alpha;
+          oo[1] *= alpha;
+#pragma unroll
+          for (int u2 = 0; u2 < 2; ++u2) {
+            const int u = kb * 2 + u2;
+            const bf16x8 bp = ab_pack(sc[2 * u2], sc[2 * u2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              // V^T fragment: for column hh * 32 + 16 dt + li the key rows {32 u + 4 g + j} and {32 u + 16 + 4 g + j}
+              const int vrow = 32 * u + 4 * g + (li >> 2);
+              const int P = hh * 8 + dt * 4 + (li & 3);                 // 8-byte piece of the 128-byte row
+              const unsigned char* ptr = vi + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
+              const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+              // (row + 16: bits 1..3 of the row, hence the swizzle, are unchanged)
+              const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
+              const bf16x8 vt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              oo[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, bp, oo[dt], 0, 0, 0);
+            }
+          }
+        }
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const u32x2 pk = {pack_bf16x2(oo[dt][0] * inv, oo[dt][1] * inv), pack_bf16x2(oo[dt][2] * inv, oo[dt][3] * inv)};
+          *reinterpret_cast<u32x2*>(ai + qrow * 128 + (((hh * 4 + dt * 2 + (g >> 1)) ^ isw(qrow)) << 4) + (g & 1) * 8) = pk;
+        }
+        const float lv = (m + __builtin_amdgcn_logf(l)) * LN2;      // natural-log lse
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, lv), rs_l,
+                                              g == 0 ? (unsigned int)(((doc * p.H + 2 * pr + hh) * AB_ROWS + qrow) * 4) : 0xFFFFFFF0u, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // the pair's a image is complete
+    }
+  };
+  ab_static_for<0, AB_CHUNKS>(chunk);
+
+  // ---- x1 = x + dropout(acc + bo): 4 consecutive columns per lane and tile (mlp_fused_kernel's epilogue)
+  const float inv_keep = DROPOUT ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const unsigned long long rng_off = p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE;
+  const unsigned int dthr = drop_thr16(p.dropout_p), dkey = drop_key(p.seed, rng_off);
+#pragma unroll
+  for (int hf2 = 0; hf2 < 2; ++hf2) {      // two rounds of 4 column tiles: 8 residual loads in flight
+    f32x4 res[4][2];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
+        res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
+      }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(Bo + n);
+        bool keep[4] = {true, true, true, true};
+        if (DROPOUT) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
+        f32x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = res[q4][rt][r] + (keep[r] ? (acc2[hf2 * 4 + q4][rt][r] + bb[r]) * inv_keep : 0.f);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_x1, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0);
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int mfp_attn_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                                  const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
+                                  void* qkv, void* a, float* lse, float* x1, int32_t B, int32_t S, int32_t D, int32_t H,
+                                  float eps, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
+                                  mfp_stream_t stream) {
+  MFP_CHECK_ARG(x && gamma && beta && Wqkv && bqkv && Wo && bo && nvalid && y1 && mean && rstd && qkv && a && lse && x1);
+  MFP_CHECK_ARG(B > 0 && B <= 8192 && S == AB_ROWS && D == AB_D && H == 8 && eps > 0.f && dropout_p >= 0.f && dropout_p < 1.f);
+  MFP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)Wqkv % 16) == 0 && ((uintptr_t)Wo % 16) == 0 && ((uintptr_t)y1 % 16) == 0 &&
+                ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)bqkv % 16) == 0 &&
+                ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)bo % 16) == 0);
+  AttnBlockParams p;
+  p.x = x; p.gamma = gamma; p.beta = beta;
+  p.Wqkv = reinterpret_cast<const unsigned short*>(Wqkv); p.bqkv = bqkv;
+  p.Wo = reinterpret_cast<const unsigned short*>(Wo); p.bo = bo; p.nvalid = nvalid;
+  p.y1 = reinterpret_cast<unsigned short*>(y1); p.mean = mean; p.rstd = rstd;
+  p.qkv = reinterpret_cast<unsigned short*>(qkv); p.a = reinterpret_cast<unsigned short*>(a); p.lse = lse; p.x1 = x1;
+  p.T = B * S; p.H = H; p.eps = eps; p.scale = 1.0f / sqrtf(32.0f);
+  p.dropout_p = dropout_p; p.seed = seed; p.offset = offset; p.step_ptr = step_ptr;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_attn_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dropout_p > 0.f) hipLaunchKernelGGL(attn_block_fwd_kernel<true>, dim3(B), dim3(512), AB_LDS, st, p);
+  else hipLaunchKernelGGL(attn_block_fwd_kernel<false>, dim3(B), dim3(512), AB_LDS, st, p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

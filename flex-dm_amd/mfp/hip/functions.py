@@ -28,6 +28,9 @@ WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
 # input-gradient products of the same half as one launch (csrc/block_fused.hip); 0 = ln_fwd + two products,
 # two dgrad products (A/B switch)
 MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
+# bf16 path, d_model 256, documents of exactly 128 positions: LN1 + Q|K|V + attention + output projection + dropout +
+# residual of a block as ONE launch (csrc/block_attn.hip: a 128-row tile is a document); 0 = the three launches
+ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
 FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
 
 
@@ -326,7 +329,13 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x = x.contiguous()
-        if _fused_ok(ctx, D) and not st.fp8:      # LN1 + Q|K|V in one launch
+        if ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S:
+            # the whole attention half in one launch
+            x1, y1, mean1, rstd1, qkv, a, lse = ops.attn_block_fwd(
+                x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), st.cw(p + "attn/dense_query/kernel", rows=3 * D),
+                st.span(st.w, p + "attn/dense_query/bias", 3 * D), st.cw(p + "attn/combine_heads/kernel"),
+                st.weight(p + "attn/combine_heads/bias"), ctx.nvalid, B, S, NUM_HEADS, (ctx.p, ctx.seed, 2 * i + 1), ctx.step_ptr)
+        elif _fused_ok(ctx, D) and not st.fp8:      # LN1 + Q|K|V in one launch
             qkv, y1, mean1, rstd1 = ops.qkv_fused_fwd(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
                                                       st.cw(p + "attn/dense_query/kernel", rows=3 * D),
                                                       st.span(st.w, p + "attn/dense_query/bias", 3 * D))
@@ -335,10 +344,11 @@ class BlockFn(torch.autograd.Function):
                                           st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
                                           st.span(st.w, p + "attn/dense_query/bias", 3 * D),
                                           w8=st.w8(p + "attn/dense_query/kernel", 3 * D) if st.fp8 else None)
-        a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
-        x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
-                      bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
-                      dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
+        if not (ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S):
+            a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
+            x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
+                          bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
+                          dropout=(ctx.p, ctx.seed, 2 * i + 1), step_ptr=ctx.step_ptr, out_dtype=torch.float32)
         if _fused_ok(ctx, D) and not st.fp8:
             # the last block also leaves the heads' bf16 operand (saves the cast pass in front of the decoder)
             x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)

@@ -308,6 +308,29 @@ def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2, b2, dropout: Tuple[float, int, in
     return x2, y2, mean, rstd, h
 
 
+def attn_block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, B: int, S: int, H: int, dropout: Tuple[float, int, int],
+                   step_ptr=None):
+    """x1 = x + Dropout(MHSA(LN(x)) Wo^T + bo) in ONE launch (d_model 256, S = 128, 8 heads; see mfp_attn_block_fwd).
+    Returns (x1, y1, mean, rstd, qkv, a, lse) -- what the three launches it replaces save for the backward pass."""
+    lib = load()
+    T, D = x.shape
+    dev = x.device
+    y1 = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    qkv = torch.empty((T, 3 * D), dtype=torch.bfloat16, device=dev)
+    a = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    mean = torch.empty((T,), dtype=torch.float32, device=dev)
+    rstd = torch.empty((T,), dtype=torch.float32, device=dev)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    x1 = torch.empty((T, D), dtype=torch.float32, device=dev)
+    flops = 2 * T * D * 3 * D + 4 * B * S * S * D + 2 * T * D * D
+    with _timed("attn_block_fwd_kernel", flops, T * (D * 4 * 3 + D * 2 * 2 + 3 * D * 2) + 4 * D * D * 2):
+        check(lib.mfp_attn_block_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(Wqkv), _ptr(bqkv), _ptr(Wo), _ptr(bo), _ptr(nvalid),
+                                     _ptr(y1), _ptr(mean), _ptr(rstd), _ptr(qkv), _ptr(a), _ptr(lse), _ptr(x1), B, S, D, H, LN_EPS,
+                                     float(dropout[0]), int(dropout[1]), int(dropout[2]),
+                                     _ptr(step_ptr) if step_ptr is not None else None, _stream()), "mfp_attn_block_fwd")
+    return x1, y1, mean, rstd, qkv, a, lse
+
+
 def qkv_fused_fwd(x, gamma, beta, W, bias):
     """qkv = LN(x) W^T + bias in one launch (d_model 256, bf16 weights [768][256]).  Returns (qkv, y1, mean, rstd)."""
     lib = load()

@@ -154,6 +154,19 @@ int mfp_mlp_fused_fwd(const float* x1, const float* gamma, const float* beta, co
                       float* rstd, void* h, float* x2, void* x2_bf16, int32_t T, int32_t D, float eps, float dropout_p,
                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
+/* The attention half of a block, forward, in one launch (transformer.py:211-221,60-99):
+ *   x1 = x + Dropout(MHSA(LN1(x)) Wo^T + bo), 8 heads of 32, key-padding mask nvalid[b] (keys >= nvalid[b] get -1e9),
+ * for d_model 256 and documents of exactly S = 128 positions (a 128-row tile is a document: its attention is local to
+ * the workgroup that owns the tile).  Saves what mfp_qkv_fused_fwd + mfp_attention_fwd + the output projection save
+ * for the backward pass, with the same meaning and layout: y1 bf16 [T,256], mean / rstd f32 [T], qkv bf16 [T,768],
+ * a bf16 [T,256] (attention output), lse f32 [B][8][128]; x1 f32 [T,256].  Wqkv bf16 [768][256], Wo bf16 [256][256]
+ * (out, in).  Dropout stream = MFP_GEMM_DROPOUT's (seed, offset, step_ptr). */
+int mfp_attn_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                       const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
+                       void* qkv, void* a, float* lse, float* x1, int32_t B, int32_t S, int32_t D, int32_t H,
+                       float eps, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
+                       mfp_stream_t stream);
+
 /* LayerNormalization + the fused Q | K | V Dense of a block in one launch (transformer.py:216-217,85-90):
  * qkv bf16 [T,768] = LN(x) W^T + bias, with y1 = LN(x) (bf16 [T,256]), mean, rstd (f32 [T]) saved for the
  * backward pass.  x f32 [T,256]; W bf16 [768][256] (out, in); d_model 256 only. */

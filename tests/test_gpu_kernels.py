@@ -932,3 +932,51 @@ def test_dgrad_d256(T):
     W = bf16_round(torch.randn(D, D, generator=g) * 0.06)             # [out][in]
     dx = ops.dgrad_d256(dy.to(DEV, torch.bfloat16), W.t().contiguous().to(DEV, torch.bfloat16))
     assert_close(dx, dy.double() @ W.double(), 2e-2, 1e-2, "vs double")
+
+
+@pytest.mark.parametrize("B,p", [(3, 0.0), (5, 0.1), (1, 0.0)])
+def test_attn_block_fwd(B, p):
+    """mfp_attn_block_fwd: x1 = x + Dropout(MHSA(LN1(x)) Wo^T + bo) in ONE launch (transformer.py:211-221,60-99; documents
+    of exactly 128 positions) against the three launches it replaces (mfp_qkv_fused_fwd, mfp_attention_fwd, the output
+    projection with residual and the same dropout stream) and a double reference; ragged key-padding masks."""
+    ops = _ops()
+    S, D, H = 128, 256, 8
+    T = B * S
+    g = torch.Generator().manual_seed(100 * B + int(p * 10))
+    x = torch.randn(T, D, generator=g) * (1.0 + torch.rand(T, 1, generator=g)) + 0.3 * torch.randn(T, 1, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    Wqkv = bf16_round(torch.randn(3 * D, D, generator=g) * 0.08)
+    bqkv = torch.randn(3 * D, generator=g) * 0.1
+    Wo = bf16_round(torch.randn(D, D, generator=g) * 0.06)
+    bo = torch.randn(D, generator=g) * 0.1
+    nvalid = torch.randint(1, S + 1, (B,), generator=g).to(torch.int32)
+    nvalid[0] = S
+    step = torch.full((1,), 2, dtype=torch.int32, device=DEV)
+    dev = lambda t, dt=None: t.to(DEV, dt) if dt else t.to(DEV)
+    xd, gd, bd, bqd, bod, nvd = dev(x), dev(gamma), dev(beta), dev(bqkv), dev(bo), dev(nvalid)
+    Wqd, Wod = dev(Wqkv, torch.bfloat16), dev(Wo, torch.bfloat16)
+    x1, y1, mean, rstd, qkv, a, lse = ops.attn_block_fwd(xd, gd, bd, Wqd, bqd, Wod, bod, nvd, B, S, H, (p, 7, 3), step)
+    # the three launches
+    qkvu, y1u, meanu, rstdu = ops.qkv_fused_fwd(xd, gd, bd, Wqd, bqd)
+    au, lseu = ops.attention_fwd(qkvu, nvd, B, S, H)
+    x1u = ops.gemm(au, Wod, T, D, D, a_kmajor=True, b_kmajor=True, bias=bod, residual=xd, dropout=(p, 7, 3), step_ptr=step,
+                   out_dtype=torch.float32)
+    assert torch.equal(y1.view(torch.int16), y1u.view(torch.int16)) and torch.equal(mean, meanu) and torch.equal(rstd, rstdu)
+    assert torch.equal(qkv.view(torch.int16), qkvu.view(torch.int16))          # same products, same order
+    assert_close(lse, lseu.cpu().double(), 1e-4, 1e-5, "lse vs attention kernel")
+    assert_close(a, au.float().cpu().double(), 2e-2, 2e-2, "a vs attention kernel")
+    assert (a != au).float().mean().item() < 0.15       # (two key blocks with a running maximum: last-bit differences)
+    # double reference from the kernel's own bf16 q | k | v
+    q64 = qkv.float().cpu().double().view(B, S, 3, H, 32)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q64[:, :, 0], q64[:, :, 1]) / 32 ** 0.5
+    km = (torch.arange(S)[None, :] >= nvalid[:, None]).double() * -1e9
+    sc = sc + km[:, None, None, :]
+    want_lse = torch.logsumexp(sc, dim=-1)
+    want_a = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, dim=-1), q64[:, :, 2]).reshape(T, D)
+    assert_close(lse, want_lse, 1e-3, 1e-4, "lse vs double")
+    assert_close(a, want_a, 2e-2, 2e-2, "a vs double")
+    if p == 0.0:
+        want_x1 = x.double() + a.float().cpu().double() @ Wo.double().t() + bo.double()
+        assert_close(x1, want_x1, 2e-3, 1e-3, "x1 vs double")
+    # same dropout mask as the projection kernel: where both kept / dropped the values agree
+    assert_close(x1, x1u.cpu().double(), 3e-2, 2e-2, "x1 vs the three launches")

@@ -42,3 +42,15 @@ if "mlp" in which:
 if "mlpbwd" in which:
     d_o2, h, W2t, W1t = rnd(T, 256), rnd(T, 512), rnd(512, 256), rnd(256, 512)
     timeit("mlp_bwd", lambda: ops.mlp_fused_bwd(d_o2, h, W2t, W1t), T * (256 * 2 * 2 + 512 * 2 * 2))
+if "attnblock" in which:
+    B = T // 128
+    Wq, bq = rnd(768, 256), torch.randn(768, device=dev)
+    Wo, bo = rnd(256, 256), torch.randn(256, device=dev)
+    nvalid = torch.full((B,), 128, dtype=torch.int32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    timeit("attn_block_fwd", lambda: ops.attn_block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, B, 128, 8, (0.1, 5, 3), step), T * (256 * 4 * 3 + 256 * 2 * 2 + 768 * 2))
+    def three():
+        qkv, y1, m, r = ops.qkv_fused_fwd(x, gam, bet, Wq, bq)
+        a, lse = ops.attention_fwd(qkv, nvalid, B, 128, 8)
+        return ops.gemm(a, Wo, T, 256, 256, a_kmajor=True, b_kmajor=True, bias=bo, residual=x, dropout=(0.1, 5, 3), step_ptr=step, out_dtype=torch.float32)
+    timeit("qkv+attn+oproj (3)", three, T * (256 * 4 * 3 + 256 * 2 * 4 + 768 * 2 * 2))
