@@ -281,69 +281,60 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       // (the output tile of a head overwrites this wave's own rows of the q image: nobody else reads these rows -- their q
       //  columns left for HBM at the head of the k chunk)
       unsigned char* ai = Im;
-#pragma nounroll
+#pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         // (head 0's output goes over the head-0 columns of this wave's q rows; head 1's q columns are still intact)
         const bf16x8 bq = *reinterpret_cast<const bf16x8*>(qi + qrow * 128 + (((hh * 4 + g) ^ isw(qrow)) << 4));
-        // two key blocks of 64 with a running maximum (16 score registers live instead of 32: the kernel sits at the
-        // 256-register limit, and a spill is a scratch access on the in-order memory counter)
-        float m = -INFINITY, l = 0.f;
-        f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma nounroll
-        for (int kb = 0; kb < 2; ++kb) {
-          f32x4 sc[4];
-          float mb = -INFINITY;
+        // Two passes over the keys instead of 32 live score registers (the kernel sits at the 256-register limit, a spill
+        // is a scratch access on the in-order memory counter, and the matrix pipe is ~10 % busy): pass 1 = the row
+        // maximum, pass 2 recomputes the scores tile by tile, exponentiates and feeds P V.
+        float m = -INFINITY;
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            const int krow = (kb * 4 + kt) * 16 + li;
+        for (int kt = 0; kt < 8; ++kt) {
+          const int krow = kt * 16 + li;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ki + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
+          const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mb + kt * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fmaf(sa[r], c2, mb4[r]));
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f32x4 pe[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int kt = 2 * u + hf, krow = kt * 16 + li;
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ki + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
-            const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mb + (kb * 4 + kt) * 16 + 4 * g);
+            const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
+            const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mb + kt * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              sa[r] = __builtin_fmaf(sa[r], c2, mb4[r]);
-              mb = fmaxf(mb, sa[r]);
+              pe[hf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, mb4[r]) - m);
+              l += pe[hf][r];
             }
-            sc[kt] = sa;
           }
-          mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
-          mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
-          const float mn = fmaxf(m, mb);
-          const float alpha = __builtin_amdgcn_exp2f(m - mn);      // first block: exp2(-inf) = 0
-          m = mn;
-          float lb = 0.f;
+          const bf16x8 bp = ab_pack(pe[0], pe[1]);
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float pe = __builtin_amdgcn_exp2f(sc[kt][r] - mn);
-              sc[kt][r] = pe;
-              lb += pe;
-            }
-          lb += __shfl_xor(lb, 16, 64);
-          lb += __shfl_xor(lb, 32, 64);
-          l = l * alpha + lb;
-          oo[0] *= alpha;
-          oo[1] *= alpha;
-#pragma unroll
-          for (int u2 = 0; u2 < 2; ++u2) {
-            const int u = kb * 2 + u2;
-            const bf16x8 bp = ab_pack(sc[2 * u2], sc[2 * u2 + 1]);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-              // V^T fragment: for column hh * 32 + 16 dt + li the key rows {32 u + 4 g + j} and {32 u + 16 + 4 g + j}
-              const int vrow = 32 * u + 4 * g + (li >> 2);
-              const int P = hh * 8 + dt * 4 + (li & 3);                 // 8-byte piece of the 128-byte row
-              const unsigned char* ptr = vi + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
-              const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
-              // (row + 16: bits 1..3 of the row, hence the swizzle, are unchanged)
-              const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
-              const bf16x8 vt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-              oo[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, bp, oo[dt], 0, 0, 0);
-            }
+          for (int dt = 0; dt < 2; ++dt) {
+            // V^T fragment: for column hh * 32 + 16 dt + li the key rows {32 u + 4 g + j} and {32 u + 16 + 4 g + j}
+            const int vrow = 32 * u + 4 * g + (li >> 2);
+            const int P = hh * 8 + dt * 4 + (li & 3);                 // 8-byte piece of the 128-byte row
+            const unsigned char* ptr = vi + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+            // (row + 16: bits 1..3 of the row, hence the swizzle, are unchanged)
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
+            const bf16x8 vt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            oo[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, bp, oo[dt], 0, 0, 0);
           }
         }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
         const float inv = 1.f / l;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
