@@ -38,6 +38,12 @@ struct AttnBlockParams {
   unsigned short* qkv; unsigned short* a; float* lse; float* x1;
   int T, H; float eps, scale;
   float dropout_p; unsigned long long seed, offset; const int* step_ptr;
+  // MLP half (template flag MLP; mlp_fused_kernel's arguments): x2 = x1 + Dropout(relu(LN2(x1) W1^T + b1) W2^T + b2)
+  const float* gamma2; const float* beta2;
+  const unsigned short* W1; const float* b1;           // [512][256] bf16, f32 [512]
+  const unsigned short* W2; const float* b2;           // [256][512] bf16, f32 [256]
+  unsigned short* y2; float* mean2; float* rstd2; unsigned short* h; float* x2; unsigned short* x2c;
+  unsigned long long offset2;                          // dropout stream of the MLP half
 };
 
 constexpr int AB_D = 256, AB_ROWS = 128, AB_CHUNKS = 16;
@@ -46,6 +52,10 @@ constexpr int AB_WS_OFF = 3 * AB_IMG;                  // q | k | v images first
 constexpr int AB_WS_B = 32768;
 constexpr int AB_VEC_OFF = AB_WS_OFF + 3 * AB_WS_B;    // bqkv (3 KB) | gamma (1 KB) | beta (1 KB) | bo (1 KB) | Mb (512 B)
 constexpr int AB_LDS = AB_VEC_OFF + (768 + 3 * 256 + 128) * 4;
+// MLP: ... | b1 (2 KB) | b2 (1 KB) | gamma2 (1 KB) | beta2 (1 KB) | row-statistic exchange [2][128] (1 KB)
+constexpr int AB_VEC2_OFF = AB_LDS;
+constexpr int AB_LDS_MLP = AB_VEC2_OFF + (512 + 3 * 256 + 256) * 4;
+constexpr int AB_F = 512;
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
@@ -64,8 +74,9 @@ __device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool DROPOUT>
+template <bool DROPOUT, bool MLP>
 __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) {
+  constexpr int NCH = MLP ? 2 * AB_CHUNKS : AB_CHUNKS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Im = smem;                      // Im + t * AB_IMG, t = 0 (q, then a), 1 (k), 2 (v)
   unsigned char* const Ws = smem + AB_WS_OFF;
@@ -91,6 +102,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y1, 0, xbytes / 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(p.qkv, 0, (unsigned int)p.T * (768 * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(p.a, 0, xbytes / 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(MLP ? p.W1 : p.Wqkv), 0, AB_F * AB_D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(MLP ? p.W2 : p.Wqkv), 0, AB_F * AB_D * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(p.lse, 0, (unsigned int)(p.T / AB_ROWS) * (unsigned int)p.H * AB_ROWS * 4u, 0x00020000);
 
   // ---- weight chunk c = 4 p + t.  t = 0, 1, 2 (q, k, v): Wqkv rows t * 256 + 64 p .. + 63, all 256 k -> image [64][512 B],
@@ -100,6 +113,25 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   auto wload = [&](int c) {
     const int pr = c >> 2, t = c & 3;
     unsigned char* dst = Ws + ((c + 1) % 3) * AB_WS_B + wave * 4096;
+    if (MLP && c >= AB_CHUNKS) {
+      // MLP chunks (mlp_fused_kernel): c' & 3 = 0, 1: W1 rows q * 128 + 64 j .. + 63, all 256 k -> [64][512 B];
+      // c' & 3 = 2, 3: W2 rows 128 j .. + 127, k = q * 128 .. + 127 -> [128][256 B]
+      const int cm = c - AB_CHUNKS, q = cm >> 2, ffn2 = (cm >> 1) & 1, j = cm & 1;
+      if (!ffn2) {
+        const int base = (q * 128 + j * 64) * (AB_D * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_u8*)(dst + i * 1024), 16, w1off ^ (i << 5), base + i * 1024, 0, 0);
+      } else {
+        const int base = (j * 128) * (AB_F * 2) + q * 256;
+        // (recomputed per chunk: not a register kept alive across the attention stage, which sits at the limit)
+        const unsigned int w2off = (unsigned int)((wave * 16 + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_u8*)(dst + i * 1024), 16, w2off ^ (i << 6), base + i * 4096, 0, 0);
+      }
+      return;
+    }
     if (t < 3) {
       const int base = (t * 256 + pr * 64) * (AB_D * 2);
 #pragma unroll
@@ -120,6 +152,11 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     const float* src = tid < 192 ? p.bqkv + tid * 4 : tid < 256 ? p.gamma + (tid - 192) * 4
                      : tid < 320 ? p.beta + (tid - 256) * 4 : p.bo + (tid - 320) * 4;
     *reinterpret_cast<f32x4*>(smem + AB_VEC_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(src);
+  }
+  if (MLP && tid < (512 + 3 * 256) / 4) {
+    const float* src = tid < 128 ? p.b1 + tid * 4 : tid < 192 ? p.b2 + (tid - 128) * 4
+                     : tid < 256 ? p.gamma2 + (tid - 192) * 4 : p.beta2 + (tid - 256) * 4;
+    *reinterpret_cast<f32x4*>(smem + AB_VEC2_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(src);
   }
   if (tid < 128) Mb[tid] = tid < nv ? 0.f : -1e9f * LOG2E;      // additive key term (exp2 domain); S = 128: no row past S
 
@@ -198,7 +235,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   auto chunk = [&](auto cc_) {
     constexpr int c = decltype(cc_)::value;
     constexpr int pr = c >> 2, t = c & 3;
-    if (c + 2 < AB_CHUNKS) wload(c + 2);
+    if (c + 2 < NCH) wload(c + 2);
     // stores of finished images, AFTER the weight loads (counted waits): q at the head of k, k at the head of v, v and a
     // at the head of o (behind the barrier that ended the attention of the pair)
     if (t == 1) stash(pr, 0);
@@ -263,12 +300,12 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     // operations retire in order): the stores at the head of chunk c - 1 (k, v: 2; o: 4), the two lse stores of an
     // attention phase behind chunk c - 1 (v), the 4 loads of chunk c + 2, the stores at the head of this chunk; chunk 0:
     // the 10 stores of the prologue (chunk 1 landed there: every x load issued after it has been consumed)
-    if (c + 1 < AB_CHUNKS) {
+    if (c + 1 < NCH) {
       constexpr int tp = (c - 1) & 3;
       constexpr int st_prev = c == 0 ? 0 : (tp == 1 || tp == 2) ? 2 : tp == 3 ? 4 : 0;
       constexpr int at_prev = (c >= 1 && tp == 2) ? 2 : 0;
       constexpr int st_this = (t == 1 || t == 2) ? 2 : t == 3 ? 4 : 0;
-      constexpr int allowed = c == 0 ? 14 : st_prev + at_prev + (c + 2 < AB_CHUNKS ? 4 : 0) + st_this;
+      constexpr int allowed = c == 0 ? 14 : st_prev + at_prev + (c + 2 < NCH ? 4 : 0) + st_this;
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -351,49 +388,284 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   };
   ab_static_for<0, AB_CHUNKS>(chunk);
 
-  // ---- x1 = x + dropout(acc + bo): 4 consecutive columns per lane and tile (mlp_fused_kernel's epilogue)
+  // ---- x1 = x + dropout(acc + bo): 4 consecutive columns per lane and tile (mlp_fused_kernel's epilogue); with the MLP
+  // half behind it the values also stay in the accumulator registers for LN2
   const float inv_keep = DROPOUT ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const unsigned long long rng_off = p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE;
-  const unsigned int dthr = drop_thr16(p.dropout_p), dkey = drop_key(p.seed, rng_off);
+  const unsigned int dthr = drop_thr16(p.dropout_p);
+  {
+    const unsigned int dkey = drop_key(p.seed, p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE);
 #pragma unroll
-  for (int hf2 = 0; hf2 < 2; ++hf2) {      // two rounds of 4 column tiles: 8 residual loads in flight
-    f32x4 res[4][2];
+    for (int hf2 = 0; hf2 < 2; ++hf2) {      // two rounds of 4 column tiles: 8 residual loads in flight
+      f32x4 res[4][2];
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4)
+      for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
+          res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
+        }
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(Bo + n);
+          bool keep[4] = {true, true, true, true};
+          if (DROPOUT) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
+          f32x4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = res[q4][rt][r] + (keep[r] ? (acc2[hf2 * 4 + q4][rt][r] + bb[r]) * inv_keep : 0.f);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_x1, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0);
+          acc2[hf2 * 4 + q4][rt] = ov;
+        }
+    }
+  }
+  if constexpr (MLP) {
+    // ================================================================= MLP half (mlp_fused_kernel behind LN2)
+    // Opaque copies of the lane coordinates: the compiler otherwise hoists this stage's address arithmetic to the top
+    // of the kernel and keeps ~20 values alive across the attention stage, which sits at the register limit (spills
+    // = scratch accesses on the in-order memory counter).
+    int li_m = li, g_m = g, tid_m = tid;
+    asm volatile("" : "+v"(li_m), "+v"(g_m), "+v"(tid_m));
+    int xs_m[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xs_m[ks] = ((ks * 4 + g_m) ^ li_m) << 4;
+    const float* const B1s = reinterpret_cast<const float*>(smem + AB_VEC2_OFF);
+    const float* const B2s = B1s + AB_F;
+    const float* const G2s = B2s + AB_D;
+    const float* const Be2s = G2s + AB_D;
+    float* const St = reinterpret_cast<float*>(smem + AB_VEC2_OFF + (AB_F + 3 * AB_D) * 4);      // [2 (nh)][128 rows]
+    const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, xbytes / 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, (unsigned int)p.T * (AB_F * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(p.x2, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2c = __builtin_amdgcn_make_buffer_rsrc(p.x2c ? p.x2c : p.y2, 0, p.x2c ? xbytes / 2 : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m2 = __builtin_amdgcn_make_buffer_rsrc(p.mean2, 0, (unsigned int)p.T * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc(p.rstd2, 0, (unsigned int)p.T * 4u, 0x00020000);
+    // ---- LN2 on the accumulator layout: a lane holds 32 columns of its two rows; the other 128 columns of a row sit
+    // in the wave (rp, 1 - nh): partial sums through LDS, summed in the fixed order nh = 0, 1
+    float mu[2], rs2[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
-        res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
-      }
+        float sacc = 0.f;
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4)
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = pass == 0 ? acc2[ct][rt][r] : acc2[ct][rt][r] - mu[rt];
+            sacc += pass == 0 ? d : d * d;
+          }
+        sacc += __shfl_xor(sacc, 16, 64);
+        sacc += __shfl_xor(sacc, 32, 64);
+        if (g_m == 0) St[nh * 128 + rp * 32 + rt * 16 + li_m] = sacc;
+      }
+      __syncthreads();
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(Bo + n);
-        bool keep[4] = {true, true, true, true};
-        if (DROPOUT) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
-        f32x4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = res[q4][rt][r] + (keep[r] ? (acc2[hf2 * 4 + q4][rt][r] + bb[r]) * inv_keep : 0.f);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_x1, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0);
+        const int lrow = rp * 32 + rt * 16 + li_m;
+        const float tot = (St[lrow] + St[128 + lrow]) * (1.0f / AB_D);
+        if (pass == 0) mu[rt] = tot;
+        else rs2[rt] = rsqrtf(tot + p.eps);
       }
+      __syncthreads();
+    }
+    // y2 (bf16) -> the [128][512 B] image (slot ^ (row & 15)); rows >= 96 sit behind ring buffer 0 (which holds a
+    // prefetched weight chunk): + 32 KB
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int lrow = rp * 32 + rt * 16 + li_m;
+      unsigned char* irow = smem + lrow * 512 + (lrow >= 96 ? 32768 : 0);
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const int tl = (ct >> 2) * 8 + nh * 4 + (ct & 3), n = tl * 16 + 4 * g_m;
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(G2s + n), bb = *reinterpret_cast<const f32x4*>(Be2s + n);
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = (acc2[ct][rt][r] - mu[rt]) * rs2[rt] * gg[r] + bb[r];
+        const u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        *reinterpret_cast<u32x2*>(irow + (((tl * 2 + (g_m >> 1)) ^ (lrow & 15)) << 4) + (g_m & 1) * 8) = pk;
+      }
+      // statistics: one writer per row (wave nh = 0, lanes g_m = 0); the others issue the same two stores out of range
+      const unsigned int so = (nh == 0 && g_m == 0) ? (unsigned int)(row0 + lrow) * 4u : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, mu[rt]), rs_m2, so, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, rs2[rt]), rs_r2, so, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid_m + 512 * i, r = idx >> 5, c16 = idx & 31;
+      const u32x4 yv = *reinterpret_cast<const u32x4*>(smem + r * 512 + (r >= 96 ? 32768 : 0) + ((c16 ^ (r & 15)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y2, (unsigned int)(row0 + r) * (AB_D * 2) + c16 * 16, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int lrow = rp * 32 + rt * 16 + li_m;
+        xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + lrow * 512 + (lrow >= 96 ? 32768 : 0) + (((ks * 4 + g_m) ^ li_m) << 4));
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // the y2 image has been read by everyone (the FFN1 epilogues write over it)
+
+    unsigned char* const Hs = smem;      // h quarter: 128 rows x 128 hidden units, 32 KB (the q | k images' place)
+    bf16x8 hf[2][4];
+    const unsigned int dkey2 = drop_key(p.seed, p.offset2 + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE);
+    auto mchunk = [&](auto cc_) {
+      constexpr int c = decltype(cc_)::value;            // global chunk number: its buffer is (c + 1) % 3
+      constexpr int cm = c - AB_CHUNKS;
+      constexpr int q = cm >> 2, ffn2 = (cm >> 1) & 1, j = cm & 1;
+      if (c + 2 < NCH) wload(c + 2);
+      f32x4 res[4][2];
+      if (q == 3 && ffn2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const int row = row0 + rp * 32 + rt * 16 + li_m;
+            res[nt][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_x1, (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_m) * 4 + (j * 8 + nt) * 64, 0, 0));
+          }
+      }
+      const unsigned char* wb = Ws + ((c + 1) % 3) * AB_WS_B;
+      if (!ffn2) {
+        const unsigned char* wa = wb + ((nh * 2) * 16 + li_m) * 512;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 wf[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs_m[0]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          if (ks + 1 < 8) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs_m[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
+          }
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+              acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(B1s + q * 128 + j * 64 + (nh * 2 + nt) * 16 + 4 * g_m);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const u32x2 pk = {pack_bf16x2(fmaxf(acc[nt][rt][0] + bb[0], 0.f), fmaxf(acc[nt][rt][1] + bb[1], 0.f)),
+                              pack_bf16x2(fmaxf(acc[nt][rt][2] + bb[2], 0.f), fmaxf(acc[nt][rt][3] + bb[3], 0.f))};
+            *reinterpret_cast<u32x2*>(Hs + (rp * 32 + rt * 16 + li_m) * 256 + (((j * 8 + (nh * 2 + nt) * 2 + (g_m >> 1)) ^ li_m) << 4) + (g_m & 1) * 8) = pk;
+          }
+        }
+      } else {
+        constexpr bool last = q == 3;
+        const unsigned char* wa = wb + ((nh * 4) * 16 + li_m) * 256;
+        bf16x8 wf[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs_m[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks + 1 < 4) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs_m[ks + 1]);
+          }
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+              acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
+                                                                           (q == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
+        }
+        if (last) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const int row = row0 + rp * 32 + rt * 16 + li_m;
+            const unsigned int rowh = drop_row(dkey2, (unsigned int)row);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const int n = (j * 8 + nh * 4 + nt) * 16 + 4 * g_m;
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(B2s + n);
+              bool keep[4] = {true, true, true, true};
+              if (DROPOUT) drop_keep4(rowh, (unsigned int)n, dthr, keep);
+              f32x4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = res[nt][rt][r] + (keep[r] ? (acc2[j * 4 + nt][rt][r] + bb[r]) * inv_keep : 0.f);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_x2,
+                                                     (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_m) * 4 + (j * 8 + nt) * 64, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_x2c,
+                                                    (unsigned int)row * (AB_D * 2) + (nh * 4 * 16 + 4 * g_m) * 2 + (j * 8 + nt) * 32, 0, 0);
+            }
+          }
+        }
+      }
+      {
+        // counted wait (mlp_fused_kernel's): h stores of the previous chunk's tail (4, behind the barrier of chunks 1, 5,
+        // 9, 13), the 4 loads of chunk c + 2, this chunk's stores; first MLP chunk: the 4 image stores at the head of the
+        // last o chunk and the 28 stores of the x1 / LN2 stage (16 + 8 + 4) are younger than the loads of chunk c + 1
+        constexpr int st_prev = (cm & 3) == 2 ? 4 : 0;
+        constexpr int st_this = cm == 0 ? 32 : cm == 14 ? 24 : 0;
+        constexpr int allowed = st_prev + (c + 2 < NCH ? 4 : 0) + st_this;
+        if (c + 1 < NCH) {
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+      if (!ffn2 && j == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = tid_m + 512 * i, r = idx >> 4, c16 = idx & 15;
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(Hs + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_h,
+                                                 (unsigned int)(row0 + r) * (AB_F * 2) + c16 * 16 + q * 256, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (rp * 32 + rt * 16 + li_m) * 256 + xs_m[ks]);
+      }
+    };
+    ab_static_for<AB_CHUNKS, 2 * AB_CHUNKS>(mchunk);
   }
 }
 
 }  // namespace
 
-extern "C" int mfp_attn_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
-                                  const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
-                                  void* qkv, void* a, float* lse, float* x1, int32_t B, int32_t S, int32_t D, int32_t H,
-                                  float eps, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
-                                  mfp_stream_t stream) {
+static int launch_block(AttnBlockParams& p, bool mlp, int B, hipStream_t st) {
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS_MLP, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const bool drop = p.dropout_p > 0.f;
+  if (mlp) {
+    if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
+    else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
+  } else {
+    if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, false>), dim3(B), dim3(512), AB_LDS, st, p);
+    else hipLaunchKernelGGL((attn_block_fwd_kernel<false, false>), dim3(B), dim3(512), AB_LDS, st, p);
+  }
+  return MFP_OK;
+}
+
+static int fill_attn(AttnBlockParams& p, const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                     const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd, void* qkv, void* a,
+                     float* lse, float* x1, int32_t B, int32_t S, int32_t D, int32_t H, float eps, float dropout_p, uint64_t seed,
+                     uint64_t offset, const int32_t* step_ptr) {
   MFP_CHECK_ARG(x && gamma && beta && Wqkv && bqkv && Wo && bo && nvalid && y1 && mean && rstd && qkv && a && lse && x1);
   MFP_CHECK_ARG(B > 0 && B <= 8192 && S == AB_ROWS && D == AB_D && H == 8 && eps > 0.f && dropout_p >= 0.f && dropout_p < 1.f);
   MFP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)Wqkv % 16) == 0 && ((uintptr_t)Wo % 16) == 0 && ((uintptr_t)y1 % 16) == 0 &&
                 ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)bqkv % 16) == 0 &&
                 ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)bo % 16) == 0);
-  AttnBlockParams p;
   p.x = x; p.gamma = gamma; p.beta = beta;
   p.Wqkv = reinterpret_cast<const unsigned short*>(Wqkv); p.bqkv = bqkv;
   p.Wo = reinterpret_cast<const unsigned short*>(Wo); p.bo = bo; p.nvalid = nvalid;
@@ -401,21 +673,45 @@ extern "C" int mfp_attn_block_fwd(const float* x, const float* gamma, const floa
   p.qkv = reinterpret_cast<unsigned short*>(qkv); p.a = reinterpret_cast<unsigned short*>(a); p.lse = lse; p.x1 = x1;
   p.T = B * S; p.H = H; p.eps = eps; p.scale = 1.0f / sqrtf(32.0f);
   p.dropout_p = dropout_p; p.seed = seed; p.offset = offset; p.step_ptr = step_ptr;
-  static bool attr_done[MFP_MAX_DEVICES] = {};
-  bool& attr_set = attr_done[mfp_device_slot()];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
-    if (e != hipSuccess) {
-      mfp_set_error("mfp_attn_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS, hipGetErrorString(e));
-      return MFP_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dropout_p > 0.f) hipLaunchKernelGGL(attn_block_fwd_kernel<true>, dim3(B), dim3(512), AB_LDS, st, p);
-  else hipLaunchKernelGGL(attn_block_fwd_kernel<false>, dim3(B), dim3(512), AB_LDS, st, p);
+  p.gamma2 = p.beta2 = p.b1 = p.b2 = nullptr; p.W1 = p.W2 = nullptr;
+  p.y2 = p.h = p.x2c = nullptr; p.mean2 = p.rstd2 = p.x2 = nullptr; p.offset2 = 0;
+  return MFP_OK;
+}
+
+extern "C" int mfp_attn_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                                  const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
+                                  void* qkv, void* a, float* lse, float* x1, int32_t B, int32_t S, int32_t D, int32_t H,
+                                  float eps, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
+                                  mfp_stream_t stream) {
+  AttnBlockParams p;
+  if (int rc = fill_attn(p, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, y1, mean, rstd, qkv, a, lse, x1, B, S, D, H, eps, dropout_p,
+                         seed, offset, step_ptr)) return rc;
+  if (int rc = launch_block(p, false, B, reinterpret_cast<hipStream_t>(stream))) return rc;
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                             const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
+                             void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
+                             const void* W1, const float* b1, const void* W2, const float* b2, void* y2, float* mean2,
+                             float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
+                             float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
+                             const int32_t* step_ptr, mfp_stream_t stream) {
+  AttnBlockParams p;
+  if (int rc = fill_attn(p, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, y1, mean, rstd, qkv, a, lse, x1, B, S, D, H, eps, dropout_p,
+                         seed, offset_attn, step_ptr)) return rc;
+  MFP_CHECK_ARG(gamma2 && beta2 && W1 && b1 && W2 && b2 && y2 && mean2 && rstd2 && h && x2);
+  MFP_CHECK_ARG(((uintptr_t)W1 % 16) == 0 && ((uintptr_t)W2 % 16) == 0 && ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)h % 16) == 0 &&
+                ((uintptr_t)x2 % 16) == 0 && ((uintptr_t)x2_bf16 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)b2 % 16) == 0 &&
+                ((uintptr_t)gamma2 % 16) == 0 && ((uintptr_t)beta2 % 16) == 0);
+  p.gamma2 = gamma2; p.beta2 = beta2;
+  p.W1 = reinterpret_cast<const unsigned short*>(W1); p.b1 = b1;
+  p.W2 = reinterpret_cast<const unsigned short*>(W2); p.b2 = b2;
+  p.y2 = reinterpret_cast<unsigned short*>(y2); p.mean2 = mean2; p.rstd2 = rstd2;
+  p.h = reinterpret_cast<unsigned short*>(h); p.x2 = x2; p.x2c = reinterpret_cast<unsigned short*>(x2_bf16);
+  p.offset2 = offset_mlp;
+  if (int rc = launch_block(p, true, B, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

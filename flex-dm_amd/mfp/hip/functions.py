@@ -31,6 +31,8 @@ MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
 # bf16 path, d_model 256, documents of exactly 128 positions: LN1 + Q|K|V + attention + output projection + dropout +
 # residual of a block as ONE launch (csrc/block_attn.hip: a 128-row tile is a document); 0 = the three launches
 ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
+# ... and the MLP half behind it on the same tile: the whole block forward in one launch; 0 = attention half + mlp_fused
+BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
 FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
 
 
@@ -329,6 +331,21 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x = x.contiguous()
+        if BLOCK_FWD and ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S:
+            # the whole block in one launch (csrc/block_attn.hip); the last block also leaves the heads' bf16 operand
+            x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)
+                    if ctx.tail["fuse"] and i == st.layout.L - 1 else None)
+            x2, saved = ops.block_fwd(
+                x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), st.cw(p + "attn/dense_query/kernel", rows=3 * D),
+                st.span(st.w, p + "attn/dense_query/bias", 3 * D), st.cw(p + "attn/combine_heads/kernel"),
+                st.weight(p + "attn/combine_heads/bias"), ctx.nvalid, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
+                st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"),
+                st.weight(p + "mlp/dense_1/bias"), B, S, NUM_HEADS, ctx.p, ctx.seed, 2 * i + 1, 2 * i + 2, ctx.step_ptr, x2_c=x2_c)
+            y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = saved
+            ctx.tail["x_c"] = (x2, x2_c) if x2_c is not None else None
+            fctx.ctx, fctx.i = ctx, i
+            fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
+            return x2
         if ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S:
             # the whole attention half in one launch
             x1, y1, mean1, rstd1, qkv, a, lse = ops.attn_block_fwd(

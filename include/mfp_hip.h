@@ -167,6 +167,17 @@ int mfp_attn_block_fwd(const float* x, const float* gamma, const float* beta, co
                        float eps, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
                        mfp_stream_t stream);
 
+/* A whole DeepSVG block, forward, in one launch (transformer.py:211-229): mfp_attn_block_fwd followed, on the same
+ * 128-row tile, by mfp_mlp_fused_fwd (x2 = x1 + Dropout(relu(LN2(x1) W1^T + b1) W2^T + b2)); same saved tensors, same
+ * dropout streams (offset_attn / offset_mlp), x2_bf16 optional as in mfp_mlp_fused_fwd.  S = 128, d_model 256. */
+int mfp_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                  const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
+                  void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
+                  const void* W1, const float* b1, const void* W2, const float* b2, void* y2, float* mean2,
+                  float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
+                  float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
+                  const int32_t* step_ptr, mfp_stream_t stream);
+
 /* LayerNormalization + the fused Q | K | V Dense of a block in one launch (transformer.py:216-217,85-90):
  * qkv bf16 [T,768] = LN(x) W^T + bias, with y1 = LN(x) (bf16 [T,256]), mean, rstd (f32 [T]) saved for the
  * backward pass.  x f32 [T,256]; W bf16 [768][256] (out, in); d_model 256 only. */

@@ -980,3 +980,44 @@ def test_attn_block_fwd(B, p):
         assert_close(x1, want_x1, 2e-3, 1e-3, "x1 vs double")
     # same dropout mask as the projection kernel: where both kept / dropped the values agree
     assert_close(x1, x1u.cpu().double(), 3e-2, 2e-2, "x1 vs the three launches")
+
+
+@pytest.mark.parametrize("B,p", [(3, 0.0), (4, 0.1)])
+def test_block_fwd(B, p):
+    """mfp_block_fwd: a whole DeepSVG block forward in ONE launch against mfp_attn_block_fwd + mfp_mlp_fused_fwd (same
+    dropout streams): the attention half bit for bit, the MLP half within bf16 rounding (LN2 statistics are summed in
+    another order), plus a double reference of the MLP half from the kernel's own x1."""
+    ops = _ops()
+    S, D, H = 128, 256, 8
+    T = B * S
+    g = torch.Generator().manual_seed(300 + B)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(T, D) * (1.0 + torch.rand(T, 1, generator=g))
+    g1, b1_, g2, b2_ = 1.0 + 0.2 * rn(D), 0.1 * rn(D), 1.0 + 0.2 * rn(D), 0.1 * rn(D)
+    Wqkv, bqkv, Wo, bo = bf16_round(rn(3 * D, D) * 0.08), rn(3 * D) * 0.1, bf16_round(rn(D, D) * 0.06), rn(D) * 0.1
+    W1, c1, W2, c2 = bf16_round(rn(2 * D, D) * 0.06), rn(2 * D) * 0.1, bf16_round(rn(D, 2 * D) * 0.05), rn(D) * 0.1
+    nvalid = torch.randint(1, S + 1, (B,), generator=g).to(torch.int32)
+    step = torch.full((1,), 1, dtype=torch.int32, device=DEV)
+    d = lambda t, dt=None: t.to(DEV, dt) if dt else t.to(DEV)
+    bf = torch.bfloat16
+    args = (d(x), d(g1), d(b1_), d(Wqkv, bf), d(bqkv), d(Wo, bf), d(bo), d(nvalid))
+    x2c = torch.empty(T, D, dtype=bf, device=DEV)
+    x2, (y1, m1, r1, qkv, a, lse, x1, y2, m2, r2, h) = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H,
+                                                                       p, 7, 3, 4, step, x2_c=x2c)
+    x1u, y1u, m1u, r1u, qkvu, au, lseu = ops.attn_block_fwd(*args, B, S, H, (p, 7, 3), step)
+    for got, want in ((y1, y1u), (qkv, qkvu), (a, au)):
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(x1, x1u) and torch.equal(lse, lseu) and torch.equal(m1, m1u) and torch.equal(r1, r1u)
+    x2u, y2u, m2u, r2u, hu = ops.mlp_fused_fwd(x1u, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), (p, 7, 4), step)
+    assert_close(m2, m2u.cpu().double(), 1e-5, 1e-5, "mean2")
+    assert_close(r2, r2u.cpu().double(), 1e-5, 1e-5, "rstd2")
+    assert (y2 != y2u).float().mean().item() < 0.01 and (y2.float() - y2u.float()).abs().max().item() <= 0.04
+    assert_close(h, hu.float().cpu().double(), 3e-2, 2e-2, "h vs mlp_fused")
+    assert_close(x2, x2u.cpu().double(), 3e-2, 2e-2, "x2 vs mlp_fused")
+    assert torch.equal(x2c.view(torch.int16), x2.to(bf).view(torch.int16))
+    if p == 0.0:
+        y2d = y2.float().cpu().double()
+        hd = torch.relu(y2d @ W1.double().t() + c1.double())
+        assert_close(h, hd, 2e-2, 1e-2, "h vs double")
+        want = x1.cpu().double() + h.float().cpu().double() @ W2.double().t() + c2.double()
+        assert_close(x2, want, 5e-3, 2e-3, "x2 vs double")

@@ -54,3 +54,17 @@ if "attnblock" in which:
         a, lse = ops.attention_fwd(qkv, nvalid, B, 128, 8)
         return ops.gemm(a, Wo, T, 256, 256, a_kmajor=True, b_kmajor=True, bias=bo, residual=x, dropout=(0.1, 5, 3), step_ptr=step, out_dtype=torch.float32)
     timeit("qkv+attn+oproj (3)", three, T * (256 * 4 * 3 + 256 * 2 * 4 + 768 * 2 * 2))
+if "block" in which:
+    B = T // 128
+    Wq, bq = rnd(768, 256), torch.randn(768, device=dev)
+    Wo, bo = rnd(256, 256), torch.randn(256, device=dev)
+    W1, b1, W2, b2 = rnd(512, 256), torch.randn(512, device=dev), rnd(256, 512), torch.randn(256, device=dev)
+    g2, be2 = torch.rand(D, device=dev) + 0.5, torch.randn(D, device=dev)
+    nvalid = torch.full((B,), 128, dtype=torch.int32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    timeit("block_fwd (1 launch)", lambda: ops.block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8, 0.1, 5, 3, 4, step),
+           T * (256 * 4 * 5 + 256 * 2 * 3 + 768 * 2 + 512 * 2))
+    def two():
+        x1 = ops.attn_block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, B, 128, 8, (0.1, 5, 3), step)[0]
+        return ops.mlp_fused_fwd(x1, g2, be2, W1, b1, W2, b2, (0.1, 5, 4), step)
+    timeit("attn_block + mlp_fused", two, T * (256 * 4 * 6 + 256 * 2 * 3 + 768 * 2 + 512 * 2))
