@@ -97,6 +97,9 @@ _KERNEL_FAMILY = (("attn_bwd", "attn_bwd"), ("attn_fwd", "attn_fwd"), ("ce_tile_
 
 
 def kernel_family(device_name):
+    if "attn_block_fwd_kernel" in device_name:    # <DROPOUT, MLP>: the whole-block variant is booked as block_fwd_kernel
+        args_ = device_name.split("attn_block_fwd_kernel<")[-1].split(">")[0].replace(" ", "").split(",")
+        return "block_fwd_kernel" if args_[-1] in ("true", "1") else "attn_block_fwd_kernel"
     for key, fam in _KERNEL_FAMILY:
         if key in device_name:
             return fam

@@ -92,6 +92,7 @@ SIGNATURES = {
                                                    c_void_p, c_void_p]),
     "mfp_attn_block_fwd": (c_int32, [c_void_p] * 15 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_block_fwd": (c_int32, [c_void_p] * 27 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "mfp_attn_block_bwd": (c_int32, [c_void_p] * 9 + [c_int32] * 4 + [c_void_p]),
     "mfp_qkv_fused_fwd": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_float, c_void_p]),
     "mfp_dgrad_d256": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_dgrad_qkv": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

@@ -382,6 +382,19 @@ def dgrad_qkv(dqkv: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
     return dy
 
 
+def attn_block_bwd(d_o1, Wot, qkv, a, lse, nvalid, Wqkvt, B: int, S: int, H: int):
+    """(dqkv, dy1) of the attention half of a block in ONE launch (see mfp_attn_block_bwd): da = d_o1 Wo stays on chip."""
+    lib = load()
+    T, D = d_o1.shape
+    dqkv = torch.empty((T, 3 * D), dtype=torch.bfloat16, device=d_o1.device)
+    dy1 = torch.empty((T, D), dtype=torch.bfloat16, device=d_o1.device)
+    flops = 2 * T * D * D + 10 * B * S * S * D + 2 * T * 3 * D * D
+    with _timed("attn_block_bwd_kernel", flops, T * (D * 2 * 3 + 3 * D * 2 * 2) + 4 * D * D * 2):
+        check(lib.mfp_attn_block_bwd(_ptr(d_o1), _ptr(Wot), _ptr(qkv), _ptr(a), _ptr(lse), _ptr(nvalid), _ptr(Wqkvt),
+                                     _ptr(dqkv), _ptr(dy1), B, S, D, H, _stream()), "mfp_attn_block_bwd")
+    return dqkv, dy1
+
+
 def encoder_dense2(xs, Ws, biases, codes, h: torch.Tensor) -> torch.Tensor:
     """h += sum_j [codes[j] == 0] (xs[j] Ws[j]^T + biases[j]) for two 512-wide numerical attributes, in place."""
     lib = load()

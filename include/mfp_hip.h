@@ -197,6 +197,16 @@ int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t
 /* The same machine for a 256 -> 256 Dense (the attention output projection): dx bf16 [T,256] = dy W, Wt bf16 [256][256]. */
 int mfp_dgrad_d256(const void* dy, const void* Wt, void* dx, int32_t T, int32_t D, mfp_stream_t stream);
 
+/* The attention half of a block, backward input-gradient chain, in one launch (Keras autodiff of transformer.py:216-221,
+ * 60-99) -- replaces mfp_dgrad_d256 + mfp_attention_bwd + mfp_dgrad_qkv for documents of exactly 128 positions:
+ * da = d_o1 Wo (stays on chip), dqkv = MHSA'(qkv, a, lse; da) (bf16 [T,768], written for the weight-gradient launch),
+ * dy1 = dqkv Wqkv (bf16 [T,256]).  d_o1 bf16 [T,256] = dropout-masked gradient of the projection output; Wot bf16
+ * [256][256] / Wqkvt bf16 [256][768] = the transposed (k-major) shadows mfp_dgrad_d256 / mfp_dgrad_qkv take; qkv, a,
+ * lse as saved by the forward pass; nvalid int32 [B].  S = 128, d_model 256, 8 heads. */
+int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void* qkv, const void* a, const float* lse,
+                       const int32_t* nvalid, const void* Wqkvt, void* dqkv, void* dy1, int32_t B, int32_t S,
+                       int32_t D, int32_t H, mfp_stream_t stream);
+
 /* Encoder, both 512-wide numerical attributes in one launch (encoder.py:156-160,174-175,194-198):
  * h[t] += sum_j [code_j[t] == 0] (x_j[t] W_j^T + b_j), x_j bf16 [T,512], W_j bf16 [256][512], b_j f32 [256],
  * code_j u8 [T] (non-zero: the attribute is masked / absent at that position and contributes nothing here),

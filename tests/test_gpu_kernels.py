@@ -982,6 +982,52 @@ def test_attn_block_fwd(B, p):
     assert_close(x1, x1u.cpu().double(), 3e-2, 2e-2, "x1 vs the three launches")
 
 
+@pytest.mark.parametrize("B", [1, 5])
+def test_attn_block_bwd(B):
+    """mfp_attn_block_bwd: da = d_o1 Wo, dqkv = MHSA'(...; da), dy1 = dqkv Wqkv in ONE launch (autodiff of
+    transformer.py:216-221,60-99; documents of 128 positions) against the three launches it replaces (mfp_dgrad_d256,
+    mfp_attention_bwd, mfp_dgrad_qkv) and a double reference built from the same bf16 inputs; ragged key masks."""
+    ops = _ops()
+    S, D, H = 128, 256, 8
+    T = B * S
+    g = torch.Generator().manual_seed(700 + B)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    bf = torch.bfloat16
+    d = lambda t, dt=None: t.to(DEV, dt) if dt else t.to(DEV)
+    qkv = d(rn(T, 3 * D) * 0.7, bf)
+    nvalid = torch.randint(1, S + 1, (B,), generator=g).to(torch.int32)
+    nvalid[0] = S
+    nvd = d(nvalid)
+    a, lse = ops.attention_fwd(qkv, nvd, B, S, H)
+    Wo = bf16_round(rn(D, D) * 0.06)
+    Wqkv = bf16_round(rn(3 * D, D) * 0.08)
+    d_o1 = d(rn(T, D) * 0.5, bf)
+    Wot, Wqt = d(Wo.t().contiguous(), bf), d(Wqkv.t().contiguous(), bf)
+    dqkv, dy1 = ops.attn_block_bwd(d_o1, Wot, qkv, a, lse, nvd, Wqt, B, S, H)
+    # the three launches
+    da_u = ops.dgrad_d256(d_o1, Wot)
+    dqkv_u = ops.attention_bwd(qkv, nvd, a, da_u, lse, B, S, H)
+    dy1_u = ops.dgrad_qkv(dqkv_u, Wqt)
+    assert_close(dqkv, dqkv_u.float().cpu().double(), 2e-2, 2e-2, "dqkv vs the three launches")
+    assert_close(dy1, dy1_u.float().cpu().double(), 2e-2, 2e-2, "dy1 vs the three launches")
+    assert (dqkv != dqkv_u).float().mean().item() < 0.15          # same operands; only the summation order of dQ differs
+    # double reference: da rounded to bf16 as both paths hold it, softmax from the saved lse
+    q64 = qkv.float().cpu().double().view(B, S, 3, H, 32)
+    da64 = bf16_round((d_o1.float().cpu() @ Wo).float()).double().view(B, S, H, 32)
+    a64 = a.float().cpu().double().view(B, S, H, 32)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q64[:, :, 0], q64[:, :, 1]) / 32 ** 0.5
+    sc = sc + ((torch.arange(S)[None, :] >= nvalid[:, None]).double() * -1e9)[:, None, None, :]
+    P = torch.exp(sc - lse.cpu().double()[..., None])
+    dP = torch.einsum("bqhd,bkhd->bhqk", da64, q64[:, :, 2])
+    delta = (da64 * a64).sum(-1).permute(0, 2, 1)                  # [B,H,S]
+    dS = P * (dP - delta[..., None]) / 32 ** 0.5
+    want = torch.stack([torch.einsum("bhqk,bkhd->bqhd", dS, q64[:, :, 1]), torch.einsum("bhqk,bqhd->bkhd", dS, q64[:, :, 0]),
+                        torch.einsum("bhqk,bqhd->bkhd", P, da64)], dim=2).reshape(T, 3 * D)
+    assert_close(dqkv, want, 3e-2, 3e-2, "dqkv vs double")
+    want_dy1 = dqkv.float().cpu().double() @ Wqkv.double()
+    assert_close(dy1, want_dy1, 1e-2, 1e-2, "dy1 vs double (from the kernel's own dqkv)")
+
+
 @pytest.mark.parametrize("B,p", [(3, 0.0), (4, 0.1)])
 def test_block_fwd(B, p):
     """mfp_block_fwd: a whole DeepSVG block forward in ONE launch against mfp_attn_block_fwd + mfp_mlp_fused_fwd (same

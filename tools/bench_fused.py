@@ -68,3 +68,15 @@ if "block" in which:
         x1 = ops.attn_block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, B, 128, 8, (0.1, 5, 3), step)[0]
         return ops.mlp_fused_fwd(x1, g2, be2, W1, b1, W2, b2, (0.1, 5, 4), step)
     timeit("attn_block + mlp_fused", two, T * (256 * 4 * 6 + 256 * 2 * 3 + 768 * 2 + 512 * 2))
+if "attnbwd" in which:
+    B = T // 128
+    qkv = (torch.randn(T, 768, device=dev) * 0.7).to(torch.bfloat16)
+    nvalid = torch.full((B,), 128, dtype=torch.int32, device=dev)
+    a, lse = ops.attention_fwd(qkv, nvalid, B, 128, 8)
+    d_o1, Wot, Wqt = rnd(T, 256), rnd(256, 256), rnd(256, 768)
+    timeit("attn_block_bwd (1)", lambda: ops.attn_block_bwd(d_o1, Wot, qkv, a, lse, nvalid, Wqt, B, 128, 8), T * (256 * 2 * 3 + 768 * 2 * 2))
+    def three_b():
+        da = ops.dgrad_d256(d_o1, Wot)
+        dq = ops.attention_bwd(qkv, nvalid, a, da, lse, B, 128, 8)
+        return ops.dgrad_qkv(dq, Wqt)
+    timeit("dgrad+attn_bwd+dgrad (3)", three_b, T * (256 * 2 * 5 + 768 * 2 * 3))
