@@ -26,6 +26,10 @@
 #ifndef BB_ABL
 #define BB_ABL 0
 #endif
+// BB_ABL == 9: timing build (tools/trace_attn_bwd.py): every wave drops shader-clock stamps at its phase boundaries into
+// the dy1 buffer (scalar stores: no vector-memory operation added) instead of the dy1 rows
+#define BB_TR(i) do { if (BB_ABL == 9) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    asm volatile("s_store_dwordx2 %0, %1, %2 glc" :: "s"(t_), "s"(trbase), "n"((i) * 8) : "memory"); } } while (0)
 
 namespace {
 
@@ -44,12 +48,13 @@ struct AttnBwdBlockParams {
 
 constexpr int BB_ROWS = 128, BB_D = 256;
 constexpr int BB_IMG = BB_ROWS * 128;                 // 16 KB
-constexpr int BB_Q = 0, BB_K = BB_IMG, BB_V = 2 * BB_IMG, BB_O = 3 * BB_IMG;
-constexpr int BB_DS = 4 * BB_IMG;                     // [2 heads][128 keys][64 B]
-constexpr int BB_LSD = BB_DS + 2 * 8192;              // [2 heads]{Ls[128], Dl[128]} f32
-constexpr int BB_WS = BB_LSD + 2048;                  // 2 x 32 KB weight ring
-constexpr int BB_WS_B = 32768;
-constexpr int BB_LDS = BB_WS + 2 * BB_WS_B;           // 149 504 B
+constexpr int BB_DA = 0;                              // da [128][512 B]; at the end the dy1 image
+constexpr int BB_Q = BB_ROWS * 512, BB_K = BB_Q + BB_IMG, BB_V = BB_K + BB_IMG;
+constexpr int BB_LSD = BB_K;                          // during the attention: [2 heads]{Ls[128], Dl[128]} f32 over the k image
+constexpr int BB_DS = BB_V;                           // during the attention: dS [2 heads][128 keys][64 B] over the v image
+constexpr int BB_WS = BB_V + BB_IMG;                  // 3 x 16 KB weight ring
+constexpr int BB_WS_B = 16384;
+constexpr int BB_LDS = BB_WS + 3 * BB_WS_B;           // 163 840 B: all of a CU's LDS
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
@@ -61,7 +66,9 @@ __device__ __forceinline__ void bb_static_for(F&& f) {
   }
 }
 
-__device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }                             // 128-byte rows, 16-byte slots
+__device__ __forceinline__ int dsw(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }        // 512-byte rows (da image)
+__device__ __forceinline__ int swz64(int row) { return ((row >> 2) & 1) << 1; }                    // 64-byte rows
 __device__ __forceinline__ int hsw(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
 
 // head hh of a pair image: 8 consecutive d of row `row` starting at d = 8 lg
@@ -77,7 +84,19 @@ __device__ __forceinline__ bf16x8 pfragtr(const unsigned char* img, int hh, int 
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));     // (same swizzle: row + 16)
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-// the same out of a 32-row block of a dS image ([keys][64 B], 8-byte piece swizzle)
+// the same two out of the da image: head h8 (0..7) of the 256 columns
+__device__ __forceinline__ bf16x8 dafragk(const unsigned char* da, int h8, int row, int lg) {
+  return *reinterpret_cast<const bf16x8*>(da + row * 512 + (((h8 * 4 + lg) ^ dsw(row)) << 4));
+}
+__device__ __forceinline__ bf16x8 dafragtr(const unsigned char* da, int h8, int kb, int c0, int li, int lg) {
+  const int row = kb + 4 * lg + (li >> 2);
+  const int P = h8 * 8 + (c0 >> 2) + (li & 3);
+  const unsigned char* ptr = da + row * 512 + ((((P >> 1) ^ dsw(row)) << 4) | ((P & 1) << 3));
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 512));     // (same swizzle: row + 16)
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// out of a 32-row block of a dS image ([keys][64 B], 8-byte piece swizzle)
 __device__ __forceinline__ bf16x8 dstr(const unsigned char* blk, int c0, int li, int lg) {
   const int row = 4 * lg + (li >> 2);
   const int P = (c0 >> 2) + (li & 3);
@@ -90,7 +109,25 @@ __device__ __forceinline__ bf16x8 bb_pack(const f32x4& a, const f32x4& b) {
   const u32x4 r = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
   return __builtin_bit_cast(bf16x8, r);
 }
+__device__ __forceinline__ float dot8(const u32x4& x, const u32x4& y) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s += bf16_to_f32((unsigned short)(x[e] & 0xffff)) * bf16_to_f32((unsigned short)(y[e] & 0xffff));
+    s += bf16_to_f32((unsigned short)(x[e] >> 16)) * bf16_to_f32((unsigned short)(y[e] >> 16));
+  }
+  return s;
+}
 
+// Weight chunks, in consumption order: seq 0..7 = Wot rows 32 c .. + 31 ([32][512 B], slot ^ (row & 15)); seq 8 + 6 p + j =
+// Wqkvt rows 0..255, k = (j >> 1) * 256 + 64 p + 32 (j & 1) .. + 31 ([256][64 B], slot ^ swz64(row)); ring slot = seq % 3.
+// Memory operations retire in order, so "chunk seq has landed" = s_waitcnt vmcnt(number of operations issued after its two
+// loads); the schedule below issues per wave, in this order (P = 9 prefetch loads of the next pair's q | k | v, a, lse; S = 2 stores):
+//   prologue: ... A0 A1 | step c of the da product: wait(2) barrier, issue chunk c + 2 (A.., then pair 0's j = 0, 1)
+//   after the K / V fragment reads of a pair: the pair's chunk j = 2
+//   pair, step j: wait(N_j) barrier; j = 0: P S(dq); j = 1: chunk 3; j = 2: S(dk) chunk 4; j = 3: chunk 5;
+//                 j = 4: S(dv) next pair's chunk 0; j = 5: next pair's chunk 1
+//   N_0 = 4 (chunks 1, 2)  N_1 = N_2 = 2 + P + S = 13 (4 in the last pair: no P)  N_3 = 4  N_4 = 2  N_5 = 4 (2 in the last pair)
 __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Ws = smem + BB_WS;
@@ -101,9 +138,10 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
   const int k0 = 32 * w4, dt_w = w4 & 1, qt_w = w4 >> 1;
   const int doc = blockIdx.x, row0 = doc * BB_ROWS;
   constexpr float LOG2E = 1.4426950408889634f;
-  constexpr unsigned int OOB = 0xFFFFFFF0u;
   const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[doc]);
   const float c2 = p.scale * LOG2E;
+  const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.dy1) + (size_t)(doc * 8 + wave) * 64;
+  BB_TR(0);
 
   const unsigned int xbytes = (unsigned int)p.T * (BB_D * 2);
   const __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.d_o1), 0, xbytes, 0x00020000);
@@ -115,45 +153,43 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
   const __amdgpu_buffer_rsrc_t rs_dq = __builtin_amdgcn_make_buffer_rsrc(p.dqkv, 0, (unsigned int)p.T * (768 * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(p.dy1, 0, xbytes, 0x00020000);
 
-  // ---- weight chunk cg = 4 pr + t into ring buffer cg & 1.  t = 0: Wot rows 64 pr .. + 63, all 256 k -> [64][512 B],
-  // slot ^ (row & 15); t = 1, 2, 3: Wqkvt rows 0 .. 255, k = (t - 1) * 256 + 64 pr .. + 63 -> [256][128 B], slot ^ isw(row)
-  const unsigned int w1off = (unsigned int)((wave * 8 + (lane >> 5)) * 512 + (((lane & 31) ^ ((wave & 1) * 8 + (lane >> 5))) << 4));
-  auto wload = [&](int cg) {
-    const int pr = cg >> 2, t = cg & 3;
-    unsigned char* dst = Ws + (cg & 1) * BB_WS_B + wave * 4096;
-    if (t == 0) {
-      const int base = (pr * 64) * (BB_D * 2);
+  auto wloadA = [&](int c) {           // seq c
+    unsigned char* dst = Ws + (c % 3) * BB_WS_B + wave * 2048;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wo, (lds_u8*)(dst + i * 1024), 16, w1off ^ (i << 5), base + i * 1024, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + (lane >> 3);
-        const unsigned int vo = (unsigned int)(row * (768 * 2) + (((lane & 7) ^ isw(row)) << 4));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wq, (lds_u8*)(dst + i * 1024), 16, vo, ((t - 1) * 256 + pr * 64) * 2, 0, 0);
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int row = wave * 4 + i * 2 + (lane >> 5);
+      const unsigned int vo = (unsigned int)(row * 512 + (((lane & 31) ^ (row & 15)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wo, (lds_u8*)(dst + i * 1024), 16, vo, c * (32 * 512), 0, 0);
     }
   };
-  // ---- q / k / v columns of pair pr -> the three images: 48 instructions of 8 rows x 128 B, six per wave
-  auto iload = [&](int pr) {
+  auto wloadP = [&](int pr, int j) {   // seq 8 + 6 pr + j
+    unsigned char* dst = Ws + ((8 + 6 * pr + j) % 3) * BB_WS_B + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wave * 32 + i * 16 + (lane >> 2);
+      const unsigned int vo = (unsigned int)(row * (768 * 2) + (((lane & 3) ^ swz64(row)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wq, (lds_u8*)(dst + i * 1024), 16, vo, ((j >> 1) * 256 + pr * 64 + (j & 1) * 32) * 2, 0, 0);
+    }
+  };
+  // the q | k | v columns of pair pr: six 16-byte pieces per thread (piece i: image i >> 1, row (tid + 512 (i & 1)) >> 3)
+  u32x4 nq[6];
+  auto qkv_fetch = [&](int pr) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const int idx = wave * 6 + i, t = idx >> 4, row = (idx & 15) * 8 + (lane >> 3);
-      const unsigned int vo = (unsigned int)((row0 + row) * (768 * 2) + (((lane & 7) ^ isw(row)) << 4));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, (lds_u8*)(smem + t * BB_IMG + (idx & 15) * 1024), 16, vo, (t * 256 + pr * 64) * 2, 0, 0);
+      const int idx = tid + 512 * (i & 1), r = idx >> 3, c16 = idx & 7;
+      nq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_qkv, (unsigned int)(row0 + r) * (768 * 2) + (i >> 1) * 512 + pr * 128 + c16 * 16, 0, 0);
     }
   };
-  iload(0);
-  wload(0);
-
-  f32x4 acc2[8][2];      // dy1 accumulators: column tile T = (ct >> 2) * 8 + nh * 4 + (ct & 3), rows 32 rp + 16 rt + li
-  int xs[4];
+  auto qkv_place = [&]() {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 512 * (i & 1), r = idx >> 3, c16 = idx & 7;
+      *reinterpret_cast<u32x4*>(smem + BB_Q + (i >> 1) * BB_IMG + r * 128 + ((c16 ^ isw(r)) << 4)) = nq[i];
+    }
+  };
   // an image's rows -> dqkv columns t * 256 + 64 pr .. (128-byte pieces)
   auto stash = [&](int pr, int t) {
-    const unsigned char* img = smem + t * BB_IMG;
+    const unsigned char* img = smem + BB_Q + t * BB_IMG;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 512 * i, r = idx >> 3, c16 = idx & 7;
@@ -161,34 +197,21 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
       __builtin_amdgcn_raw_buffer_store_b128(v, rs_dq, (unsigned int)(row0 + r) * (768 * 2) + t * 512 + pr * 128 + c16 * 16, 0, 0);
     }
   };
-  // K = 64 product: acc2 += image t (A operand) x ring buffer `buf` ([256][128 B] chunk)
-  auto kprod = [&](int t, int buf, bool first) {
-    if (BB_ABL == 2) { if (first) for (int ct = 0; ct < 8; ++ct) acc2[ct][0] = acc2[ct][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; return; }
-    const unsigned char* ai = smem + t * BB_IMG;
-    const unsigned char* wb = Ws + buf * BB_WS_B;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 hf[2];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int row = rp * 32 + rt * 16 + li;
-        hf[rt] = *reinterpret_cast<const bf16x8*>(ai + row * 128 + (((ks * 4 + g) ^ isw(row)) << 4));
-      }
-#pragma unroll
-      for (int ct = 0; ct < 8; ++ct) {
-        const int wrow = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + li;
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + wrow * 128 + (((ks * 4 + g) ^ isw(wrow)) << 4));
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-          acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf[rt], (first && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[ct][rt], 0, 0, 0);
-      }
-    }
-  };
 
-  auto pair = [&](auto pp_) {
-    constexpr int pr = decltype(pp_)::value;
-    constexpr int cg0 = 4 * pr;
-    // ---- (a) d_o1 fragments of this wave's two row tiles (registers), (b) the a piece and lse for delta, (c) chunk c1
+  // the a pieces / lse of pair pr for its deltas: thread (row tid >> 2, 16-column quarter tid & 3: head (tid & 3) >> 1)
+  const int drow = tid >> 2, dq4 = tid & 3;
+  u32x4 a0, a1;
+  float lse_r;
+  auto a_fetch = [&](int pr) {
+    const unsigned int aoff = (unsigned int)(row0 + drow) * (BB_D * 2) + pr * 128 + dq4 * 32;
+    a0 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff, 0, 0);
+    a1 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff + 16, 0, 0);
+    lse_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+        rs_l, tid < 256 ? (unsigned int)(((doc * p.H + 2 * pr + (tid >> 7)) * BB_ROWS + (tid & 127)) * 4) : 0xFFFFFFF0u, 0, 0));
+  };
+  // ---- prologue: the d_o1 fragments and chunks 0, 1 first (the da product starts when they are in); behind them pair 0's
+  // q | k | v and a / lse (nine loads: they land under the da product)
+  {
     bf16x8 xf[2][8];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -196,188 +219,219 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
       for (int ks = 0; ks < 8; ++ks)
         xf[rt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
             rs_do, (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (BB_D * 2) + g * 16 + ks * 64, 0, 0));
-    const int drow = tid >> 2, dq4 = tid & 3;          // delta: row, 16-column quarter of the pair (head dq4 >> 1)
-    const unsigned int aoff = (unsigned int)(row0 + drow) * (BB_D * 2) + pr * 128 + dq4 * 32;
-    const u32x4 a0 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff, 0, 0);
-    const u32x4 a1 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff + 16, 0, 0);
-    const float lse_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-        rs_l, tid < 256 ? (unsigned int)(((doc * p.H + 2 * pr + (tid >> 7)) * BB_ROWS + (tid & 127)) * 4) : OOB, 0, 0));
-    wload(cg0 + 1);
-    // ---- (d) chunk c0 has landed: memory operations retire in order; younger than its loads are (pair 0) the 16 + 3 + 4
-    // operations above, (later pairs) also the two dv stores at the head of the previous c3 and the six image loads
-    if (pr == 0) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- (e) c0: da_pair = d_o1 Wot rows 64 pr .. + 63 -> image O
-    {
-      const unsigned char* wa = Ws + (cg0 & 1) * BB_WS_B + ((nh * 2) * 16 + li) * 512;
-      f32x4 acc[2][2];
+    wloadA(0);
+    wloadA(1);
+    qkv_fetch(0);
+    a_fetch(0);
+    BB_TR(1);
+    int xs[4];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      bf16x8 wf[2][2];
+    for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
+    // ---- da = d_o1 Wo: eight chunks of 32 output columns -> the da image
+    bb_static_for<0, 8>([&](auto c_) {
+      constexpr int c = decltype(c_)::value;
+      if (c < 2) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");      // younger: the next chunk + the nine
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (c == 0) BB_TR(3);
+      if (c + 2 < 8) wloadA(c + 2);
+      else wloadP(0, c + 2 - 8);
+      const unsigned char* wa = Ws + (c % 3) * BB_WS_B + (nh * 16 + li) * 512;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[0]);
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wa + xs[ks & 3] + (ks >> 2) * 256);
 #pragma unroll
-      for (int ks = 0; ks < (BB_ABL == 3 ? 1 : 8); ++ks) {
-        if (ks + 1 < 8) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+        for (int rt = 0; rt < 2; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[rt][ks], acc[rt], 0, 0, 0);
       }
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = rp * 32 + rt * 16 + li;
+        const u32x2 pk = {pack_bf16x2(acc[rt][0], acc[rt][1]), pack_bf16x2(acc[rt][2], acc[rt][3])};
+        *reinterpret_cast<u32x2*>(smem + BB_DA + row * 512 + (((4 * c + 2 * nh + (g >> 1)) ^ dsw(row)) << 4) + (g & 1) * 8) = pk;
+      }
+    });
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  BB_TR(4);
+  qkv_place();
+  BB_TR(2);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 acc2[8][2];      // dy1 accumulators: column tile T = (ct >> 2) * 8 + nh * 4 + (ct & 3), rows 32 rp + 16 rt + li
+  // one K = 32 step of the dy1 product: acc2 += image t, k half kh (A operand) x ring slot ([256][64 B] chunk)
+  auto kprod = [&](int t, int kh, int slot, bool first) {
+    const unsigned char* ai = smem + BB_Q + t * BB_IMG;
+    const unsigned char* wb = Ws + slot * BB_WS_B;
+    bf16x8 hf[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const int row = rp * 32 + rt * 16 + li;
-          const u32x2 pk = {pack_bf16x2(acc[nt][rt][0], acc[nt][rt][1]), pack_bf16x2(acc[nt][rt][2], acc[nt][rt][3])};
-          *reinterpret_cast<u32x2*>(smem + BB_O + row * 128 + ((((nh * 2 + nt) * 2 + (g >> 1)) ^ isw(row)) << 4) + (g & 1) * 8) = pk;
-        }
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = rp * 32 + rt * 16 + li;
+      hf[rt] = *reinterpret_cast<const bf16x8*>(ai + row * 128 + (((kh * 4 + g) ^ isw(row)) << 4));
     }
-    // ---- (f) the pair's q / k / v images have landed (younger: the a / lse loads and chunk c1), da is in its image
-    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const int wrow = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + li;
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + wrow * 64 + ((g ^ swz64(wrow)) << 4));
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf[rt], first ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[ct][rt], 0, 0, 0);
+    }
+  };
+
+  auto pair = [&](auto pp_) {
+    constexpr int pr = decltype(pp_)::value;
+    constexpr bool last = pr == 3;
+    BB_TR(5 + 12 * pr);
+    // ---- delta = rowsum(da * a) of the pair's two heads (this thread: a row's 16 columns), Ls = lse * log2(e)
+    float dpart;
+    {
+      const u32x4 d0 = *reinterpret_cast<const u32x4*>(smem + BB_DA + drow * 512 + (((pr * 8 + 2 * dq4) ^ dsw(drow)) << 4));
+      const u32x4 d1 = *reinterpret_cast<const u32x4*>(smem + BB_DA + drow * 512 + (((pr * 8 + 2 * dq4 + 1) ^ dsw(drow)) << 4));
+      dpart = dot8(d0, a0) + dot8(d1, a1);
+      dpart += __shfl_xor(dpart, 1, 64);
+    }
+    const float ls_w = lse_r * LOG2E;
+    // ---- this wave's K / V fragments (keys k0 .. + 31 as B operands) and K^T (d tile dt_w) of every key block; after the
+    // barrier the k / v images are free: Ls / Dl go over the first, dS over the second
+    int li_p = li, g_p = g;      // (opaque copies: the pair's LDS addresses are worked out here, not kept from kernel entry)
+    asm volatile("" : "+v"(li_p), "+v"(g_p));
+    bf16x8 bk[2], bv[2], kT[4];
+    float madd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = k0 + 16 * t + li_p;
+      bk[t] = pfragk(smem + BB_K, hh, j, g_p);
+      bv[t] = pfragk(smem + BB_V, hh, j, g_p);
+      madd[t] = j < nv ? 0.f : -1e9f * LOG2E;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) kT[kb] = pfragtr(smem + BB_K, hh, 32 * kb, 16 * dt_w, li_p, g_p);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    wload(cg0 + 2);        // into c0's buffer; lands under the attention phase
-    // ---- (g) delta = rowsum(da * a) per head, Ls = lse * log2(e)
+    // (the compiler drains every LDS-DMA before a transposing LDS read: the pair's third chunk is issued behind those reads)
+    wloadP(pr, 2);
     {
       float* const LsD = reinterpret_cast<float*>(smem + BB_LSD);
-      const u32x4 d0 = *reinterpret_cast<const u32x4*>(smem + BB_O + drow * 128 + (((2 * dq4) ^ isw(drow)) << 4));
-      const u32x4 d1 = *reinterpret_cast<const u32x4*>(smem + BB_O + drow * 128 + (((2 * dq4 + 1) ^ isw(drow)) << 4));
-      float part = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        part += bf16_to_f32((unsigned short)(d0[e] & 0xffff)) * bf16_to_f32((unsigned short)(a0[e] & 0xffff));
-        part += bf16_to_f32((unsigned short)(d0[e] >> 16)) * bf16_to_f32((unsigned short)(a0[e] >> 16));
-        part += bf16_to_f32((unsigned short)(d1[e] & 0xffff)) * bf16_to_f32((unsigned short)(a1[e] & 0xffff));
-        part += bf16_to_f32((unsigned short)(d1[e] >> 16)) * bf16_to_f32((unsigned short)(a1[e] >> 16));
-      }
-      part += __shfl_xor(part, 1, 64);
-      if ((dq4 & 1) == 0) LsD[(dq4 >> 1) * 256 + 128 + drow] = part;
-      if (tid < 256) LsD[(tid >> 7) * 256 + (tid & 127)] = lse_r * LOG2E;
+      if ((dq4 & 1) == 0) LsD[(dq4 >> 1) * 256 + 128 + drow] = dpart;
+      if (tid < 256) LsD[(tid >> 7) * 256 + (tid & 127)] = ls_w;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // ---- (h) attention backward of head 2 pr + hh: this wave owns keys k0 .. + 31
+    // ---- attention backward of head 2 pr + hh: this wave owns keys k0 .. + 31 (see attn_bwd1_hd32, csrc/attention.hip)
+    BB_TR(6 + 12 * pr);
     {
       const unsigned char* const Qi = smem + BB_Q;
-      const unsigned char* const Ki = smem + BB_K;
-      const unsigned char* const Vi = smem + BB_V;
-      const unsigned char* const Oi = smem + BB_O;
+      const unsigned char* const Da = smem + BB_DA;
       unsigned char* const dsi = smem + BB_DS + hh * 8192;
       const float* const Ls = reinterpret_cast<const float*>(smem + BB_LSD) + hh * 256;
       const float* const Dl = Ls + 128;
-      bf16x8 bk[2], bv[2];
-      float madd[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int j = k0 + 16 * t + li;
-        bk[t] = pfragk(Ki, hh, j, g);
-        bv[t] = pfragk(Vi, hh, j, g);
-        madd[t] = j < nv ? 0.f : -1e9f * LOG2E;
-      }
-      f32x4 dk[2][2], dv[2][2], dq[4];
-      if (BB_ABL == 1) dq[0] = dq[1] = dq[2] = dq[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int h8 = 2 * pr + hh;
+      f32x4 dk[2][2], dv[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) { dk[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int qb = 0; qb < (BB_ABL == 1 ? 0 : 4); ++qb) {
-        f32x4 pp[2][2], ds[2][2];     // [query tile][key tile]
+        u32x2 ppk[2][2], dsk[2][2];     // P and dS as bf16 pairs, [query tile][key tile]
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           const int q = qb * 32 + qt * 16;
-          const bf16x8 aq = pfragk(Qi, hh, q + li, g), ado = pfragk(Oi, hh, q + li, g);
-          const f32x4 Lr = *reinterpret_cast<const f32x4*>(Ls + q + 4 * g);
-          const f32x4 Dr = *reinterpret_cast<const f32x4*>(Dl + q + 4 * g);
+          const bf16x8 aq = pfragk(Qi, hh, q + li_p, g_p), ado = dafragk(Da, h8, q + li_p, g_p);
+          const f32x4 Lr = *reinterpret_cast<const f32x4*>(Ls + q + 4 * g_p);
+          const f32x4 Dr = *reinterpret_cast<const f32x4*>(Dl + q + 4 * g_p);
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bk[t], z, 0, 0, 0);
             const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado, bv[t], z, 0, 0, 0);
+            float pe[4], de[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, madd[t]) - Lr[r]);
-              pp[qt][t][r] = pe;
-              ds[qt][t][r] = pe * (dpacc[r] - Dr[r]);
+              pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, madd[t]) - Lr[r]);
+              de[r] = pe[r] * (dpacc[r] - Dr[r]);
             }
-            const int row = k0 + 16 * t + li;
-            const u32x2 pk = {pack_bf16x2(ds[qt][t][0], ds[qt][t][1]), pack_bf16x2(ds[qt][t][2], ds[qt][t][3])};
-            *reinterpret_cast<u32x2*>(dsi + row * 64 + (((4 * qt + g) ^ hsw(row)) << 3)) = pk;
+            ppk[qt][t] = (u32x2){pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3])};
+            dsk[qt][t] = (u32x2){pack_bf16x2(de[0], de[1]), pack_bf16x2(de[2], de[3])};
+            const int row = k0 + 16 * t + li_p;
+            *reinterpret_cast<u32x2*>(dsi + row * 64 + (((4 * qt + g_p) ^ hsw(row)) << 3)) = dsk[qt][t];
           }
         }
-        const bf16x8 doT0 = pfragtr(Oi, hh, qb * 32, 0, li, g), doT1 = pfragtr(Oi, hh, qb * 32, 16, li, g);
-        const bf16x8 qT0 = pfragtr(Qi, hh, qb * 32, 0, li, g), qT1 = pfragtr(Qi, hh, qb * 32, 16, li, g);
+        const bf16x8 doT0 = dafragtr(Da, h8, qb * 32, 0, li_p, g_p), doT1 = dafragtr(Da, h8, qb * 32, 16, li_p, g_p);
+        const bf16x8 qT0 = pfragtr(Qi, hh, qb * 32, 0, li_p, g_p), qT1 = pfragtr(Qi, hh, qb * 32, 16, li_p, g_p);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const bf16x8 bp = bb_pack(pp[0][t], pp[1][t]);
-          const bf16x8 bds = bb_pack(ds[0][t], ds[1][t]);
+          const bf16x8 bp = __builtin_bit_cast(bf16x8, (u32x4){ppk[0][t][0], ppk[0][t][1], ppk[1][t][0], ppk[1][t][1]});
+          const bf16x8 bds = __builtin_bit_cast(bf16x8, (u32x4){dsk[0][t][0], dsk[0][t][1], dsk[1][t][0], dsk[1][t][1]});
           dv[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT0, bp, dv[t][0], 0, 0, 0);
           dv[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT1, bp, dv[t][1], 0, 0, 0);
           dk[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT0, bds, dk[t][0], 0, 0, 0);
           dk[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT1, bds, dk[t][1], 0, 0, 0);
         }
-        // every wave's dS tile of this query block is in the head's image: dQ^T tile (dt_w, qt_w) over all 128 keys
+        // every wave's dS tile of this query block is in the head's image: dQ^T tile (dt_w, qt_w) over all 128 keys; the
+        // q image's rows of this block have been read for the last time, dq (bf16, scaled) goes over them
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         f32x4 accq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
-          accq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfragtr(Ki, hh, 32 * kb, 16 * dt_w, li, g), dstr(dsi + kb * 2048, 16 * qt_w, li, g), accq, 0, 0, 0);
-        dq[qb] = accq;
-        // (single dS image per head: everyone has read it before the next query block's tiles go in)
+          accq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[kb], dstr(dsi + kb * 2048, 16 * qt_w, li_p, g_p), accq, 0, 0, 0);
+        {
+          const int row = 32 * qb + 16 * qt_w + li_p;
+          const f32x4 qv = accq * p.scale;
+          *reinterpret_cast<u32x2*>(smem + BB_Q + row * 128 + (((hh * 4 + dt_w * 2 + (g_p >> 1)) ^ isw(row)) << 4) + (g_p & 1) * 8) =
+              (u32x2){pack_bf16x2(qv[0], qv[1]), pack_bf16x2(qv[2], qv[3])};
+        }
+        // (one dS image per head: everyone has read it before the next query block's tiles go in)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      // ---- (i) dq / dk / dv (bf16) over the q / k / v images: every wave is past its last read of them (the barrier above)
+      // ---- dk / dv (bf16) over the k / v images (Ls / Dl and dS are dead: the barrier above)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const int row = k0 + 16 * t + li;
-          const int so = (((hh * 4 + dt * 2 + (g >> 1)) ^ isw(row)) << 4) + (g & 1) * 8;
+          const int row = k0 + 16 * t + li_p;
+          const int so = (((hh * 4 + dt * 2 + (g_p >> 1)) ^ isw(row)) << 4) + (g_p & 1) * 8;
           const f32x4 kv = dk[t][dt] * p.scale;
           *reinterpret_cast<u32x2*>(smem + BB_K + row * 128 + so) = (u32x2){pack_bf16x2(kv[0], kv[1]), pack_bf16x2(kv[2], kv[3])};
           *reinterpret_cast<u32x2*>(smem + BB_V + row * 128 + so) = (u32x2){pack_bf16x2(dv[t][dt][0], dv[t][dt][1]), pack_bf16x2(dv[t][dt][2], dv[t][dt][3])};
         }
-#pragma unroll
-      for (int qb = 0; qb < 4; ++qb) {
-        const int row = 32 * qb + 16 * qt_w + li;
-        const f32x4 qv = dq[qb] * p.scale;
-        *reinterpret_cast<u32x2*>(smem + BB_Q + row * 128 + (((hh * 4 + dt_w * 2 + (g >> 1)) ^ isw(row)) << 4) + (g & 1) * 8) =
-            (u32x2){pack_bf16x2(qv[0], qv[1]), pack_bf16x2(qv[2], qv[3])};
-      }
     }
+    // ---- dy1 += dq_pair Wq^T + dk_pair Wk^T + dv_pair Wv^T slices: six K = 32 steps; dq | dk | dv leave for HBM on the way
+    BB_TR(7 + 12 * pr);
+    bb_static_for<0, 6>([&](auto j_) {
+      constexpr int j = decltype(j_)::value;
+      constexpr int seq = 8 + 6 * pr + j;
+      if constexpr (j == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if constexpr (j == 1 || j == 2) { if (last) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory"); }
+      else if constexpr (j == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if constexpr (j == 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else { if (last) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();
+      BB_TR(8 + 12 * pr + j);
+      if constexpr (j == 0 && !last) { qkv_fetch(pr + 1); a_fetch(pr + 1); }
+      if constexpr ((j & 1) == 0) stash(pr, j >> 1);
+      if constexpr (j >= 1 && j + 2 < 6) wloadP(pr, j + 2);
+      if constexpr (j + 2 >= 6 && !last) wloadP(pr + 1, j + 2 - 6);
+      kprod(j >> 1, j & 1, seq % 3, pr == 0 && j == 0);
+    });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // ---- (j) c1: dq -> HBM; dy1 += dq_pair Wq^T slice (chunk c1, buffer 1); then chunk c2 (loaded under the attention)
-    stash(pr, 0);
-    kprod(0, (cg0 + 1) & 1, pr == 0);
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      // chunk c2 landed (younger: the two dq stores)
-    __builtin_amdgcn_s_barrier();
-    // ---- (k) c2
-    wload(cg0 + 3);        // into c1's buffer (read by everyone before the barrier above)
-    stash(pr, 1);
-    kprod(1, (cg0 + 2) & 1, false);
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      // chunk c3 landed (younger: the two dk stores)
-    __builtin_amdgcn_s_barrier();
-    // ---- (l) c3; the next pair's first chunk goes into c2's buffer
-    if (pr < 3) wload(cg0 + 4);
-    stash(pr, 2);
-    kprod(2, (cg0 + 3) & 1, false);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- (m) the images are free: the next pair's q / k / v columns
-    if (pr < 3) iload(pr + 1);
+    BB_TR(14 + 12 * pr);
+    if constexpr (!last) {
+      qkv_place();
+      BB_TR(15 + 12 * pr);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   };
   bb_static_for<0, 4>(pair);
 
-  // ---- dy1 (bf16) -> [128][512 B] image over the four pair images (slot ^ (row & 15)) -> whole 512-byte rows
+  // ---- dy1 (bf16) -> [128][512 B] image over the da image (slot ^ (row & 15)) -> whole 512-byte rows
 #pragma unroll
   for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
@@ -387,6 +441,8 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
       *reinterpret_cast<u32x2*>(smem + row * 512 + (((tl * 2 + (g >> 1)) ^ (row & 15)) << 4) + (g & 1) * 8) = pk;
     }
   __syncthreads();
+  BB_TR(53);
+  if (BB_ABL == 9) { asm volatile("s_dcache_wb" ::: "memory"); return; }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = tid + 512 * i, r = idx >> 5, c16 = idx & 31;

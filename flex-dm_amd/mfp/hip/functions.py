@@ -33,6 +33,8 @@ MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
 ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
 # ... and the MLP half behind it on the same tile: the whole block forward in one launch; 0 = attention half + mlp_fused
 BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
+# the attention half's input gradients (da, attention backward, dy1) in one launch (csrc/block_attn_bwd.hip); "0" = three
+ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "1") == "1"
 FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
 
 
@@ -430,12 +432,19 @@ class BlockFn(torch.autograd.Function):
                                             ctx.step_ptr), jobs=ctx.ln_jobs)
         # ---- attention: x1 = x + drop(a Wo + bo)
         wt = st.cwt(p + "attn/combine_heads/kernel")
-        if _fused_ok(ctx, D) and wt is not None:
-            da = ops.dgrad_d256(d_o1, wt)      # activation-stationary (csrc/block_fused.hip)
+        wtq = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
+        dy1 = None
+        if (ATTN_BLOCK_BWD and _fused_ok(ctx, D) and wt is not None and wtq is not None and cdt == torch.bfloat16
+                and S == 128 and T == B * S):
+            # da = d_o1 Wo, attention backward and dy1 = dqkv Wqkv in one launch (csrc/block_attn_bwd.hip)
+            dqkv, dy1 = ops.attn_block_bwd(d_o1, wt, qkv, a, lse, ctx.nvalid, wtq, B, S, NUM_HEADS)
         else:
-            da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True,
-                          b_kmajor=wt is not None, out_dtype=cdt)
-        dqkv = ops.attention_bwd(qkv, ctx.nvalid, a, da, lse, B, S, NUM_HEADS)
+            if _fused_ok(ctx, D) and wt is not None:
+                da = ops.dgrad_d256(d_o1, wt)      # activation-stationary (csrc/block_fused.hip)
+            else:
+                da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D,
+                              a_kmajor=True, b_kmajor=wt is not None, out_dtype=cdt)
+            dqkv = ops.attention_bwd(qkv, ctx.nvalid, a, da, lse, B, S, NUM_HEADS)
 
         def wgrads_attn():
             ops.gemm(d_o1, a, D, D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "attn/combine_heads/kernel"),
@@ -456,12 +465,13 @@ class BlockFn(torch.autograd.Function):
             ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1)
         else:
             ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
-        wt = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
-        if _fused_ok(ctx, D) and wt is not None:
-            dy1 = ops.dgrad_qkv(dqkv, wt)       # activation-stationary (csrc/block_fused.hip)
+        if dy1 is not None:
+            pass
+        elif _fused_ok(ctx, D) and wtq is not None:
+            dy1 = ops.dgrad_qkv(dqkv, wtq)       # activation-stationary (csrc/block_fused.hip)
         else:
-            dy1 = ops.gemm(dqkv, wt if wt is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
-                           3 * D, a_kmajor=True, b_kmajor=wt is not None, out_dtype=cdt)
+            dy1 = ops.gemm(dqkv, wtq if wtq is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
+                           3 * D, a_kmajor=True, b_kmajor=wtq is not None, out_dtype=cdt)
         if i > 0:   # dx is the dx2 of block i-1: hand its masked/cast copy over (skips a dropout_bwd)
             pp = "blocks/seq2seq_%d/" % (i - 1)
             dx, nxt = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
