@@ -125,9 +125,11 @@ __device__ __forceinline__ float dot8(const u32x4& x, const u32x4& y) {
 // loads); the schedule below issues per wave, in this order (P = 9 prefetch loads of the next pair's q | k | v, a, lse; S = 2 stores):
 //   prologue: ... A0 A1 | step c of the da product: wait(2) barrier, issue chunk c + 2 (A.., then pair 0's j = 0, 1)
 //   after the K / V fragment reads of a pair: the pair's chunk j = 2
-//   pair, step j: wait(N_j) barrier; j = 0: P S(dq); j = 1: chunk 3; j = 2: S(dk) chunk 4; j = 3: chunk 5;
+//   pair, step j: wait(N_j) barrier; j = 0: S(dq); j = 1: chunk 3; j = 2: S(dk) chunk 4; j = 3: chunk 5, P;
 //                 j = 4: S(dv) next pair's chunk 0; j = 5: next pair's chunk 1
-//   N_0 = 4 (chunks 1, 2)  N_1 = N_2 = 2 + P + S = 13 (4 in the last pair: no P)  N_3 = 4  N_4 = 2  N_5 = 4 (2 in the last pair)
+//   N_0 .. N_3 = 4   N_4 = 2 + P = 11   N_5 = P + S + 2 = 13   (last pair: no P, no next chunks: N_4 = N_5 = 2)
+// P goes behind the pair's last weight chunk: loads return in order, a weight chunk (an L2 hit) issued behind the HBM loads
+// of P would not count as landed before they are.
 __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Ws = smem + BB_WS;
@@ -406,17 +408,15 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
     bb_static_for<0, 6>([&](auto j_) {
       constexpr int j = decltype(j_)::value;
       constexpr int seq = 8 + 6 * pr + j;
-      if constexpr (j == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else if constexpr (j == 1 || j == 2) { if (last) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory"); }
-      else if constexpr (j == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else if constexpr (j == 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-      else { if (last) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+      if constexpr (j <= 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if constexpr (j == 4) { if (last) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); }
+      else { if (last) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory"); }
       __builtin_amdgcn_s_barrier();
       BB_TR(8 + 12 * pr + j);
-      if constexpr (j == 0 && !last) { qkv_fetch(pr + 1); a_fetch(pr + 1); }
       if constexpr ((j & 1) == 0) stash(pr, j >> 1);
       if constexpr (j >= 1 && j + 2 < 6) wloadP(pr, j + 2);
       if constexpr (j + 2 >= 6 && !last) wloadP(pr + 1, j + 2 - 6);
+      if constexpr (j == 3 && !last) { qkv_fetch(pr + 1); a_fetch(pr + 1); }
       kprod(j >> 1, j & 1, seq % 3, pr == 0 && j == 0);
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
