@@ -59,6 +59,14 @@ constexpr int AB_F = 512;
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
+#ifndef AB_ABL
+#define AB_ABL 0
+#endif
+// AB_ABL == 9: timing build (tools/trace_block_fwd.py): every wave drops shader-clock stamps at its phase boundaries into the
+// x2_bf16 buffer (scalar stores: no vector-memory operation added); the bf16 copy itself is not written
+#define AB_TR(i) do { if (AB_ABL == 9) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    asm volatile("s_store_dwordx2 %0, %1, %2 glc" :: "s"(t_), "s"(trbase), "n"((i) * 8) : "memory"); } } while (0)
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void ab_static_for(F&& f) {
   if constexpr (I < N) {
@@ -94,6 +102,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
   const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[doc]);
 
+  const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(doc * 8 + wave) * 64;
+  AB_TR(0);
   const unsigned int xbytes = (unsigned int)p.T * (AB_D * 4);
   const __amdgpu_buffer_rsrc_t rs_wq = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wqkv), 0, 768 * AB_D * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wo), 0, AB_D * AB_D * 2, 0x00020000);
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       for (int e = 0; e < 4; ++e) { v[ks][e] = a[e]; v[ks][4 + e] = b[e]; s += a[e] + b[e]; }
     }
     __syncthreads();      // gamma / beta are in LDS
+    AB_TR(1);
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     const float mu = s * (1.0f / AB_D);
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rp * 32 + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();       // chunks 0, 1 are in LDS (first memory operations of the kernel); the LN image has been read
+  AB_TR(2);
 
   int xs[4];
 #pragma unroll
@@ -385,6 +397,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();      // the pair's a image is complete
     }
+    AB_TR(3 + c);
   };
   ab_static_for<0, AB_CHUNKS>(chunk);
 
@@ -438,9 +451,10 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, xbytes / 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, (unsigned int)p.T * (AB_F * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(p.x2, 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x2c = __builtin_amdgcn_make_buffer_rsrc(p.x2c ? p.x2c : p.y2, 0, p.x2c ? xbytes / 2 : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2c = __builtin_amdgcn_make_buffer_rsrc(p.x2c ? p.x2c : p.y2, 0, (p.x2c && AB_ABL != 9) ? xbytes / 2 : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_m2 = __builtin_amdgcn_make_buffer_rsrc(p.mean2, 0, (unsigned int)p.T * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc(p.rstd2, 0, (unsigned int)p.T * 4u, 0x00020000);
+    AB_TR(19);
     // ---- LN2 on the accumulator layout: a lane holds 32 columns of its two rows; the other 128 columns of a row sit
     // in the wave (rp, 1 - nh): partial sums through LDS, summed in the fixed order nh = 0, 1
     float mu[2], rs2[2];
@@ -470,6 +484,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       }
       __syncthreads();
     }
+    AB_TR(20);
     // y2 (bf16) -> the [128][512 B] image (slot ^ (row & 15)); rows >= 96 sit behind ring buffer 0 (which holds a
     // prefetched weight chunk): + 32 KB
 #pragma unroll
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // the y2 image has been read by everyone (the FFN1 epilogues write over it)
+    AB_TR(21);
 
     unsigned char* const Hs = smem;      // h quarter: 128 rows x 128 hidden units, 32 KB (the q | k images' place)
     bf16x8 hf[2][4];
@@ -625,8 +641,10 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
           for (int ks = 0; ks < 4; ++ks)
             hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (rp * 32 + rt * 16 + li_m) * 256 + xs_m[ks]);
       }
+      AB_TR(22 + cm);
     };
     ab_static_for<AB_CHUNKS, 2 * AB_CHUNKS>(mchunk);
+    if (AB_ABL == 9) asm volatile("s_dcache_wb" ::: "memory");
   }
 }
 
