@@ -408,28 +408,30 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   {
     const unsigned int dkey = drop_key(p.seed, p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE);
 #pragma unroll
-    for (int hf2 = 0; hf2 < 2; ++hf2) {      // two rounds of 4 column tiles: 8 residual loads in flight
-      f32x4 res[4][2];
+    for (int hf2 = 0; hf2 < 4; ++hf2) {      // four rounds of 2 column tiles: 4 residual loads in flight (16 registers:
+                                             // 8 in flight spilled an accumulator tile across LN2 in the MLP variant)
+      f32x4 res[2][2];
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
+      for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
+          const int row = row0 + rp * 32 + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
           res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
         }
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
+      for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          const int row = row0 + rp * 32 + rt * 16 + li, n = (hf2 * 8 + nh * 4 + q4) * 16 + 4 * g;
+          const int ct = (hf2 >> 1) * 4 + (hf2 & 1) * 2 + q4;
+          const int row = row0 + rp * 32 + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
           const f32x4 bb = *reinterpret_cast<const f32x4*>(Bo + n);
           bool keep[4] = {true, true, true, true};
           if (DROPOUT) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
           f32x4 ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = res[q4][rt][r] + (keep[r] ? (acc2[hf2 * 4 + q4][rt][r] + bb[r]) * inv_keep : 0.f);
+          for (int r = 0; r < 4; ++r) ov[r] = res[q4][rt][r] + (keep[r] ? (acc2[ct][rt][r] + bb[r]) * inv_keep : 0.f);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_x1, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0);
-          acc2[hf2 * 4 + q4][rt] = ov;
+          acc2[ct][rt] = ov;
         }
     }
   }
@@ -533,14 +535,18 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       constexpr int q = cm >> 2, ffn2 = (cm >> 1) & 1, j = cm & 1;
       if (c + 2 < NCH) wload(c + 2);
       f32x4 res[4][2];
+      // (the output stage's addresses are worked out here, from fresh opaque copies: hoisted to the head of the MLP stage
+      //  they were spilled across it, and each reload is a scratch access that drains the x2 stores issued before it)
+      int li_e = li_m, g_e = g_m;
       if (q == 3 && ffn2) {
+        asm volatile("" : "+v"(li_e), "+v"(g_e));
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
-            const int row = row0 + rp * 32 + rt * 16 + li_m;
+            const int row = row0 + rp * 32 + rt * 16 + li_e;
             res[nt][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rs_x1, (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_m) * 4 + (j * 8 + nt) * 64, 0, 0));
+                rs_x1, (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_e) * 4 + (j * 8 + nt) * 64, 0, 0));
           }
       }
       const unsigned char* wb = Ws + ((c + 1) % 3) * AB_WS_B;
@@ -597,11 +603,11 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         if (last) {
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
-            const int row = row0 + rp * 32 + rt * 16 + li_m;
+            const int row = row0 + rp * 32 + rt * 16 + li_e;
             const unsigned int rowh = drop_row(dkey2, (unsigned int)row);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-              const int n = (j * 8 + nh * 4 + nt) * 16 + 4 * g_m;
+              const int n = (j * 8 + nh * 4 + nt) * 16 + 4 * g_e;
               const f32x4 bb = *reinterpret_cast<const f32x4*>(B2s + n);
               bool keep[4] = {true, true, true, true};
               if (DROPOUT) drop_keep4(rowh, (unsigned int)n, dthr, keep);
@@ -609,9 +615,9 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
 #pragma unroll
               for (int r = 0; r < 4; ++r) o[r] = res[nt][rt][r] + (keep[r] ? (acc2[j * 4 + nt][rt][r] + bb[r]) * inv_keep : 0.f);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_x2,
-                                                     (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_m) * 4 + (j * 8 + nt) * 64, 0, 0);
+                                                     (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_e) * 4 + (j * 8 + nt) * 64, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_x2c,
-                                                    (unsigned int)row * (AB_D * 2) + (nh * 4 * 16 + 4 * g_m) * 2 + (j * 8 + nt) * 32, 0, 0);
+                                                    (unsigned int)row * (AB_D * 2) + (nh * 4 * 16 + 4 * g_e) * 2 + (j * 8 + nt) * 32, 0, 0);
             }
           }
         }
@@ -629,9 +635,11 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         }
       }
       if (!ffn2 && j == 1) {
+        int tid_h = tid_m;      // (opaque per quarter: the four store addresses are not kept across the quarters)
+        asm volatile("" : "+v"(tid_h));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int idx = tid_m + 512 * i, r = idx >> 4, c16 = idx & 15;
+          const int idx = tid_h + 512 * i, r = idx >> 4, c16 = idx & 15;
           __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(Hs + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_h,
                                                  (unsigned int)(row0 + r) * (AB_F * 2) + c16 * 16 + q * 256, 0, 0);
         }
