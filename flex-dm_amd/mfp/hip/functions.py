@@ -34,7 +34,19 @@ ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
 # ... and the MLP half behind it on the same tile: the whole block forward in one launch; 0 = attention half + mlp_fused
 BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
 # the attention half's input gradients (da, attention backward, dy1) in one launch (csrc/block_attn_bwd.hip); "0" = three
-ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "1") == "1"
+# unset: when the documents fill the chip (one workgroup = one document per CU); with fewer documents than CUs (c4: 128 per
+# GPU) the three launches, which split a document over more workgroups, are faster (1.187 vs 1.210 ms per step)
+ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "")
+_CU_COUNT = {}
+
+
+def _attn_block_bwd_on(ctx) -> bool:
+    if ATTN_BLOCK_BWD != "":
+        return ATTN_BLOCK_BWD == "1"
+    dev = ctx.store.w.device
+    if dev not in _CU_COUNT:
+        _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return ctx.B >= _CU_COUNT[dev]
 FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
 
 
@@ -434,7 +446,7 @@ class BlockFn(torch.autograd.Function):
         wt = st.cwt(p + "attn/combine_heads/kernel")
         wtq = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
         dy1 = None
-        if (ATTN_BLOCK_BWD and _fused_ok(ctx, D) and wt is not None and wtq is not None and cdt == torch.bfloat16
+        if (_attn_block_bwd_on(ctx) and _fused_ok(ctx, D) and wt is not None and wtq is not None and cdt == torch.bfloat16
                 and S == 128 and T == B * S):
             # da = d_o1 Wo, attention backward and dy1 = dqkv Wqkv in one launch (csrc/block_attn_bwd.hip)
             dqkv, dy1 = ops.attn_block_bwd(d_o1, wt, qkv, a, lse, ctx.nvalid, wtq, B, S, NUM_HEADS)

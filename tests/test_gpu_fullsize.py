@@ -112,6 +112,26 @@ def test_c4_per_gpu_shape_equals_its_halves_and_the_c2_batch():
     assert err <= 2e-2 * scale, (err, scale)
 
 
+def test_attention_backward_in_one_launch_equals_the_three_launches():
+    """c2 batch (256 documents: the chip is full, so the one-launch attention backward of csrc/block_attn_bwd.hip is what
+    the step runs) against the three launches it replaces (mfp_dgrad_d256, mfp_attention_bwd, mfp_dgrad_qkv): same bf16
+    operands, only the summation order of dQ over the keys differs -> gradients agree to bf16 rounding of dqkv."""
+    from mfp.hip import functions as F
+    ic, model = _model("bf16")
+    batch, modified, masks, _ = _masked_batch(ic, seed=7)
+    keep = F.ATTN_BLOCK_BWD
+    try:
+        F.ATTN_BLOCK_BWD = "1"
+        sums1, logits1, g1 = _loss_grads(model, ic, batch, modified, masks)
+        F.ATTN_BLOCK_BWD = "0"
+        sums0, logits0, g0 = _loss_grads(model, ic, batch, modified, masks)
+    finally:
+        F.ATTN_BLOCK_BWD = keep
+    assert torch.equal(logits1, logits0) and torch.allclose(sums1, sums0, rtol=1e-5, atol=1e-6)    # (sums: f32 atomics)
+    err, scale = (g1 - g0).abs().max().item(), g0.abs().max().item()
+    assert err <= 2e-3 * scale, (err, scale)
+
+
 def test_c4_per_gpu_shape_captured_step_equals_eager_step():
     """c4's per-GPU shard through the product's own train step: the hipGraph replay (what bench.py --config c4 times)
     leaves exactly the parameters the eager step leaves -- same kernels, same counter-based masks and dropout."""
