@@ -1,0 +1,531 @@
+// Decoder heads + LossLayer + the heads' input gradient in ONE launch (reference models/architecture/decoder.py:95-111,
+// models/metrics.py:213-299, and their autodiff), d_model 256, bf16 operands:
+//
+//     logits = x W^T + b                      x bf16 [T,256], W bf16 [U][256] (all heads side by side, 8-aligned columns)
+//     per head: masked clipped-softmax CE (categorical) / sum of squares + cosine score (numerical), their per-key
+//               sums, and dlogits = d(sum of losses / B) / d(logits)             (csrc/loss.hip states the formulas)
+//     dx = dlogits W                          f32 [T,256] (+ the dropout-masked bf16 copy the last block starts from)
+//
+// It replaces gemm_ws_kernel (heads forward) + ce_tile_kernel + mse_kernel + dgrad_rows_kernel: the f32 logits (5.5 KB
+// per element: 181 MB at c2) are never written unless the caller wants them, dlogits (bf16, the weight-gradient launch
+// needs it) is written once and not read back here, and W streams through LDS ONCE for both products.
+//
+// One 8-wave workgroup per 128 rows; x fragments stay in registers (64), dx accumulates in 64 registers.  The columns are
+// walked in CHUNKS of <= 64 (host-built table): a categorical chunk holds whole items (softmax groups), a numerical head
+// is cut into 64-column chunks.  Per chunk c (32 KB of W = rows col0 .. col0 + 63 as a [64][512 B] LDS image, 3-buffer
+// LDS-DMA ring, counted waits):
+//   1. logits tile = W_c x^T (transposed product: a lane holds 4 consecutive columns of its row) + bias
+//   2. categorical: tile -> LDS (f32), one 16-lane group per ACTIVE (row, item) runs softmax / clipped CE / gradient in
+//      place (ce_tile_kernel's walk), 16-byte pieces of inactive items / padding are written as zeros -> bf16 dl image;
+//      numerical: in the accumulator layout -- targets (loaded one chunk ahead, only rows that carry a loss) ->
+//      2 (p - y) / B -> dl image; sum of squares / |y|^2 / |p|^2 / y.p per row carried in registers across the head's chunks
+//   3. dl image -> HBM (dlogits) and, as the B operand, dx += dl_c W_c with W_c read TRANSPOSED from the same LDS image
+//      (ds_read_b64_tr_b16; row swizzle ((row & 7) << 1 | (row >> 3) & 1 keeps both read patterns conflict-free).
+// Per-key sums leave as per-workgroup partials (no global atomics): the caller reduces them (mfp_reduce_partials).
+// Every iteration issues the same vector-memory operations (out-of-range offsets / zero-sized buffers where a chunk has
+// nothing to load or store), so "chunk c has landed" is s_waitcnt vmcnt(24) in every iteration.
+#include "common.h"
+
+namespace {
+
+constexpr int HL_ROWS = 128, HL_D = 256, HL_MAXCH = 40, HL_MAXIT = 16, HL_MAXU = 1536;
+constexpr int HL_WS_B = 32768;
+constexpr int HL_TILE = 3 * HL_WS_B, HL_TW = 68;             // f32 [128][68] staging of a categorical chunk
+constexpr int HL_DLI = HL_TILE + HL_ROWS * HL_TW * 4;        // bf16 dl image [128][128 B]
+constexpr int HL_WROW = HL_DLI + 16384;                      // u8 [16 keys][128 rows]: the row carries a loss for the key
+constexpr int HL_YLAB = HL_WROW + 2048;                      // u8 [128 rows][16 items]: label
+constexpr int HL_BIAS = HL_YLAB + 2048;                      // f32 [HL_MAXU]
+constexpr int HL_RED = HL_BIAS + HL_MAXU * 4;                // f32 [16][3] (+ pad)
+constexpr int HL_ACT = HL_RED + 256;                         // u16 [1024] compacted active (row, item-in-chunk)
+constexpr int HL_NACT = HL_ACT + 2048;
+constexpr int HL_ITAB = HL_NACT + 16;                        // int [3][16]: item -> key, first column, classes
+constexpr int HL_LDS = HL_ITAB + 192;                        // 162 256 B
+
+struct HlParams {
+  const unsigned short* X;
+  const unsigned short* W;
+  const float* bias;
+  const int* nvalid;
+  float* part;               // [workgroups][48]
+  unsigned short* dlogits;   // [T][ld] bf16
+  float* logits;             // [T][ld] f32 or nullptr
+  float* dX;                 // [T][256] f32
+  unsigned short* dXd;       // [T][256] bf16 dropout-masked copy or nullptr
+  const int* step_ptr;
+  unsigned long long seed, offset;
+  mfp_loss_key key[MFP_MAX_LOSS_KEYS];
+  int nkeys, nitem, nch, T, S, U, ld;
+  float inv_B, dropout_p;
+  int item_key[HL_MAXIT], item_feat[HL_MAXIT], item_col[HL_MAXIT], item_C[HL_MAXIT];
+  // chunk table, 32-bit words only (a byte / short array indexed by the loop counter becomes a VECTOR-memory load inside
+  // the counted-wait schedule): [0] col0 | ncols << 16, [1] kind | key << 8 | first << 16 | last << 24 (kind 0 categorical,
+  // 1 numerical), [2] item0 | nitem << 8, [3] / [4] 8-column piece -> item (one byte each, 0xFF: padding / another chunk's)
+  int ch[HL_MAXCH][8];
+};
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+__device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int dsw(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+
+__global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const Ws = smem;
+  float* const Tile = reinterpret_cast<float*>(smem + HL_TILE);
+  unsigned char* const Dli = smem + HL_DLI;
+  unsigned char* const Wrow = smem + HL_WROW;
+  unsigned char* const Ylab = smem + HL_YLAB;
+  float* const Bias = reinterpret_cast<float*>(smem + HL_BIAS);
+  float* const Red = reinterpret_cast<float*>(smem + HL_RED);
+  unsigned short* const Act = reinterpret_cast<unsigned short*>(smem + HL_ACT);
+  int* const Nact = reinterpret_cast<int*>(smem + HL_NACT);
+  int* const Itab = reinterpret_cast<int*>(smem + HL_ITAB);      // (per-lane item lookups go to LDS, never to the kernel arguments)
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rp = wave & 3, nh = wave >> 2;
+  const int row0 = blockIdx.x * HL_ROWS;
+  const int nch = p.nch;
+  constexpr unsigned int OOB = 0xFFFFFFF0u;
+  const int step_now = (p.dXd && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
+
+  const unsigned int xbytes = (unsigned int)p.T * (HL_D * 2);
+  const unsigned int ldb2 = (unsigned int)p.ld * 2u, ldb4 = (unsigned int)p.ld * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.X), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W), 0, (unsigned int)p.U * (HL_D * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dl = __builtin_amdgcn_make_buffer_rsrc(p.dlogits, 0, (unsigned int)p.T * ldb2, 0x00020000);
+  // (no logits / no masked copy wanted: zero-sized buffers; the stores are issued all the same -- the counted waits stay fixed)
+  const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(p.logits ? (void*)p.logits : (void*)p.dX, 0, p.logits ? (unsigned int)p.T * ldb4 : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.dX, 0, (unsigned int)p.T * (HL_D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(p.dXd ? (void*)p.dXd : (void*)p.dX, 0, p.dXd ? xbytes : 0u, 0x00020000);
+
+  // ---- weight chunk c -> ring buffer c % 3: W rows col0 .. col0 + 63 ([64][512 B], slot ^ dsw(row)); rows past U read zero
+  auto wload = [&](int c) {
+    const int col0 = c < nch ? (p.ch[c][0] & 0xffff) : p.U;
+    unsigned char* dst = Ws + (c % 3) * HL_WS_B + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 8 + i * 2 + (lane >> 5);
+      const unsigned int vo = (unsigned int)(row * 512 + (((lane & 31) ^ dsw(row)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_u8*)(dst + i * 1024), 16, vo, col0 * 512, 0, 0);
+    }
+  };
+  // ---- targets of a numerical chunk for this lane's (row tile, column tile) pairs: only rows that carry a loss
+  auto tload = [&](int c, f32x4 (&tg)[2][2]) {
+    const int w1 = c < nch ? p.ch[c][1] : 0;
+    const bool num = (w1 & 0xff) == 1;
+    const int k = num ? ((w1 >> 8) & 0xff) : 0;
+    const mfp_loss_key& key = p.key[k];
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(key.target), 0, num ? (unsigned int)p.T * (unsigned int)key.n_class * 4u : 0u, 0x00020000);
+    const int cb = num ? (p.ch[c < nch ? c : 0][0] & 0xffff) - key.col_off : 0;
+    // (branch-free: offsets first, then the four loads back to back)
+    unsigned int off[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int row = rp * 32 + rt * 16 + li;
+      const int wv = Wrow[k * 128 + row];
+      const bool on = num & (wv != 0);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        off[nt][rt] = on ? ((unsigned int)(row0 + row) * (unsigned int)key.n_class + cb + (nh * 2 + nt) * 16 + 4 * g) * 4u : OOB;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        tg[nt][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, off[nt][rt], 0, 0));
+  };
+
+  // ---- prologue: x fragments, chunks 0 and 1; per (key, row) weights, per (row, item) labels, bias -> LDS
+  bf16x8 xf[2][8];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      xf[rt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+          rs_x, (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (HL_D * 2) + g * 16 + ks * 64, 0, 0));
+  wload(0);
+  wload(1);
+  {
+    const int row = tid & 127, t = row0 + row;
+    for (int k = tid >> 7; k < p.nkeys; k += 4) {
+      const mfp_loss_key& key = p.key[k];
+      bool w = false;
+      if (t < p.T) {
+        const int b = t / p.S, s = t - b * p.S;
+        const unsigned char m = key.mask[t];
+        const int nv = p.nvalid[b];
+        const int v = key.cond_idx != nullptr ? key.cond_idx[(long long)t * key.cond_stride] : 0;
+        const bool cnd = key.cond_idx == nullptr || (v >= 0 && v < 32 && ((key.cond_bits >> v) & 1u));
+        w = m != 0 && s < nv && cnd;
+      }
+      Wrow[k * 128 + row] = w ? 1 : 0;
+    }
+    for (int it = tid >> 7; it < p.nitem; it += 4) {
+      const mfp_loss_key& key = p.key[p.item_key[it]];
+      int y = 0;
+      if (t < p.T) y = reinterpret_cast<const int*>(key.target)[(long long)t * key.n_feat + p.item_feat[it]];
+      Ylab[row * 16 + it] = (unsigned char)(y < 0 ? 255 : (y > 254 ? 255 : y));
+    }
+    for (int i = tid; i < HL_MAXU; i += 512) Bias[i] = i < p.U ? p.bias[i] : 0.f;
+    if (tid < 48) Red[tid] = 0.f;
+    if (tid == 0) *Nact = 0;
+    if (tid < 16) { Itab[tid] = p.item_key[tid]; Itab[16 + tid] = p.item_col[tid]; Itab[32 + tid] = p.item_C[tid]; }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int xs[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ dsw(li)) << 4;
+  f32x4 acc2[8][2];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) acc2[a][0] = acc2[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ms[2][4];      // numerical head in flight: per row tile {sum d^2, sum y^2, sum p^2, sum y p} over this lane's columns
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) ms[rt][0] = ms[rt][1] = ms[rt][2] = ms[rt][3] = 0.f;
+  f32x4 tg[2][2];
+  tload(0, tg);
+
+  for (int c = 0; c < nch; ++c) {
+    // chunk c has landed: younger than its four loads are the 10 other operations of iteration c - 2 and the 14 of c - 1
+    asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                                    // B1
+    // (opaque copies per iteration: loop-invariant address arithmetic is not hoisted out of the loop and kept in registers)
+    int li_c = li, g_c = g, tid_c = tid;
+    asm volatile("" : "+v"(li_c), "+v"(g_c), "+v"(tid_c));
+    const int cw0 = p.ch[c][0], cw1 = p.ch[c][1], cw2 = p.ch[c][2];
+    const int col0 = cw0 & 0xffff, ncols = cw0 >> 16, kind = cw1 & 0xff, ckey = (cw1 >> 8) & 0xff;
+    const bool cfirst = (cw1 >> 16) & 1, clast = (cw1 >> 24) & 1;
+    wload(c + 2);                                                                    // 4 loads
+    const unsigned char* wb = Ws + (c % 3) * HL_WS_B;
+    // ---- 1. logits tile: acc[nt][rt] = rows 32 rp + 16 rt + li_c, columns col0 + (2 nh + nt) 16 + 4 g_c .. + 3
+    f32x4 acc[2][2];
+    {
+      const unsigned char* wa = wb + ((nh * 2) * 16 + li_c) * 512;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[ks & 3] + (ks >> 2) * 256);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[rt][ks], acc[nt][rt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int cc = (nh * 2 + nt) * 16 + 4 * g_c;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(Bias + col0 + cc);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          acc[nt][rt] += bb;
+          const int row = rp * 32 + rt * 16 + li_c;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt][rt]), rs_lg,
+                                                 cc < ncols ? (unsigned int)(row0 + row) * ldb4 + (unsigned int)(col0 + cc) * 4u : OOB, 0, 0);   // 4 stores
+        }
+      }
+    }
+    if (kind == 0) {
+      // ---- 2a. categorical chunk: logits -> LDS, active (row, item) pairs compacted
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          *reinterpret_cast<f32x4*>(Tile + (rp * 32 + rt * 16 + li_c) * HL_TW + (nh * 2 + nt) * 16 + 4 * g_c) = acc[nt][rt];
+      const int item0 = cw2 & 0xff, ni = (cw2 >> 8) & 0xff;
+      for (int idx = tid_c; idx < 128 * ni; idx += 512) {
+        const int row = idx & 127, j = idx >> 7;
+        if (Wrow[Itab[item0 + j] * 128 + row]) Act[atomicAdd(Nact, 1)] = (unsigned short)(row | (j << 7));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                                  // B2
+      const int na = *Nact;
+      const int l16 = tid_c & 15;
+      for (int a = tid_c >> 4; a < na; a += 32) {
+        const int code = Act[a], row = code & 127, item = item0 + (code >> 7);
+        const int kidx = Itab[item], C = Itab[32 + item];
+        float* z = Tile + row * HL_TW + (Itab[16 + item] - col0);
+        const int y = Ylab[row * 16 + item];
+        float m = -INFINITY;
+        int am = 0x7fffffff;
+        for (int j = l16; j < C; j += 16) { const float v = z[j]; if (v > m) { m = v; am = j; } }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          const float om = __shfl_xor(m, o, 64);
+          const int oa = __shfl_xor(am, o, 64);
+          if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        }
+        float se = 0.f;
+        for (int j = l16; j < C; j += 16) { const float e = expf(z[j] - m); z[j] = e; se += e; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+        const float inv = 1.f / se;
+        float sq = 0.f, qy = 0.f;
+        for (int j = l16; j < C; j += 16) {
+          const float pj = z[j] * inv;
+          const float q = fminf(fmaxf(pj, 1e-7f), 1.f - 1e-7f);
+          sq += q;
+          if (j == y) qy = q;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); qy += __shfl_xor(qy, o, 64); }
+        const float loss = -logf(qy) + logf(sq);
+        const float inv_sq = 1.f / sq, inv_qy = 1.f / qy;
+        float gp = 0.f;
+        for (int j = l16; j < C; j += 16) {
+          const float pj = z[j] * inv;
+          const float gg = (pj >= 1e-7f && pj <= 1.f - 1e-7f) ? ((j == y ? -inv_qy : 0.f) + inv_sq) : 0.f;
+          gp += gg * pj;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) gp += __shfl_xor(gp, o, 64);
+        for (int j = l16; j < C; j += 16) {
+          const float pj = z[j] * inv;
+          const float gg = (pj >= 1e-7f && pj <= 1.f - 1e-7f) ? ((j == y ? -inv_qy : 0.f) + inv_sq) : 0.f;
+          z[j] = pj * (gg - gp) * p.inv_B;
+        }
+        if (l16 == 0) {
+          atomicAdd(&Red[kidx * 3 + 0], loss * p.inv_B);
+          atomicAdd(&Red[kidx * 3 + 1], am == y ? 1.f : 0.f);
+          atomicAdd(&Red[kidx * 3 + 2], 1.f);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                                  // B3
+      if (tid_c == 0) *Nact = 0;
+      const unsigned long long pmap = (unsigned long long)(unsigned int)p.ch[c][3] | ((unsigned long long)(unsigned int)p.ch[c][4] << 32);
+      // tile -> dl image: a thread converts two 8-column pieces; pieces of inactive items / padding / other chunks' columns are 0
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid_c + 512 * i, row = idx >> 3, c8 = idx & 7;
+        const int item = (int)((pmap >> (8 * c8)) & 0xFFull);
+        u32x4 pk = {0u, 0u, 0u, 0u};
+        if (item != 0xFF && Wrow[Itab[item] * 128 + row]) {
+          const float* src = Tile + row * HL_TW + c8 * 8;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+          const int lim = Itab[16 + item] + Itab[32 + item] - (col0 + c8 * 8);       // classes of the item left in this piece
+          float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (e >= lim) v[e] = 0.f;
+          pk = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        }
+        *reinterpret_cast<u32x4*>(Dli + row * 128 + ((c8 ^ isw(row)) << 4)) = pk;
+      }
+    } else {
+      // ---- 2b. numerical chunk, in the accumulator layout
+      const int k = ckey;
+      if (cfirst) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) ms[rt][0] = ms[rt][1] = ms[rt][2] = ms[rt][3] = 0.f;
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = rp * 32 + rt * 16 + li_c;
+        const bool on = Wrow[k * 128 + row] != 0;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          u32x2 pk = {0u, 0u};
+          if (on) {
+            float d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = acc[nt][rt][r], yv = tg[nt][rt][r];
+              d[r] = pv - yv;
+              ms[rt][0] += d[r] * d[r]; ms[rt][1] += yv * yv; ms[rt][2] += pv * pv; ms[rt][3] += yv * pv;
+              d[r] *= 2.f * p.inv_B;
+            }
+            pk = (u32x2){pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3])};
+          }
+          *reinterpret_cast<u32x2*>(Dli + row * 128 + ((((nh * 2 + nt) * 2 + (g_c >> 1)) ^ isw(row)) << 4) + (g_c & 1) * 8) = pk;
+        }
+      }
+      if (clast) {
+        // row sums: over the 4 lanes of a row in this wave, then the two column halves (waves nh = 0, 1) through LDS
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ms[rt][q] += __shfl_xor(ms[rt][q], 16, 64);
+            ms[rt][q] += __shfl_xor(ms[rt][q], 32, 64);
+          }
+        if (nh == 1 && g_c == 0) {
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            *reinterpret_cast<f32x4*>(Tile + (rp * 32 + rt * 16 + li_c) * 4) = (f32x4){ms[rt][0], ms[rt][1], ms[rt][2], ms[rt][3]};
+        }
+      }
+    }
+    tload(c + 1, tg);                                                                // 4 loads: the next chunk's targets
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                                    // B4: the dl image is complete
+    if (kind == 1 && clast && nh == 0) {
+      const int k = ckey;
+      float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+      if (g_c == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const int row = rp * 32 + rt * 16 + li_c;
+          if (Wrow[k * 128 + row]) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(Tile + row * 4);
+            const float sd = ms[rt][0] + o[0], sy = ms[rt][1] + o[1], sp = ms[rt][2] + o[2], syp = ms[rt][3] + o[3];
+            const float cosv = syp * rsqrtf(fmaxf(sy, 1e-12f)) * rsqrtf(fmaxf(sp, 1e-12f));
+            l0 += sd * p.inv_B; l1 += 0.5f * cosv + 0.5f; l2 += 1.f;
+          }
+        }
+      }
+      l0 = wave_sum(l0); l1 = wave_sum(l1); l2 = wave_sum(l2);
+      if (lane == 0 && l2 != 0.f) { atomicAdd(&Red[k * 3 + 0], l0); atomicAdd(&Red[k * 3 + 1], l1); atomicAdd(&Red[k * 3 + 2], l2); }
+    }
+    // ---- 3. dl image -> dlogits (16-byte pieces of the chunk's own columns), dx += dl_c W_c
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid_c + 512 * i, row = idx >> 3, c8 = idx & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Dli + row * 128 + ((c8 ^ isw(row)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs_dl, c8 * 8 < ncols ? (unsigned int)(row0 + row) * ldb2 + (unsigned int)(col0 + c8 * 8) * 2u : OOB, 0, 0);   // 2 stores
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 hf[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = rp * 32 + rt * 16 + li_c;
+        // (k order of a transposing read: lane group g holds u = 32 ks + 4 g + j and 32 ks + 16 + 4 g + j, j = 0..3 --
+        //  the dl operand is picked up in the same order: two 8-byte pieces)
+        const int p0 = 8 * ks + g_c, p1 = p0 + 4;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Dli + row * 128 + (((p0 >> 1) ^ isw(row)) << 4) + (p0 & 1) * 8);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Dli + row * 128 + (((p1 >> 1) ^ isw(row)) << 4) + (p1 & 1) * 8);
+        hf[rt] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        // W_c^T fragment: for column n = tile * 16 + li_c the chunk rows {32 ks + 4 g_c + j} and {32 ks + 16 + 4 g_c + j}, j = 0..3
+        const int tile = (ct >> 2) * 8 + nh * 4 + (ct & 3);
+        const int wrow = 32 * ks + 4 * g_c + (li_c >> 2);
+        const int P = tile * 4 + (li_c & 3);                        // 8-byte piece of the 512-byte row
+        const unsigned char* ptr = wb + wrow * 512 + ((((P >> 1) ^ dsw(wrow)) << 4) | ((P & 1) << 3));
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 512));     // (row + 16: same swizzle)
+        const bf16x8 wt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt, hf[rt], acc2[ct][rt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- dx (f32) and its dropout-masked, 1/keep-scaled bf16 copy (dgrad_rows_kernel's epilogue); the per-key partial sums
+  {
+    const float inv_keep = 1.0f / (1.0f - p.dropout_p);
+    const unsigned int dthr = drop_thr16(p.dropout_p);
+    const unsigned int dkey = drop_key(p.seed, p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row = row0 + rp * 32 + rt * 16 + li, n = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + 4 * g;
+        const f32x4 v = acc2[ct][rt];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_c, (unsigned int)row * (HL_D * 4) + n * 4, 0, 0);
+        bool keep[4] = {true, true, true, true};
+        if (p.dropout_p > 0.f) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
+        const u32x2 pk = {pack_bf16x2(keep[0] ? v[0] * inv_keep : 0.f, keep[1] ? v[1] * inv_keep : 0.f),
+                          pack_bf16x2(keep[2] ? v[2] * inv_keep : 0.f, keep[3] ? v[3] * inv_keep : 0.f)};
+        __builtin_amdgcn_raw_buffer_store_b64(pk, rs_d, (unsigned int)row * (HL_D * 2) + n * 2, 0, 0);
+      }
+  }
+  __syncthreads();
+  if (tid < 48) p.part[(long long)blockIdx.x * 48 + tid] = tid < p.nkeys * 3 ? Red[tid] : 0.f;
+}
+
+}  // namespace
+
+extern "C" size_t mfp_heads_loss_partials(int32_t T) { return (size_t)((T + HL_ROWS - 1) / HL_ROWS); }
+
+extern "C" int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys,
+                                      int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits,
+                                      float* dx, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p,
+                                      uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(x && W && bias && keys && nvalid && part && dlogits && dx);
+  MFP_CHECK_ARG(B > 0 && S > 0 && D == HL_D && U > 0 && U % 8 == 0 && U <= HL_MAXU && nkeys > 0 && nkeys <= MFP_MAX_LOSS_KEYS);
+  MFP_CHECK_ARG((long long)B * S <= (1 << 20) && dropout_p >= 0.f && dropout_p < 1.f);
+  MFP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)dlogits % 16) == 0 && ((uintptr_t)logits % 16) == 0 &&
+                ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dx_drop % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+  HlParams p;
+  p.X = reinterpret_cast<const unsigned short*>(x); p.W = reinterpret_cast<const unsigned short*>(W); p.bias = bias;
+  p.nvalid = nvalid; p.part = part; p.dlogits = reinterpret_cast<unsigned short*>(dlogits); p.logits = logits;
+  p.dX = dx; p.dXd = reinterpret_cast<unsigned short*>(dx_drop); p.step_ptr = step_ptr; p.seed = seed; p.offset = offset;
+  p.nkeys = nkeys; p.T = B * S; p.S = S; p.U = U; p.ld = U; p.inv_B = 1.0f / (float)B; p.dropout_p = dropout_p;
+  // heads in column order; categorical items (key, feature) and the chunk table
+  int order[MFP_MAX_LOSS_KEYS];
+  for (int i = 0; i < nkeys; ++i) { p.key[i] = keys[i]; order[i] = i; }
+  for (int i = nkeys; i < MFP_MAX_LOSS_KEYS; ++i) p.key[i] = keys[0];
+  for (int i = 1; i < nkeys; ++i)
+    for (int j = i; j > 0 && keys[order[j]].col_off < keys[order[j - 1]].col_off; --j) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  p.nitem = 0; p.nch = 0;
+  int prev_end = 0;
+  short ncols[HL_MAXCH]; unsigned char nitem_c[HL_MAXCH]; unsigned char pm[HL_MAXCH][8];
+  auto new_chunk = [&](int col0, int kind, int key) -> int {
+    if (p.nch >= HL_MAXCH) return -1;
+    const int c = p.nch++;
+    p.ch[c][0] = col0; p.ch[c][1] = kind | (key << 8); p.ch[c][2] = p.nitem;
+    ncols[c] = 0; nitem_c[c] = 0;
+    for (int e = 0; e < 8; ++e) pm[c][e] = 0xFF;
+    return c;
+  };
+  int cur = -1;      // open categorical chunk
+  for (int oi = 0; oi < nkeys; ++oi) {
+    const int ki = order[oi];
+    const mfp_loss_key& k = keys[ki];
+    MFP_CHECK_ARG(k.col_off >= prev_end && k.col_off % 8 == 0 && k.n_class > 0 && k.n_feat > 0);   // heads must not overlap
+    prev_end = k.col_off + k.n_feat * k.n_class;
+    MFP_CHECK_ARG(prev_end <= U);
+    if (k.is_numerical) {
+      MFP_CHECK_ARG(k.n_feat == 1 && k.n_class % 8 == 0);
+      cur = -1;
+      for (int c0 = 0; c0 < k.n_class; c0 += 64) {
+        const int c = new_chunk(k.col_off + c0, 1, ki);
+        MFP_CHECK_ARG(c >= 0);
+        ncols[c] = (short)(k.n_class - c0 < 64 ? k.n_class - c0 : 64);
+        if (c0 == 0) p.ch[c][1] |= 1 << 16;
+        if (c0 + 64 >= k.n_class) p.ch[c][1] |= 1 << 24;
+      }
+      continue;
+    }
+    for (int f = 0; f < k.n_feat; ++f) {
+      const int col = k.col_off + f * k.n_class;
+      MFP_CHECK_ARG(col % 8 == 0 && k.n_class <= 64 && p.nitem < HL_MAXIT);     // items sit on 8-column boundaries (ModelLayout pads)
+      const int end8 = (col + k.n_class + 7) / 8 * 8;
+      if (cur < 0 || end8 - p.ch[cur][0] > 64) {
+        cur = new_chunk(col, 0, 0);
+        MFP_CHECK_ARG(cur >= 0);
+      }
+      const int it = p.nitem++;
+      p.item_key[it] = ki; p.item_feat[it] = f; p.item_col[it] = col; p.item_C[it] = k.n_class;
+      nitem_c[cur]++;
+      ncols[cur] = (short)((end8 < U ? end8 : U) - p.ch[cur][0]);
+      for (int c8 = (col - p.ch[cur][0]) / 8; c8 < (end8 - p.ch[cur][0]) / 8 && c8 < 8; ++c8) pm[cur][c8] = (unsigned char)it;
+    }
+  }
+  for (int it = p.nitem; it < HL_MAXIT; ++it) { p.item_key[it] = 0; p.item_feat[it] = 0; p.item_col[it] = 0; p.item_C[it] = 0; }
+  for (int c = 0; c < HL_MAXCH; ++c) {
+    if (c >= p.nch) { p.ch[c][0] = U; p.ch[c][1] = 0; p.ch[c][2] = 0; ncols[c] = 0; nitem_c[c] = 0; for (int e = 0; e < 8; ++e) pm[c][e] = 0xFF; }
+    p.ch[c][0] |= (int)ncols[c] << 16;
+    p.ch[c][2] |= (int)nitem_c[c] << 8;
+    p.ch[c][3] = (int)((unsigned)pm[c][0] | ((unsigned)pm[c][1] << 8) | ((unsigned)pm[c][2] << 16) | ((unsigned)pm[c][3] << 24));
+    p.ch[c][4] = (int)((unsigned)pm[c][4] | ((unsigned)pm[c][5] << 8) | ((unsigned)pm[c][6] << 16) | ((unsigned)pm[c][7] << 24));
+    p.ch[c][5] = p.ch[c][6] = p.ch[c][7] = 0;
+  }
+  MFP_CHECK_ARG(p.nch > 0);
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_heads_loss_fwd_bwd: cannot raise dynamic LDS to %d: %s", HL_LDS, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(heads_loss_kernel, dim3((p.T + HL_ROWS - 1) / HL_ROWS), dim3(512), HL_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}

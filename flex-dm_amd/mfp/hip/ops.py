@@ -610,6 +610,75 @@ def loss_fwd_bwd(logits: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tenso
     return sums, dlogits
 
 
+def _loss_key_array(keys: Sequence[dict]):
+    arr = (LossKey * len(keys))()
+    for i, k in enumerate(keys):
+        arr[i].col_off, arr[i].n_feat, arr[i].n_class = k["col_off"], k["n_feat"], k["n_class"]
+        arr[i].is_numerical = int(k["is_numerical"])
+        arr[i].target, arr[i].mask = _ptr(k["target"]), _ptr(k["mask"])
+        arr[i].cond_idx = _ptr(k.get("cond_idx"))
+        arr[i].cond_stride = k.get("cond_stride", 1)
+        arr[i].cond_bits = k.get("cond_bits", 0xFFFFFFFF)
+    return arr
+
+
+def heads_loss_fused_ok(keys: Sequence[dict], U: int, D: int) -> bool:
+    """Shapes mfp_heads_loss_fwd_bwd takes: d_model 256, 8-aligned heads, categorical items of <= 64 classes on 8-column
+    boundaries, numerical widths % 8 == 0, at most 16 (key, feature) items and 40 column chunks."""
+    if D != 256 or U % 8 != 0 or U > 1536 or len(keys) > 16:
+        return False
+    items = chunks = 0
+    for k in keys:
+        if k["col_off"] % 8 != 0:
+            return False
+        if k["is_numerical"]:
+            if k["n_feat"] != 1 or k["n_class"] % 8 != 0:
+                return False
+            chunks += (k["n_class"] + 63) // 64
+        else:
+            if k["n_class"] > 64 or (k["n_feat"] > 1 and k["n_class"] % 8 != 0):
+                return False
+            items += k["n_feat"]
+            chunks += k["n_feat"]
+    return items <= 16 and chunks <= 40
+
+
+def heads_loss_fused(x_c: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tensor,
+                     B: int, S: int, dlogits: Optional[torch.Tensor] = None, want_logits: bool = True,
+                     drop: Optional[tuple] = None):
+    """Heads forward + LossLayer + heads input gradient in ONE launch (see mfp_heads_loss_fwd_bwd).  x_c bf16 [B*S,256],
+    W bf16 [U,256], bias f32 [U].  Returns (part [P,48] per-workgroup partial sums, dlogits bf16 [T,U], logits f32 [T,U] or
+    None, dx f32 [T,256], dx_drop bf16 [T,256] or None); ``drop`` = (p, seed, offset, step_ptr) as in :func:`dgrad_rows`.
+    Reduce the partials with :func:`reduce_partials` (N = 3 * len(keys), pstride 48)."""
+    lib = load()
+    T, D = x_c.shape
+    U = W.shape[0]
+    dev = x_c.device
+    arr = _loss_key_array(keys)
+    P = lib.mfp_heads_loss_partials(T)
+    part = torch.empty((P, 48), dtype=torch.float32, device=dev)
+    if dlogits is None:
+        dlogits = torch.empty((T, U), dtype=torch.bfloat16, device=dev)
+    logits = torch.empty((T, U), dtype=torch.float32, device=dev) if want_logits else None
+    dx = torch.empty((T, D), dtype=torch.float32, device=dev)
+    dxd = torch.empty((T, D), dtype=torch.bfloat16, device=dev) if drop is not None else None
+    p_, seed_, off_, sp_ = drop if drop is not None else (0.0, 0, 0, None)
+    nb = T * (D * 2 + U * 2 + D * 4 + (D * 2 if drop is not None else 0) + (U * 4 if want_logits else 0)) + U * D * 2
+    with _timed("heads_loss_kernel", 2 * 2 * T * U * D, nb):
+        check(lib.mfp_heads_loss_fwd_bwd(_ptr(x_c), _ptr(W), _ptr(bias), U, arr, len(keys), _ptr(nvalid), _ptr(part),
+                                         _ptr(dlogits), _ptr(logits), _ptr(dx), _ptr(dxd), B, S, D, float(p_), int(seed_),
+                                         int(off_), _ptr(sp_), _stream()), "mfp_heads_loss_fwd_bwd")
+    return part, dlogits, logits, dx, dxd
+
+
+def reduce_partials(part: torch.Tensor, out: torch.Tensor, N: int) -> None:
+    """out[:N] = column sums of part[:, :N] (one launch; fixed summation order)."""
+    lib = load()
+    with _timed("reduce_partials_batch", 0, part.numel() * 4):
+        check(lib.mfp_reduce_partials(_ptr(part), _ptr(out), None, None, N, N, part.shape[0], N, part.shape[1], _stream()),
+              "mfp_reduce_partials")
+
+
 def sort_positions(nvalid: torch.Tensor, flag: torch.Tensor, B: int, S: int, labels: Sequence[torch.Tensor] = None,
                    logits: torch.Tensor = None, heads: Sequence = None, out: torch.Tensor = None) -> torch.Tensor:
     """Row map of ``sort_inputs`` (reference tensor_utils.py:14-44) for the documents whose

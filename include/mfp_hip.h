@@ -344,6 +344,21 @@ int mfp_loss_fwd_bwd_acc(const float* logits, void* dlogits, int32_t ld, const m
                          int32_t nkeys, const int32_t* nvalid, float* sums, int32_t B, int32_t S,
                          int32_t dl_dtype, const int32_t* pred_row, const int32_t* true_row, mfp_stream_t stream);
 
+/* Decoder heads + LossLayer + the heads' input gradient in ONE launch (decoder.py:95-111, metrics.py:213-299 and their
+ * autodiff) -- replaces mfp_gemm (heads forward) + mfp_loss_fwd_bwd + mfp_dgrad_rows on the bf16 path, d_model 256:
+ *   logits = x W^T + bias (x bf16 [B*S,256], W bf16 [U][256], bias f32 [U]; U % 8 == 0, U <= 1536), per key the losses
+ *   of mfp_loss_fwd_bwd (same mfp_loss_key array; categorical items on 8-column boundaries and <= 64 classes, numerical
+ *   widths % 8 == 0), dlogits bf16 [B*S,U] (what the heads' weight gradient multiplies), dx = dlogits W f32 [B*S,256]
+ *   and, when dx_drop != NULL, its dropout-masked 1/keep-scaled bf16 copy (keying of mfp_dgrad_rows).
+ * logits f32 [B*S,U] is written only when non-NULL.  The per-key sums leave as per-workgroup partials:
+ * part f32 [mfp_heads_loss_partials(B*S)][48], entry [w][3 k + {0,1,2}] = {loss / B, score, count} of key k; reduce with
+ * mfp_reduce_partials(part, sums, ..., P = partials, N = 3 * nkeys, pstride = 48).  No position-sorted variant. */
+size_t mfp_heads_loss_partials(int32_t T);
+int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys /*host*/,
+                           int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits, float* dx,
+                           void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed,
+                           uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
+
 /* sort_inputs (reference models/tensor_utils.py:14-44) as a row map.  Per document b with flag[b]:
  *   priority(s) = sum_k v_k(s) * 100^(4-k) + [s >= nvalid[b]] * 100^5   (k over type, left, top,
  *   width, height), ascending stable order; row_map[b*S + r] = b*S + (position holding rank r).

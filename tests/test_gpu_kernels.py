@@ -982,6 +982,88 @@ def test_attn_block_fwd(B, p):
     assert_close(x1, x1u.cpu().double(), 3e-2, 2e-2, "x1 vs the three launches")
 
 
+@pytest.mark.parametrize("B,S,want_logits,p", [(3, 128, True, 0.0), (5, 12, True, 0.1), (4, 96, False, 0.1)])
+def test_heads_loss_fused(B, S, want_logits, p):
+    """mfp_heads_loss_fwd_bwd: heads forward + LossLayer + heads input gradient in ONE launch (decoder.py:95-111,
+    metrics.py:213-299) against the launches it replaces on the same bf16 operands (mfp_gemm heads forward ->
+    mfp_loss_fwd_bwd -> dlogits W) and a double reference for dx; Crello heads in ModelLayout's 8-aligned layout, ragged
+    documents, a key without any loss, a loss condition, a tile that is not full (T % 128 != 0)."""
+    ops = _ops()
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.params import ModelLayout
+    ic = make_input_columns("crello")
+    lay = ModelLayout(ic, 256, 1)
+    U, D, T = lay.Upad, 256, B * S
+    batch = synthetic_batch(ic, B, S, seed=4, ragged=True)
+    g = torch.Generator().manual_seed(90 + B)
+    x = bf16_round(torch.randn(T, D, generator=g))
+    W = torch.zeros(U, D)
+    bias = torch.zeros(U)
+    descr, keep_alive = [], []
+    types = batch["type"].to(DEV)
+    for k in lay.head_order:
+        c = ic[k]
+        o, n = lay.head_cols[k]
+        W[o:o + n] = bf16_round(torch.randn(n, D, generator=g) * (0.15 if c["type"] == "categorical" else 0.05))
+        bias[o:o + n] = torch.randn(n, generator=g) * 0.1
+        tgt = batch[k].to(DEV).contiguous()
+        msk = (torch.rand(B, S, generator=g) < 0.3).to(torch.uint8).to(DEV).contiguous()
+        if k == "opacity":
+            msk.zero_()          # a key that carries no loss at all
+        keep_alive += [tgt, msk]
+        d = dict(col_off=o, n_feat=c["shape"][-1] if c["type"] == "categorical" else 1,
+                 n_class=c["input_dim"] if c["type"] == "categorical" else c["shape"][-1],
+                 is_numerical=c["type"] != "categorical", target=tgt, mask=msk)
+        if "loss_condition" in c:
+            bits = sum(1 << i for i, f in enumerate(c["loss_condition"]["mask"]) if f)
+            d.update(cond_idx=types, cond_stride=1, cond_bits=bits)
+        descr.append(d)
+    assert ops.heads_loss_fused_ok(descr, U, D)
+    nvalid = (batch["length"].reshape(-1) + 1).to(torch.int32).to(DEV)
+    xd, Wd, bd = x.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16), bias.to(DEV)
+    step = torch.full((1,), 3, dtype=torch.int32, device=DEV)
+    drop = (p, 11, 6, step) if p > 0 else None
+    part, dl, logits, dx, dxd = ops.heads_loss_fused(xd, Wd, bd, descr, nvalid, B, S, want_logits=want_logits, drop=drop)
+    sums = torch.zeros(len(descr) * 3, device=DEV)
+    ops.reduce_partials(part, sums, 3 * len(descr))
+    sums = sums.view(len(descr), 3).cpu().double()
+    # the launches it replaces
+    logits_u = ops.gemm(xd, Wd, T, U, D, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, bias=bd)
+    sums_u, dl_u = ops.loss_fwd_bwd(logits_u, descr, nvalid, B, S, torch.bfloat16)
+    if want_logits:
+        assert_close(logits, logits_u.cpu().double(), 1e-5, 1e-4, "logits vs the heads GEMM")
+    else:
+        assert logits is None
+    su = sums_u.cpu().double()
+    for i, k in enumerate(lay.head_order):
+        assert abs(sums[i, 0] - su[i, 0]) <= 1e-4 * max(1.0, abs(su[i, 0])), (k, sums[i], su[i])
+        assert abs(sums[i, 1] - su[i, 1]) <= 1e-3 * max(1.0, abs(su[i, 1])), (k, sums[i], su[i])
+        assert sums[i, 2] == su[i, 2], (k, sums[i], su[i])
+    assert sums[lay.head_order.index("opacity"), 2] == 0
+    assert_close(dl, dl_u.float().cpu().double(), 1e-2, 1e-5, "dlogits vs the loss kernels")
+    pad = torch.ones(U, dtype=torch.bool)
+    for k in lay.head_order:
+        o, n = lay.head_cols[k]
+        pad[o:o + n] = False
+    assert (dl[:, pad.to(DEV)] == 0).all()
+    # dx = dlogits W from the kernel's own bf16 dlogits
+    want_dx = dl.float().cpu().double() @ W.double()
+    assert_close(dx, want_dx, 2e-3, 1e-6 + 2e-3 * want_dx.abs().max().item(), "dx vs double")
+    if p > 0:
+        kept = dxd != 0
+        frac = kept.float().mean().item()
+        nz = (dx != 0).float().mean().item()
+        assert abs(frac - (1 - p) * nz) < 0.02, (frac, nz)
+        assert_close(dxd[kept], (dx[kept] / (1 - p)).cpu().double(), 1e-2, 1e-6, "masked copy")
+        # the same mask as mfp_dgrad_rows draws for this (seed, offset, step)
+        ldw = (U + 127) // 128 * 128
+        Wt = torch.zeros(D, ldw, dtype=torch.bfloat16, device=DEV)
+        Wt[:, :U] = Wd.t()
+        _, dxd_u = ops.dgrad_rows(dl, Wt, U, drop=drop)
+        both = (dx != 0) & (ops.dgrad_rows(dl, Wt, U) != 0)
+        assert torch.equal((dxd != 0) & both, (dxd_u != 0) & both)
+
+
 @pytest.mark.parametrize("B", [1, 5])
 def test_attn_block_bwd(B):
     """mfp_attn_block_bwd: da = d_o1 Wo, dqkv = MHSA'(...; da), dy1 = dqkv Wqkv in ONE launch (autodiff of
