@@ -8,19 +8,25 @@
 //
 // It replaces dgrad_qkv_kernel<256>, attn_bwd1_hd32 and dgrad_qkv_kernel<768>: da (1 KB per token, written and read)
 // never leaves the chip, dqkv (1.5 KB) is written once for the weight-gradient launch and not read back here; two launch
-// boundaries less.  Per head pair p = 0..3:
-//   c0  da_p = d_o1 Wo^T rows 64 p .. + 63 (weight chunk [64][512 B] of the transposed shadow) -> LDS image [128][128 B];
-//       meanwhile the q / k / v columns of the pair stream HBM -> LDS images by LDS-DMA;
-//   attention backward of heads 2 p, 2 p + 1 out of the four images, the single-pass algorithm of attn_bwd1_hd32
-//       (csrc/attention.hip) with four waves per head: wave (hh, w) owns keys 32 w .. + 31 of head hh, every score once
-//       (lane = key), P and dS feed dV / dK from registers, dS goes through a shared [128 keys][32 queries] image per head
-//       and wave (dt, qt) computes the tile dQ^T[d][q] over all keys;
-//   dq_p, dk_p, dv_p (bf16) overwrite the q / k / v images; from there they leave for HBM (dqkv) and are the A operands
-//   c1..c3  dy1 accumulators (64 registers) += dq_p Wq^T + dk_p Wk^T + dv_p Wv^T slices ([256][128 B] chunks of the
-//       transposed fused kernel, K = 64 each).
-// Weights stream through TWO 32 KB buffers (LDS: 4 pair images 64 KB, dS 16 KB, weights 64 KB, statistics 2 KB); the
-// chunk behind the attention phase is loaded during it, so only c3's chunk has a prefetch distance of one chunk.
-// Images with 128-byte rows: 16-byte slot ^ ((row >> 1) & 7); dS image: 8-byte piece swizzle of attn_bwd1_hd32.
+// boundaries less.  LDS (all 160 KB of the CU): da image [128][512 B] (64 KB; at the end the dy1 image), the q | k | v
+// images of one head pair [128][128 B] each (48 KB), a ring of three 16 KB weight chunks.
+//   da product first: the d_o1 fragments of the tile sit in registers, eight chunks of 32 rows of the transposed
+//       output-projection kernel stream through the ring, da (bf16) goes into its image -- d_o1 is read from HBM once.
+//   Per head pair p = 0..3:
+//     K / V fragments (keys 32 w .. + 31 of head hh as B operands) and K^T of every key block go into registers; from
+//     then on the k image's place holds Ls / Dl (delta = rowsum(da * a) from the da image and the pair's a columns) and
+//     the v image's place the dS exchange;
+//     attention backward of heads 2 p, 2 p + 1: the single-pass algorithm of attn_bwd1_hd32 (csrc/attention.hip) with four
+//     waves per head -- every score once (lane = key), P and dS (packed bf16) feed dV / dK from registers, dS goes through a
+//     shared [128 keys][32 queries] image per head and wave (dt, qt) computes the tile dQ^T[d][q] over all keys; dq is
+//     written over the q rows of a query block as soon as the block is done, dk / dv over the k / v images at the end;
+//     six K = 32 steps: dy1 accumulators (64 registers) += d{q,k,v}_p times the matching [256][64 B] chunk of the transposed
+//     fused Q|K|V kernel; the three images leave for HBM (dqkv) on the way;
+//     the next pair's q | k | v columns, a columns and lse are prefetched into 33 REGISTERS behind the pair's last weight
+//     chunk and placed into the images when the products are done with them.
+// Images with 128-byte rows: 16-byte slot ^ ((row >> 1) & 7); da image (512-byte rows): slot ^ ((row & 7) << 1 | (row >> 3) & 1)
+// -- conflict-free for the row-wise fragment reads and the transposing reads; dS image: 8-byte piece swizzle of
+// attn_bwd1_hd32.  256 VGPRs, no spill (a spill reload is a scratch access: it would drain the weight ring).
 #include "common.h"
 #include <type_traits>
 #ifndef BB_ABL

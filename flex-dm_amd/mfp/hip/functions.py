@@ -33,6 +33,8 @@ MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
 ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
 # ... and the MLP half behind it on the same tile: the whole block forward in one launch; 0 = attention half + mlp_fused
 BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
+# heads forward + LossLayer + heads input gradient in one launch (csrc/heads_loss.hip); "0" = four launches
+HEADS_FUSED = os.environ.get("MFP_HEADS_FUSED", "1") == "1"
 # the attention half's input gradients (da, attention backward, dy1) in one launch (csrc/block_attn_bwd.hip); "0" = three
 # unset: when the documents fill the chip (one workgroup = one document per CU); with fewer documents than CUs (c4: 128 per
 # GPU) the three launches, which split a document over more workgroups, are faster (1.187 vs 1.210 ms per step)
@@ -515,7 +517,7 @@ def _heads_fwd(ctx: StepCtx, h_c: torch.Tensor) -> torch.Tensor:
                     bias=st.span(st.w, "decoder/decoder_%s/bias" % first, L.Upad))
 
 
-def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Tensor:
+def _heads_wgrad(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> None:
     st, L = ctx.store, ctx.store.layout
     first = L.head_order[0]
     T, D, U = ctx.T, L.D, L.Upad
@@ -528,13 +530,30 @@ def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Ten
                  out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
                  colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U), splitk=ops.wgrad_splitk(T, U, D))
     ctx.on_side(wgrad_heads, dl_c, h_c)
+
+
+def _heads_drop(ctx: StepCtx):
+    """(p, seed, offset, step_ptr) of the last block's MLP dropout when the heads' input-gradient kernel is to leave the
+    masked bf16 gradient that block's backward starts from, else None."""
+    L = ctx.store.layout
+    if ctx.tail["fuse"] and WGRAD_GROUP and ctx.training and L.L > 0:
+        return (ctx.p, ctx.seed, 2 * (L.L - 1) + 2, ctx.step_ptr)
+    return None
+
+
+def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Tensor:
+    st, L = ctx.store, ctx.store.layout
+    first = L.head_order[0]
+    T, D, U = ctx.T, L.D, L.Upad
+    _heads_wgrad(ctx, dl_c, h_c)
     wt = st.heads_t()
     if MLP_FUSE and wt is not None and dl_c.dtype == torch.bfloat16 and D == 256 and T <= (1 << 19):
         last = L.L - 1
-        if ctx.tail["fuse"] and WGRAD_GROUP and ctx.training and L.L > 0:
+        drop = _heads_drop(ctx)
+        if drop is not None:
             # ... and the dropout-masked bf16 copy the last block's backward starts from (mfp_dropout_bwd fused into
             # the epilogue; that Dense's bias gradient then comes out of the block's grouped weight-gradient launch)
-            dh, d_o2 = ops.dgrad_rows(dl_c, wt, U, drop=(ctx.p, ctx.seed, 2 * last + 2, ctx.step_ptr))
+            dh, d_o2 = ops.dgrad_rows(dl_c, wt, U, drop=drop)
             ctx.handoff[last] = d_o2
             ctx.tail["bias_wgg"].add(last)
             return dh
@@ -590,6 +609,38 @@ class DecoderLossFn(torch.autograd.Function):
         else:
             h_c = ctx.to_cdt(h)
         ctx.tail["x_c"] = None
+        st, L = ctx.store, ctx.store.layout
+        if (HEADS_FUSED and ctx.cdt == torch.bfloat16 and ctx.loss_sort is None and MLP_FUSE
+                and ops.heads_loss_fused_ok(keys, L.Upad, L.D)):
+            # heads + losses + d(loss)/d(h) in ONE launch (csrc/heads_loss.hip): the f32 logits are written only when
+            # somebody wants them, the per-key sums come back as per-workgroup partials
+            first = L.head_order[0]
+            dl = st.scratch("dlogits", (ctx.T, L.Upad), ctx.cdt)
+            drop = _heads_drop(ctx)
+            part, dl, logits, dx, dxd = ops.heads_loss_fused(
+                h_c, st.cw("decoder/decoder_%s/kernel" % first, rows=L.Upad),
+                st.span(st.w, "decoder/decoder_%s/bias" % first, L.Upad), keys, ctx.nvalid, ctx.B, ctx.S, dlogits=dl,
+                want_logits=ctx.tail.get("want_logits", True), drop=drop)
+            n3 = 3 * len(keys)
+            flat = ctx.tail["sums"]
+            if flat is not None and flat.numel() == n3 + 1:
+                sums, loss = flat[:n3].view(len(keys), 3), flat[n3:].view(())
+                ctx.tail["sums"] = None
+                if ctx.ln_jobs is not None and torch.is_grad_enabled():
+                    # summed with the LayerNorm parameter-gradient partials, in the one launch at the end of the backward pass
+                    ctx.ln_jobs.append(dict(part=part, out0=flat, out1=None, out2=None, split1=n3, split2=n3,
+                                            P=part.shape[0], N=n3, pstride=part.shape[1]))
+                else:
+                    ops.reduce_partials(part, flat, n3)
+            else:
+                sums = torch.empty((len(keys), 3), dtype=torch.float32, device=h_c.device)
+                ops.reduce_partials(part, sums, n3)
+                loss = sums[:, 0].sum()
+            if logits is None:
+                logits = h_c.new_empty((0, L.Upad), dtype=torch.float32)
+            fctx.ctx, fctx.saved = ctx, (h_c, dl, dx, dxd)
+            fctx.mark_non_differentiable(sums, logits)
+            return loss, sums, logits
         logits = _heads_fwd(ctx, h_c)
         dl = ctx.store.scratch("dlogits", logits.shape, ctx.cdt)   # zeroed once: pad columns stay 0
         pred_row, true_row = loss_row_maps(ctx.loss_sort, logits, ctx.nvalid, ctx.B, ctx.S)
@@ -615,6 +666,15 @@ class DecoderLossFn(torch.autograd.Function):
     @staticmethod
     def backward(fctx, dloss, dsums, dlogits):
         ctx = fctx.ctx
+        if len(fctx.saved) == 4:      # the one-launch path: the input gradient came out of the forward launch
+            h_c, dl, dh, dxd = fctx.saved
+            _heads_wgrad(ctx, dl, h_c)
+            if dxd is not None:
+                last = ctx.store.layout.L - 1
+                ctx.handoff[last] = dxd
+                ctx.tail["bias_wgg"].add(last)
+            fctx.saved = None
+            return dh, None, None
         h_c, dl = fctx.saved
         dh = _heads_bwd(ctx, dl, h_c)
         fctx.saved = None

@@ -284,6 +284,7 @@ class MFP:
         if self.fast_masking and self.input_dtype == "set":
             ctx = self.model.make_ctx(batch, True, nvalid=nvalid)
             ctx.tail["sums"] = sums_flat
+            ctx.tail["want_logits"] = False      # the step returns the per-key sums; nobody reads the logits
             idx_all, codes, xs, masks = self._masker(batch, tasks, ctx.nvalid, ctx.B, ctx.S, self.model.step_ptr)
             keys = build_loss_keys(self._all_input_columns, self.model.layout.head_cols, batch, masks)
             cin = {"task": tasks[..., None], "length": batch["length"]} if self.context is not None else None

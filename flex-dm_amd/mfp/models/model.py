@@ -96,6 +96,8 @@ class Model:
         B, S, D = h.shape
         ctx.loss_sort = loss_sort
         loss, sums, logits = DecoderLossFn.apply(h.reshape(B * S, D), ctx, loss_keys)
+        if logits.shape[0] == 0:      # (the train step asked for no logits: ctx.tail["want_logits"] = False)
+            return loss, sums, {}
         outputs = split_logits(logits, self.layout, self.input_columns, B, S)
         outputs["_flat_logits"] = logits
         return loss, sums, outputs
