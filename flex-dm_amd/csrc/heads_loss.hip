@@ -25,6 +25,14 @@
 // Every iteration issues the same vector-memory operations (out-of-range offsets / zero-sized buffers where a chunk has
 // nothing to load or store), so "chunk c has landed" is s_waitcnt vmcnt(24) in every iteration.
 #include "common.h"
+#ifndef HL_ABL
+#define HL_ABL 0
+#endif
+// HL_ABL == 9: timing build (tools/trace_heads.py): every wave drops shader-clock stamps (scalar stores, no vector-memory
+// operation added) into the logits buffer, which is then not written: stamp 4 c + {0: chunk landed, 1: logits tile,
+// 2: dl image complete, 3: second product} of chunk c, 254 = start, 255 = end
+#define HL_TR(i) do { if (HL_ABL == 9) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); const unsigned int o_ = (unsigned int)(i) * 8u; \
+    asm volatile("s_store_dwordx2 %0, %1, %2 glc" :: "s"(t_), "s"(trbase), "s"(o_) : "memory"); } } while (0)
 
 namespace {
 
@@ -65,6 +73,25 @@ struct HlParams {
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
+// All-reduce over a 16-lane row with DPP moves (quad xor 1, quad xor 2, half-row mirror, row mirror): a `__shfl_xor` is a
+// ds_bpermute round trip, and the softmax walk below is a chain of ~28 of them per item.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+  v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0x140>(v));
+  return v;
+}
+
 __device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int dsw(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
 
@@ -87,6 +114,8 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   const int nch = p.nch;
   constexpr unsigned int OOB = 0xFFFFFFF0u;
   const int step_now = (p.dXd && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
+  const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.logits) + (size_t)(blockIdx.x * 8 + wave) * 256;
+  HL_TR(254);
 
   const unsigned int xbytes = (unsigned int)p.T * (HL_D * 2);
   const unsigned int ldb2 = (unsigned int)p.ld * 2u, ldb4 = (unsigned int)p.ld * 4u;
@@ -94,7 +123,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W), 0, (unsigned int)p.U * (HL_D * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dl = __builtin_amdgcn_make_buffer_rsrc(p.dlogits, 0, (unsigned int)p.T * ldb2, 0x00020000);
   // (no logits / no masked copy wanted: zero-sized buffers; the stores are issued all the same -- the counted waits stay fixed)
-  const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(p.logits ? (void*)p.logits : (void*)p.dX, 0, p.logits ? (unsigned int)p.T * ldb4 : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(p.logits ? (void*)p.logits : (void*)p.dX, 0, (p.logits && HL_ABL != 9) ? (unsigned int)p.T * ldb4 : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.dX, 0, (unsigned int)p.T * (HL_D * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(p.dXd ? (void*)p.dXd : (void*)p.dX, 0, p.dXd ? xbytes : 0u, 0x00020000);
 
@@ -109,6 +138,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_u8*)(dst + i * 1024), 16, vo, col0 * 512, 0, 0);
     }
   };
+  unsigned int onm[2] = {0u, 0u};      // bit k: this lane's row (of row tile rt) carries a loss for key k (filled after the prologue)
   // ---- targets of a numerical chunk for this lane's (row tile, column tile) pairs: only rows that carry a loss
   auto tload = [&](int c, f32x4 (&tg)[2][2]) {
     const int w1 = c < nch ? p.ch[c][1] : 0;
@@ -122,8 +152,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = rp * 32 + rt * 16 + li;
-      const int wv = Wrow[k * 128 + row];
-      const bool on = num & (wv != 0);
+      const bool on = num & (((onm[rt] >> k) & 1u) != 0u);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
         off[nt][rt] = on ? ((unsigned int)(row0 + row) * (unsigned int)key.n_class + cb + (nh * 2 + nt) * 16 + 4 * g) * 4u : OOB;
@@ -146,25 +175,34 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   wload(0);
   wload(1);
   {
+    // (four keys / four items per thread, all their loads issued before the first is used: one memory round trip each,
+    //  not a chain per key; the key index is wave-uniform, so the key records are scalar loads)
     const int row = tid & 127, t = row0 + row;
-    for (int k = tid >> 7; k < p.nkeys; k += 4) {
-      const mfp_loss_key& key = p.key[k];
-      bool w = false;
-      if (t < p.T) {
-        const int b = t / p.S, s = t - b * p.S;
-        const unsigned char m = key.mask[t];
-        const int nv = p.nvalid[b];
-        const int v = key.cond_idx != nullptr ? key.cond_idx[(long long)t * key.cond_stride] : 0;
-        const bool cnd = key.cond_idx == nullptr || (v >= 0 && v < 32 && ((key.cond_bits >> v) & 1u));
-        w = m != 0 && s < nv && cnd;
-      }
-      Wrow[k * 128 + row] = w ? 1 : 0;
+    const int kq = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const bool live = t < p.T;
+    const int b = live ? t / p.S : 0, s = t - b * p.S;
+    const int nv = p.nvalid[b];
+    unsigned char m[4]; int v[4]; int y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kq + 4 * i;
+      const mfp_loss_key& key = p.key[k < p.nkeys ? k : 0];
+      m[i] = (live && k < p.nkeys) ? key.mask[t] : 0;
+      v[i] = (live && k < p.nkeys && key.cond_idx != nullptr) ? key.cond_idx[(long long)t * key.cond_stride] : 0;
+      const int it = kq + 4 * i;
+      const int itc = it < p.nitem ? it : 0;
+      const mfp_loss_key& ikey = p.key[p.item_key[itc]];
+      y[i] = (live && it < p.nitem) ? reinterpret_cast<const int*>(ikey.target)[(long long)t * ikey.n_feat + p.item_feat[itc]] : 0;
     }
-    for (int it = tid >> 7; it < p.nitem; it += 4) {
-      const mfp_loss_key& key = p.key[p.item_key[it]];
-      int y = 0;
-      if (t < p.T) y = reinterpret_cast<const int*>(key.target)[(long long)t * key.n_feat + p.item_feat[it]];
-      Ylab[row * 16 + it] = (unsigned char)(y < 0 ? 255 : (y > 254 ? 255 : y));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kq + 4 * i;
+      if (k < p.nkeys) {
+        const mfp_loss_key& key = p.key[k];
+        const bool cnd = key.cond_idx == nullptr || (v[i] >= 0 && v[i] < 32 && ((key.cond_bits >> v[i]) & 1u));
+        Wrow[k * 128 + row] = (m[i] != 0 && s < nv && cnd && live) ? 1 : 0;
+      }
+      if (k < p.nitem) Ylab[row * 16 + k] = (unsigned char)(y[i] < 0 ? 255 : (y[i] > 254 ? 255 : y[i]));
     }
     for (int i = tid; i < HL_MAXU; i += 512) Bias[i] = i < p.U ? p.bias[i] : 0.f;
     if (tid < 48) Red[tid] = 0.f;
@@ -174,6 +212,9 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+    for (int k = 0; k < p.nkeys; ++k) onm[rt] |= (unsigned int)(Wrow[k * 128 + rp * 32 + rt * 16 + li] != 0) << k;
   int xs[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ dsw(li)) << 4;
@@ -190,6 +231,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
     // chunk c has landed: younger than its four loads are the 10 other operations of iteration c - 2 and the 14 of c - 1
     asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                    // B1
+    HL_TR(4 * c);
     // (opaque copies per iteration: loop-invariant address arithmetic is not hoisted out of the loop and kept in registers)
     int li_c = li, g_c = g, tid_c = tid;
     asm volatile("" : "+v"(li_c), "+v"(g_c), "+v"(tid_c));
@@ -226,6 +268,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         }
       }
     }
+    HL_TR(4 * c + 1);
     if (kind == 0) {
       // ---- 2a. categorical chunk: logits -> LDS, active (row, item) pairs compacted
 #pragma unroll
@@ -234,12 +277,20 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         for (int rt = 0; rt < 2; ++rt)
           *reinterpret_cast<f32x4*>(Tile + (rp * 32 + rt * 16 + li_c) * HL_TW + (nh * 2 + nt) * 16 + 4 * g_c) = acc[nt][rt];
       const int item0 = cw2 & 0xff, ni = (cw2 >> 8) & 0xff;
-      for (int idx = tid_c; idx < 128 * ni; idx += 512) {
+      for (int idx = tid_c; idx < 128 * ni; idx += 512) {      // (128 ni is a multiple of the wave size: whole waves)
         const int row = idx & 127, j = idx >> 7;
-        if (Wrow[Itab[item0 + j] * 128 + row]) Act[atomicAdd(Nact, 1)] = (unsigned short)(row | (j << 7));
+        const bool on = Wrow[Itab[item0 + j] * 128 + row] != 0;
+        // one LDS atomic per wave (per-item atomics on the one counter were most of this phase)
+        const unsigned long long bm = __ballot(on);
+        int base = 0;
+        if (lane == 0 && bm != 0ull) base = atomicAdd(Nact, __popcll(bm));
+        base = __shfl(base, 0, 64);
+        if (on) Act[base + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)(row | (j << 7));
       }
+      if (c < 8) HL_TR(128 + 8 * c);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                                  // B2
+      if (c < 8) HL_TR(128 + 8 * c + 1);
       const int na = *Nact;
       const int l16 = tid_c & 15;
       for (int a = tid_c >> 4; a < na; a += 32) {
@@ -247,52 +298,57 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         const int kidx = Itab[item], C = Itab[32 + item];
         float* z = Tile + row * HL_TW + (Itab[16 + item] - col0);
         const int y = Ylab[row * 16 + item];
+        // the item's classes (<= 64: four per lane) stay in registers from the one LDS read to the one LDS write
+        float zv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zv[q] = l16 + 16 * q < C ? z[l16 + 16 * q] : -INFINITY;
         float m = -INFINITY;
         int am = 0x7fffffff;
-        for (int j = l16; j < C; j += 16) { const float v = z[j]; if (v > m) { m = v; am = j; } }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          const float om = __shfl_xor(m, o, 64);
-          const int oa = __shfl_xor(am, o, 64);
-          if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        for (int q = 0; q < 4; ++q) if (zv[q] > m) { m = zv[q]; am = l16 + 16 * q; }
+        {      // max, and the FIRST index that holds it (as the serial reference walk)
+          const float mm = row16_max(m);
+          am = row16_min(m == mm ? am : 0x7fffffff);
+          m = mm;
         }
         float se = 0.f;
-        for (int j = l16; j < C; j += 16) { const float e = expf(z[j] - m); z[j] = e; se += e; }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
-        const float inv = 1.f / se;
+        for (int q = 0; q < 4; ++q) { zv[q] = l16 + 16 * q < C ? __builtin_amdgcn_exp2f((zv[q] - m) * 1.4426950408889634f) : 0.f; se += zv[q]; }
+        se = row16_sum(se);
+        const float inv = __builtin_amdgcn_rcpf(se);
         float sq = 0.f, qy = 0.f;
-        for (int j = l16; j < C; j += 16) {
-          const float pj = z[j] * inv;
-          const float q = fminf(fmaxf(pj, 1e-7f), 1.f - 1e-7f);
-          sq += q;
-          if (j == y) qy = q;
-        }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); qy += __shfl_xor(qy, o, 64); }
-        const float loss = -logf(qy) + logf(sq);
-        const float inv_sq = 1.f / sq, inv_qy = 1.f / qy;
-        float gp = 0.f;
-        for (int j = l16; j < C; j += 16) {
-          const float pj = z[j] * inv;
-          const float gg = (pj >= 1e-7f && pj <= 1.f - 1e-7f) ? ((j == y ? -inv_qy : 0.f) + inv_sq) : 0.f;
-          gp += gg * pj;
+        for (int q = 0; q < 4; ++q) {
+          const int j = l16 + 16 * q;
+          zv[q] *= inv;                                        // p_j
+          const float qq = fminf(fmaxf(zv[q], 1e-7f), 1.f - 1e-7f);
+          if (j < C) sq += qq;
+          if (j == y) qy = qq;
         }
+        sq = row16_sum(sq); qy = row16_sum(qy);
+        const float loss = (__builtin_amdgcn_logf(sq) - __builtin_amdgcn_logf(qy)) * 0.6931471805599453f;
+        const float inv_sq = __builtin_amdgcn_rcpf(sq), inv_qy = __builtin_amdgcn_rcpf(qy);
+        float gg[4], gp = 0.f;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) gp += __shfl_xor(gp, o, 64);
-        for (int j = l16; j < C; j += 16) {
-          const float pj = z[j] * inv;
-          const float gg = (pj >= 1e-7f && pj <= 1.f - 1e-7f) ? ((j == y ? -inv_qy : 0.f) + inv_sq) : 0.f;
-          z[j] = pj * (gg - gp) * p.inv_B;
+        for (int q = 0; q < 4; ++q) {
+          const int j = l16 + 16 * q;
+          gg[q] = (j < C && zv[q] >= 1e-7f && zv[q] <= 1.f - 1e-7f) ? ((j == y ? -inv_qy : 0.f) + inv_sq) : 0.f;
+          gp += gg[q] * zv[q];
         }
+        gp = row16_sum(gp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (l16 + 16 * q < C) z[l16 + 16 * q] = zv[q] * (gg[q] - gp) * p.inv_B;
         if (l16 == 0) {
           atomicAdd(&Red[kidx * 3 + 0], loss * p.inv_B);
           atomicAdd(&Red[kidx * 3 + 1], am == y ? 1.f : 0.f);
           atomicAdd(&Red[kidx * 3 + 2], 1.f);
         }
       }
+      if (c < 8) HL_TR(128 + 8 * c + 2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                                  // B3
+      if (c < 8) HL_TR(128 + 8 * c + 3);
       if (tid_c == 0) *Nact = 0;
       const unsigned long long pmap = (unsigned long long)(unsigned int)p.ch[c][3] | ((unsigned long long)(unsigned int)p.ch[c][4] << 32);
       // tile -> dl image: a thread converts two 8-column pieces; pieces of inactive items / padding / other chunks' columns are 0
@@ -322,7 +378,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int row = rp * 32 + rt * 16 + li_c;
-        const bool on = Wrow[k * 128 + row] != 0;
+        const bool on = ((onm[rt] >> k) & 1u) != 0u;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           u32x2 pk = {0u, 0u};
@@ -356,9 +412,12 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         }
       }
     }
+    if (c < 8) HL_TR(128 + 8 * c + 4);
     tload(c + 1, tg);                                                                // 4 loads: the next chunk's targets
+    if (c < 8) HL_TR(128 + 8 * c + 5);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                    // B4: the dl image is complete
+    HL_TR(4 * c + 2);
     if (kind == 1 && clast && nh == 0) {
       const int k = ckey;
       float l0 = 0.f, l1 = 0.f, l2 = 0.f;
@@ -411,8 +470,10 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         for (int rt = 0; rt < 2; ++rt) acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt, hf[rt], acc2[ct][rt], 0, 0, 0);
       }
     }
+    HL_TR(4 * c + 3);
   }
 
+  HL_TR(253);
   // ---- dx (f32) and its dropout-masked, 1/keep-scaled bf16 copy (dgrad_rows_kernel's epilogue); the per-key partial sums
   {
     const float inv_keep = 1.0f / (1.0f - p.dropout_p);
@@ -433,6 +494,8 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
       }
   }
   __syncthreads();
+  HL_TR(255);
+  if (HL_ABL == 9) asm volatile("s_dcache_wb" ::: "memory");
   if (tid < 48) p.part[(long long)blockIdx.x * 48 + tid] = tid < p.nkeys * 3 ? Red[tid] : 0.f;
 }
 
