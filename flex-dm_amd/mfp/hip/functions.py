@@ -626,7 +626,7 @@ class DecoderLossFn(torch.autograd.Function):
             if flat is not None and flat.numel() == n3 + 1:
                 sums, loss = flat[:n3].view(len(keys), 3), flat[n3:].view(())
                 ctx.tail["sums"] = None
-                if ctx.ln_jobs is not None and torch.is_grad_enabled():
+                if ctx.ln_jobs is not None and fctx.needs_input_grad[0]:      # (a backward pass will follow)
                     # summed with the LayerNorm parameter-gradient partials, in the one launch at the end of the backward pass
                     ctx.ln_jobs.append(dict(part=part, out0=flat, out1=None, out2=None, split1=n3, split2=n3,
                                             P=part.shape[0], N=n3, pstride=part.shape[1]))
