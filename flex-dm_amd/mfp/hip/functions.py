@@ -112,7 +112,12 @@ class StepCtx:
         c.nvalid = (self.nvalid + 1).contiguous()
         return c
 
-    def on_side(self, fn, *tensors, which: int = 0):
+    # MFP_SIDE_STREAMS=2: only a block's grouped weight-gradient launch leaves the main stream, and only for as long as
+    # that block's LN1 backward (an HBM-bound streaming kernel whose workgroups fit beside the weight-gradient ones) runs:
+    # BlockFn joins before it returns.  Every other on_side call joins at once (= in line).
+    OVERLAP = os.environ.get("MFP_SIDE_STREAMS", "0") == "2"
+
+    def on_side(self, fn, *tensors, which: int = 0, hold: bool = False):
         """Run ``fn`` (weight-gradient GEMMs: off the critical path, only Adam needs them) on the
         side HIP stream, forked after everything enqueued so far on the current stream.  Every
         kernel of the step leaves most of a CU idle (profiles/r01_gemm_qkv_timeline.txt), so the
@@ -127,6 +132,12 @@ class StepCtx:
             fn()
         for t in tensors:   # their memory must not be recycled by main-stream allocations too early
             t.record_stream(side)
+        if self.OVERLAP and not hold:
+            main.wait_stream(side)
+
+    def join_held(self):
+        if self.OVERLAP and self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def flush_ln_jobs(self):
         """Sum the LayerNorm gamma / beta (/ fused bias) gradient partials of every layer handled so
@@ -476,7 +487,7 @@ class BlockFn(torch.autograd.Function):
                      colsum=st.grad(p + "mlp/dense_1/bias") if i in ctx.tail["bias_wgg"] else None),
                 dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)], T)
         if grouped:
-            ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1)
+            ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1, hold=True)
         else:
             ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
         if dy1 is not None:
@@ -504,6 +515,7 @@ class BlockFn(torch.autograd.Function):
             else:
                 dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
                                        st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), jobs=ctx.ln_jobs)
+        ctx.join_held()
         fctx.saved = None
         return dx, None, None
 

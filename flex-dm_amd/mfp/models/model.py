@@ -49,7 +49,7 @@ class Model:
                                dropout=dropout, l2=l2)
         self.step_ptr = None  # device int32 step counter (set by the optimizer) for dropout offsets
         import os
-        cuda = self.store.device.type == "cuda" and os.environ.get("MFP_SIDE_STREAMS", "0") == "1"   # 1: weight gradients on side streams (measured 85 us/step SLOWER with the grouped launches)
+        cuda = self.store.device.type == "cuda" and os.environ.get("MFP_SIDE_STREAMS", "0") in ("1", "2")   # 1: weight gradients on side streams (measured 85 us/step SLOWER with the grouped launches)
         self.side_stream = torch.cuda.Stream(device=self.store.device) if cuda else None
         self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=self.store.device) for _ in range(2)] if cuda else []
         self._first = _first_seq_key(input_columns)
