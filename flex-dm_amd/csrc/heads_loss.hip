@@ -57,7 +57,8 @@ struct HlParams {
   float* part;               // [workgroups][48]
   unsigned short* dlogits;   // [T][ld] bf16
   float* logits;             // [T][ld] f32 or nullptr
-  float* dX;                 // [T][256] f32
+  float* dX;                 // [T][256] f32 or nullptr
+  unsigned short* dXb;       // [T][256] bf16 (the same, unmasked, in the compute dtype) or nullptr
   unsigned short* dXd;       // [T][256] bf16 dropout-masked copy or nullptr
   const int* step_ptr;
   unsigned long long seed, offset;
@@ -123,9 +124,10 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W), 0, (unsigned int)p.U * (HL_D * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dl = __builtin_amdgcn_make_buffer_rsrc(p.dlogits, 0, (unsigned int)p.T * ldb2, 0x00020000);
   // (no logits / no masked copy wanted: zero-sized buffers; the stores are issued all the same -- the counted waits stay fixed)
-  const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(p.logits ? (void*)p.logits : (void*)p.dX, 0, (p.logits && HL_ABL != 9) ? (unsigned int)p.T * ldb4 : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.dX, 0, (unsigned int)p.T * (HL_D * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(p.dXd ? (void*)p.dXd : (void*)p.dX, 0, p.dXd ? xbytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(p.logits ? (void*)p.logits : (void*)p.dlogits, 0, (p.logits && HL_ABL != 9) ? (unsigned int)p.T * ldb4 : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.dX ? (void*)p.dX : (void*)p.dlogits, 0, p.dX ? (unsigned int)p.T * (HL_D * 4) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cb = __builtin_amdgcn_make_buffer_rsrc(p.dXb ? (void*)p.dXb : (void*)p.dlogits, 0, p.dXb ? xbytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(p.dXd ? (void*)p.dXd : (void*)p.dlogits, 0, p.dXd ? xbytes : 0u, 0x00020000);
 
   // ---- weight chunk c -> ring buffer c % 3: W rows col0 .. col0 + 63 ([64][512 B], slot ^ dsw(row)); rows past U read zero
   auto wload = [&](int c) {
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         const int row = row0 + rp * 32 + rt * 16 + li, n = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + 4 * g;
         const f32x4 v = acc2[ct][rt];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_c, (unsigned int)row * (HL_D * 4) + n * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rs_cb, (unsigned int)row * (HL_D * 2) + n * 2, 0, 0);
         bool keep[4] = {true, true, true, true};
         if (p.dropout_p > 0.f) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
         const u32x2 pk = {pack_bf16x2(keep[0] ? v[0] * inv_keep : 0.f, keep[1] ? v[1] * inv_keep : 0.f),
@@ -505,17 +508,17 @@ extern "C" size_t mfp_heads_loss_partials(int32_t T) { return (size_t)((T + HL_R
 
 extern "C" int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys,
                                       int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits,
-                                      float* dx, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p,
+                                      float* dx, void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p,
                                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
-  MFP_CHECK_ARG(x && W && bias && keys && nvalid && part && dlogits && dx);
+  MFP_CHECK_ARG(x && W && bias && keys && nvalid && part && dlogits && (dx || dx_bf16));
   MFP_CHECK_ARG(B > 0 && S > 0 && D == HL_D && U > 0 && U % 8 == 0 && U <= HL_MAXU && nkeys > 0 && nkeys <= MFP_MAX_LOSS_KEYS);
   MFP_CHECK_ARG((long long)B * S <= (1 << 20) && dropout_p >= 0.f && dropout_p < 1.f);
   MFP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)dlogits % 16) == 0 && ((uintptr_t)logits % 16) == 0 &&
-                ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dx_drop % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+                ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dx_bf16 % 16) == 0 && ((uintptr_t)dx_drop % 16) == 0 && ((uintptr_t)bias % 16) == 0);
   HlParams p;
   p.X = reinterpret_cast<const unsigned short*>(x); p.W = reinterpret_cast<const unsigned short*>(W); p.bias = bias;
   p.nvalid = nvalid; p.part = part; p.dlogits = reinterpret_cast<unsigned short*>(dlogits); p.logits = logits;
-  p.dX = dx; p.dXd = reinterpret_cast<unsigned short*>(dx_drop); p.step_ptr = step_ptr; p.seed = seed; p.offset = offset;
+  p.dX = dx; p.dXb = reinterpret_cast<unsigned short*>(dx_bf16); p.dXd = reinterpret_cast<unsigned short*>(dx_drop); p.step_ptr = step_ptr; p.seed = seed; p.offset = offset;
   p.nkeys = nkeys; p.T = B * S; p.S = S; p.U = U; p.ld = U; p.inv_B = 1.0f / (float)B; p.dropout_p = dropout_p;
   // heads in column order; categorical items (key, feature) and the chunk table
   int order[MFP_MAX_LOSS_KEYS];

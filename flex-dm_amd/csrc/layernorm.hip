@@ -66,14 +66,16 @@ constexpr int LN_BWD_ROWS = 32;  // rows per workgroup (4 waves x 8 rows); 64 an
 // kernel also emits ddrop = cdt(keep ? dx/(1-p) : 0) with the dropout keying of the GEMM epilogue
 // (a lane holds 4 consecutive columns = one drop_keep4 call) and the column sums of ddrop (the Dense
 // bias gradient) as a third partial vector -- saving a full re-read of dx and two launches.
-template <typename TDY, int NVEC>
+// TRES = type of the residual gradient stream (dres in, dx out): float, or bf16 (unsigned short) when the step carries
+// the residual gradient in the compute dtype (mfp_layernorm_bwd_res16: 1 KB per element and layer less).
+template <typename TDY, int NVEC, typename TRES = float>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
-                                                     const float* __restrict__ dres,
-                                                     float* __restrict__ dx, float* __restrict__ part,
+                                                     const TRES* __restrict__ dres,
+                                                     TRES* __restrict__ dx, float* __restrict__ part,
                                                      int T, int D, TDY* __restrict__ ddrop, float drop_p,
                                                      unsigned long long seed, unsigned long long offset0,
                                                      const int* __restrict__ step_ptr) {
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   auto load_row = [&](int row, RowIn& in) {
     const float* xr = x + (long long)row * D;
     const TDY* dyr = dy + (long long)row * D;
-    const float* drr = dres ? dres + (long long)row * D : nullptr;
+    const TRES* drr = dres ? dres + (long long)row * D : nullptr;
     in.mu = mean[row];
     in.rs = rstd[row];
 #pragma unroll
@@ -113,7 +115,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
       } else {
         in.dvh[i] = *reinterpret_cast<const u32x2*>(dyr + c);
       }
-      if (drr) in.rv[i] = *reinterpret_cast<const float4*>(drr + c);
+      if (drr) {
+        if constexpr (sizeof(TRES) == 4) {
+          in.rv[i] = *reinterpret_cast<const float4*>(drr + c);
+        } else {
+          const u32x2 t = *reinterpret_cast<const u32x2*>(drr + c);
+          in.rv[i] = make_float4(bf16_to_f32((unsigned short)(t[0] & 0xffff)), bf16_to_f32((unsigned short)(t[0] >> 16)),
+                                 bf16_to_f32((unsigned short)(t[1] & 0xffff)), bf16_to_f32((unsigned short)(t[1] >> 16)));
+        }
+      }
     }
   };
   float4 gam[NVEC];
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
     }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
-    float* dxr = dx + (long long)row * D;
+    TRES* dxr = dx + (long long)row * D;
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int c = lane * 4 + i * 256, j = 4 * i;
@@ -164,7 +174,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         const float4 r = cur.rv[i];
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
-      *reinterpret_cast<float4*>(dxr + c) = o;
+      if constexpr (sizeof(TRES) == 4) {
+        *reinterpret_cast<float4*>(dxr + c) = o;
+      } else {
+        *reinterpret_cast<u32x2*>(dxr + c) = (u32x2){pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
+      }
       if (ddrop != nullptr) {
         if (drop_p > 0.f) {
           bool keep[4];
@@ -241,16 +255,16 @@ extern "C" size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D) {
   return nblk * 3 * D * sizeof(float);
 }
 
-extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
-                                 const float* rstd, const float* dres, float* dx, float* dgamma,
-                                 float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
-                                 int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
-                                 uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+template <typename TRES>
+static int ln_bwd_impl(const char* who, const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       const TRES* dres, TRES* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                       int32_t T, int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p, uint64_t seed,
+                       uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
   MFP_CHECK_ARG(dy && x && gamma && mean && rstd && dx && (dgamma != nullptr) == (dbeta != nullptr));
   MFP_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024);
   MFP_CHECK_ARG((ddrop == nullptr) == (drop_colsum == nullptr) && drop_p >= 0.f && drop_p < 1.f);
   if (!workspace || workspace_bytes < mfp_layernorm_bwd_workspace_bytes(T, D)) {
-    mfp_set_error("mfp_layernorm_bwd: workspace too small");
+    mfp_set_error("%s: workspace too small", who);
     return MFP_EWORKSPACE;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -258,7 +272,7 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
   float* part = reinterpret_cast<float*>(workspace);
   MFP_CHECK_ARG(dy_dtype == MFP_F32 || dy_dtype == MFP_BF16);
   const int nvec = (D + 255) / 256;
-#define LN_BWD(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D, (TT*)ddrop, drop_p, seed, offset, step_ptr)
+#define LN_BWD(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV, TRES>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D, (TT*)ddrop, drop_p, seed, offset, step_ptr)
   if (dy_dtype == MFP_F32) {
     if (nvec == 1) LN_BWD(float, 1); else if (nvec == 2) LN_BWD(float, 2); else LN_BWD(float, 4);
   } else {
@@ -271,6 +285,25 @@ extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* ga
   launch_reduce_rows3(part, dgamma, dbeta, drop_colsum, D, 2 * D, nblk, ddrop != nullptr ? 3 * D : 2 * D, 3 * D, st);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
+}
+
+extern "C" int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, const float* dres, float* dx, float* dgamma,
+                                 float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
+                                 int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
+                                 uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  return ln_bwd_impl<float>("mfp_layernorm_bwd", dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, workspace_bytes, T, D,
+                            dy_dtype, ddrop, drop_colsum, drop_p, seed, offset, step_ptr, stream);
+}
+
+extern "C" int mfp_layernorm_bwd_res16(const void* dy, const float* x, const float* gamma, const float* mean,
+                                       const float* rstd, const void* dres, void* dx, float* dgamma,
+                                       float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
+                                       int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
+                                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  return ln_bwd_impl<unsigned short>("mfp_layernorm_bwd_res16", dy, x, gamma, mean, rstd, reinterpret_cast<const unsigned short*>(dres),
+                                     reinterpret_cast<unsigned short*>(dx), dgamma, dbeta, workspace, workspace_bytes, T, D, dy_dtype,
+                                     ddrop, drop_colsum, drop_p, seed, offset, step_ptr, stream);
 }
 
 extern "C" int32_t mfp_layernorm_bwd_partial_rows(int32_t T) { return (T + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }

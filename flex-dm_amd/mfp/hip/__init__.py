@@ -103,6 +103,8 @@ SIGNATURES = {
     "mfp_layernorm_fwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_int32, c_void_p]),
     "mfp_layernorm_bwd": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                     c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "mfp_layernorm_bwd_res16": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                          c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mfp_layernorm_bwd_partial_rows": (c_int32, [c_int32]),
     "mfp_reduce_partials": (c_int32, [c_void_p] * 4 + [c_int64, c_int64, c_int32, c_int64, c_int64, c_void_p]),
@@ -135,7 +137,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int32, c_void_p]),
     "mfp_heads_loss_partials": (ctypes.c_size_t, [c_int32]),
     "mfp_heads_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
                                          c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_loss_fwd_bwd_acc": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p, c_void_p,
                                        c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -33,6 +33,22 @@ MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
 ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
 # ... and the MLP half behind it on the same tile: the whole block forward in one launch; 0 = attention half + mlp_fused
 BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
+# the gradient of the residual stream (what one block's backward hands to the next) in bf16 instead of f32 on the bf16
+# train step: every LayerNorm backward then reads and writes 0.5 KB instead of 1 KB per element for it.  autograd sees
+# stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  Measured:
+# 1.547 vs 1.559 ms per c2 step (the LayerNorm backward is not purely bandwidth-bound at 3 KB per element) for eight more
+# bf16 roundings on the way down -- OFF by default ("1" = on)
+RES_GRAD_BF16 = os.environ.get("MFP_RES_GRAD_BF16", "0") == "1"
+
+
+def _res16_ok(ctx) -> bool:
+    """The bf16 train step whose only consumers of the residual gradient are the LayerNorm backward kernels and the
+    encoder's grouped weight-gradient launch (which reads its bf16 copy anyway)."""
+    L = ctx.store.layout
+    return (RES_GRAD_BF16 and ctx.cdt == torch.bfloat16 and ctx.training and ctx.tail["fuse"] and WGRAD_GROUP and MLP_FUSE
+            and L.table_rows_pad <= 1024 and L.D == 256 and L.L > 0)
+
+
 # heads forward + LossLayer + heads input gradient in one launch (csrc/heads_loss.hip); "0" = four launches
 HEADS_FUSED = os.environ.get("MFP_HEADS_FUSED", "1") == "1"
 # the attention half's input gradients (da, attention backward, dy1) in one launch (csrc/block_attn_bwd.hip); "0" = three
@@ -89,6 +105,7 @@ class StepCtx:
         self.ln_jobs = [] if os.environ.get("MFP_LN_BATCH_REDUCE", "1") == "1" else None
         self.loss_sort = None   # RICO position-sorted loss: dict(flag, labels, heads, ignore_sort)
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
+        self.res_grad = None   # the bf16 gradient of the residual stream on its way down (RES_GRAD_BF16), else None
         # train-step tail fusions (shared with the context-token view of this step): "fuse" (set by
         # Model.forward_loss when the last block feeds the heads directly), "x_c" = (x2, its bf16 copy written by
         # the last block's MLP kernel), "bias_wgg" = blocks whose dense_1 bias gradient comes from the grouped
@@ -423,7 +440,11 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = fctx.saved
-        dx2 = dx2.contiguous()
+        r16 = ctx.res_grad is not None      # the residual gradient arrives in bf16 through the context (RES_GRAD_BF16)
+        if r16:
+            dx2, ctx.res_grad = ctx.res_grad, None
+        else:
+            dx2 = dx2.contiguous()
         sk = ops.wgrad_splitk
         # ---- MLP: x2 = x1 + drop(h W2 + b2)
         d_o2 = ctx.handoff.pop(i, None)   # produced by the LN1 backward of block i+1 (fused)
@@ -504,6 +525,10 @@ class BlockFn(torch.autograd.Function):
                                         drop=(st.grad(pp + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * (i - 1) + 2,
                                               ctx.step_ptr), jobs=ctx.ln_jobs)
             ctx.handoff[i - 1] = nxt
+        elif r16:      # block 0: dx IS the compute-dtype gradient the encoder's weight-gradient products read
+            dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
+                                   st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), jobs=ctx.ln_jobs)
+            ctx.dh_c = dx
         else:
             if cdt == torch.bfloat16:
                 # block 0: the fused consumer at rate 0 is a plain compute-dtype copy of dx -- what the
@@ -517,6 +542,10 @@ class BlockFn(torch.autograd.Function):
                                        st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), jobs=ctx.ln_jobs)
         ctx.join_held()
         fctx.saved = None
+        if r16:
+            if i > 0:
+                ctx.res_grad = dx
+            return ctx.store.scratch("grad_placeholder", (1,), x.dtype).expand(x.shape), None, None
         return dx, None, None
 
 
@@ -629,10 +658,12 @@ class DecoderLossFn(torch.autograd.Function):
             first = L.head_order[0]
             dl = st.scratch("dlogits", (ctx.T, L.Upad), ctx.cdt)
             drop = _heads_drop(ctx)
+            r16 = drop is not None and fctx.needs_input_grad[0] and _res16_ok(ctx)
             part, dl, logits, dx, dxd = ops.heads_loss_fused(
                 h_c, st.cw("decoder/decoder_%s/kernel" % first, rows=L.Upad),
                 st.span(st.w, "decoder/decoder_%s/bias" % first, L.Upad), keys, ctx.nvalid, ctx.B, ctx.S, dlogits=dl,
-                want_logits=ctx.tail.get("want_logits", True), drop=drop)
+                want_logits=ctx.tail.get("want_logits", True), drop=drop,
+                dx_dtype=torch.bfloat16 if r16 else torch.float32)
             n3 = 3 * len(keys)
             flat = ctx.tail["sums"]
             if flat is not None and flat.numel() == n3 + 1:
@@ -651,6 +682,7 @@ class DecoderLossFn(torch.autograd.Function):
             if logits is None:
                 logits = h_c.new_empty((0, L.Upad), dtype=torch.float32)
             fctx.ctx, fctx.saved = ctx, (h_c, dl, dx, dxd)
+            fctx.hshape = (h.shape, h.dtype)
             fctx.mark_non_differentiable(sums, logits)
             return loss, sums, logits
         logits = _heads_fwd(ctx, h_c)
@@ -686,6 +718,9 @@ class DecoderLossFn(torch.autograd.Function):
                 ctx.handoff[last] = dxd
                 ctx.tail["bias_wgg"].add(last)
             fctx.saved = None
+            if dh.dtype == torch.bfloat16:      # RES_GRAD_BF16: the gradient goes down in StepCtx, autograd gets a placeholder
+                ctx.res_grad = dh
+                return ctx.store.scratch("grad_placeholder", (1,), fctx.hshape[1]).expand(fctx.hshape[0]), None, None
             return dh, None, None
         h_c, dl = fctx.saved
         dh = _heads_bwd(ctx, dl, h_c)

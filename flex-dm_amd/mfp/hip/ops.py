@@ -455,17 +455,20 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma
     backward pass (:func:`reduce_partials_batch`)."""
     lib = load()
     T, D = x.shape
+    # the residual gradient stream (dres in, dx out) is f32, or bf16 when the caller carries it in bf16 (res16)
+    res16 = (dres is not None and dres.dtype == torch.bfloat16) or (dx is not None and dx.dtype == torch.bfloat16)
     if dx is None:
-        dx = torch.empty((T, D), dtype=torch.float32, device=x.device)
+        dx = torch.empty((T, D), dtype=torch.bfloat16 if res16 else torch.float32, device=x.device)
+    assert dres is None or dres.dtype == dx.dtype
     ddrop = torch.empty((T, D), dtype=dy.dtype, device=x.device) if drop is not None else None
     colsum, p_, seed_, off_, sp_ = drop if drop is not None else (None, 0.0, 0, 0, None)
     nbytes = lib.mfp_layernorm_bwd_workspace_bytes(T, D)
     # deferred reduction: the partials must outlive this call -> their own buffer, not the shared one
     own_ws = defer is not None or jobs is not None
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if own_ws else workspace(nbytes, x.device)
-    nb = T * D * (_esz(dy) + 4 + (4 if dres is not None else 0) + 4 + (_esz(dy) if drop is not None else 0))
+    nb = T * D * (_esz(dy) + 4 + (_esz(dx) if dres is not None else 0) + _esz(dx) + (_esz(dy) if drop is not None else 0))
     with _timed("ln_bwd_kernel", 0, nb):
-        check(lib.mfp_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
+        check((lib.mfp_layernorm_bwd_res16 if res16 else lib.mfp_layernorm_bwd)(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
                                     _ptr(dx), _ptr(None if own_ws else dgamma),
                                     _ptr(None if own_ws else dbeta), ws.data_ptr(), ws.numel(), T, D,
                                     dt_code(dy.dtype), _ptr(ddrop), _ptr(colsum), float(p_), int(seed_), int(off_),
@@ -645,7 +648,7 @@ def heads_loss_fused_ok(keys: Sequence[dict], U: int, D: int) -> bool:
 
 def heads_loss_fused(x_c: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tensor,
                      B: int, S: int, dlogits: Optional[torch.Tensor] = None, want_logits: bool = True,
-                     drop: Optional[tuple] = None):
+                     drop: Optional[tuple] = None, dx_dtype: torch.dtype = torch.float32):
     """Heads forward + LossLayer + heads input gradient in ONE launch (see mfp_heads_loss_fwd_bwd).  x_c bf16 [B*S,256],
     W bf16 [U,256], bias f32 [U].  Returns (part [P,48] per-workgroup partial sums, dlogits bf16 [T,U], logits f32 [T,U] or
     None, dx f32 [T,256], dx_drop bf16 [T,256] or None); ``drop`` = (p, seed, offset, step_ptr) as in :func:`dgrad_rows`.
@@ -660,13 +663,14 @@ def heads_loss_fused(x_c: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, key
     if dlogits is None:
         dlogits = torch.empty((T, U), dtype=torch.bfloat16, device=dev)
     logits = torch.empty((T, U), dtype=torch.float32, device=dev) if want_logits else None
-    dx = torch.empty((T, D), dtype=torch.float32, device=dev)
+    dx = torch.empty((T, D), dtype=dx_dtype, device=dev)      # f32, or bf16 for a step that carries residual gradients in bf16
     dxd = torch.empty((T, D), dtype=torch.bfloat16, device=dev) if drop is not None else None
     p_, seed_, off_, sp_ = drop if drop is not None else (0.0, 0, 0, None)
-    nb = T * (D * 2 + U * 2 + D * 4 + (D * 2 if drop is not None else 0) + (U * 4 if want_logits else 0)) + U * D * 2
+    nb = T * (D * 2 + U * 2 + D * _esz(dx) + (D * 2 if drop is not None else 0) + (U * 4 if want_logits else 0)) + U * D * 2
     with _timed("heads_loss_kernel", 2 * 2 * T * U * D, nb):
         check(lib.mfp_heads_loss_fwd_bwd(_ptr(x_c), _ptr(W), _ptr(bias), U, arr, len(keys), _ptr(nvalid), _ptr(part),
-                                         _ptr(dlogits), _ptr(logits), _ptr(dx), _ptr(dxd), B, S, D, float(p_), int(seed_),
+                                         _ptr(dlogits), _ptr(logits), _ptr(dx) if dx_dtype == torch.float32 else None,
+                                         _ptr(dx) if dx_dtype == torch.bfloat16 else None, _ptr(dxd), B, S, D, float(p_), int(seed_),
                                          int(off_), _ptr(sp_), _stream()), "mfp_heads_loss_fwd_bwd")
     return part, dlogits, logits, dx, dxd
 

@@ -242,6 +242,13 @@ int mfp_layernorm_bwd(const void* dy, const float* x, const float* gamma, const 
                       float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
                       int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
+/* The same with the residual gradient stream (dres in, dx out) in bf16 [T,D] instead of f32: the bf16 train step carries
+ * the gradient of the residual stream in the compute dtype (1 KB per element and LayerNorm less HBM traffic). */
+int mfp_layernorm_bwd_res16(const void* dy, const float* x, const float* gamma, const float* mean,
+                            const float* rstd, const void* dres, void* dx, float* dgamma,
+                            float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
+                            int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
+                            uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D);
 /* dgamma == dbeta == NULL: mfp_layernorm_bwd leaves the per-workgroup partials
  * [P = ceil(T/32)][3][D] (dgamma | dbeta | colsum(ddrop)) in `workspace` and the caller sums them
@@ -349,14 +356,15 @@ int mfp_loss_fwd_bwd_acc(const float* logits, void* dlogits, int32_t ld, const m
  *   logits = x W^T + bias (x bf16 [B*S,256], W bf16 [U][256], bias f32 [U]; U % 8 == 0, U <= 1536), per key the losses
  *   of mfp_loss_fwd_bwd (same mfp_loss_key array; categorical items on 8-column boundaries and <= 64 classes, numerical
  *   widths % 8 == 0), dlogits bf16 [B*S,U] (what the heads' weight gradient multiplies), dx = dlogits W f32 [B*S,256]
- *   and, when dx_drop != NULL, its dropout-masked 1/keep-scaled bf16 copy (keying of mfp_dgrad_rows).
+ *   (dx and / or its plain bf16 copy dx_bf16: at least one) and, when dx_drop != NULL, its dropout-masked 1/keep-scaled
+ *   bf16 copy (keying of mfp_dgrad_rows).
  * logits f32 [B*S,U] is written only when non-NULL.  The per-key sums leave as per-workgroup partials:
  * part f32 [mfp_heads_loss_partials(B*S)][48], entry [w][3 k + {0,1,2}] = {loss / B, score, count} of key k; reduce with
  * mfp_reduce_partials(part, sums, ..., P = partials, N = 3 * nkeys, pstride = 48).  No position-sorted variant. */
 size_t mfp_heads_loss_partials(int32_t T);
 int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys /*host*/,
                            int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits, float* dx,
-                           void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed,
+                           void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed,
                            uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
 /* sort_inputs (reference models/tensor_utils.py:14-44) as a row map.  Per document b with flag[b]:

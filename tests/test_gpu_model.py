@@ -557,6 +557,47 @@ def test_grouped_wgrad_equals_per_product_path():
         assert err <= tol * scale + 1e-7, (name, err, scale)
 
 
+def test_bf16_residual_gradient_stream_vs_f32():
+    """bf16 train step: the gradient of the residual stream carried in bf16 between the LayerNorm backward kernels
+    (MFP_RES_GRAD_BF16, mfp_layernorm_bwd_res16; autograd sees placeholders) against the same step with the f32 stream --
+    same batch, masks and dropout streams.  The f32 stream's own distance to the oracle is what the budgets of
+    test_timed_shape_parity_vs_oracle hold; here: every parameter gradient within a few bf16 roundings of that, cosine
+    practically 1, and no NaN-poisoned buffer left unwritten."""
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.hip import functions
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    B, S = 64, 128
+    batch = synthetic_batch(ic, B, S, seed=3, ragged=True, device=DEV)
+    grads = []
+    old = functions.RES_GRAD_BF16
+    try:
+        for r16 in (False, True):
+            functions.RES_GRAD_BF16 = r16
+            model = MFP(ic, num_blocks=4, latent_dim=256, dropout=0.1, l2=1e-2, masking_method="random",
+                        dtype="bf16", device=DEV)
+            model.compile(learning_rate=1e-3)
+            model.model.store.g.fill_(float("nan"))
+            sums = model._forward_backward(batch)
+            torch.cuda.synchronize()
+            grads.append((model.model.store.grads_state_dict(), sums.clone()))
+    finally:
+        functions.RES_GRAD_BF16 = old
+    (g0, s0), (g1, s1) = grads
+    assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-5)          # the forward pass is the same
+    worst_cos, worst_rel = 1.0, 0.0
+    for name, a in g0.items():
+        b = g1[name]
+        assert torch.isfinite(b).all(), name
+        if name.endswith("attn/dense_key/bias"):
+            continue        # exactly zero in exact arithmetic (a constant added to every key's score): rounding noise only
+        a64, b64 = a.double().flatten(), b.double().flatten()
+        if a64.norm() > 0:
+            worst_cos = min(worst_cos, float((a64 @ b64) / (a64.norm() * b64.norm() + 1e-300)))
+            worst_rel = max(worst_rel, float((a64 - b64).norm() / a64.norm()))
+    assert worst_cos > 0.9995 and worst_rel < 3e-2, (worst_cos, worst_rel)
+
+
 # ------------------------------------------------------------------ BASELINE config c5 shape (D=512, 8 blocks, S=256)
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_c5_shape_parity_vs_oracle(dtype):
