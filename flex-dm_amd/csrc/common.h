@@ -62,15 +62,26 @@ template <> struct cdt_traits<unsigned short> {
 };
 
 // ----------------------------------------------------------------------------- wave reductions
+// All-reduce over the 64 lanes: four DPP steps inside each 16-lane row (quad xor 1, quad xor 2, half-row mirror, row
+// mirror), then the four row results through scalar registers.  (`__shfl_xor` is a ds_bpermute round trip of ~100+ clocks:
+// a chain of six per sum was what a LayerNorm-backward row spent most of its time in.)
+template <int CTRL>
+__device__ __forceinline__ float mfp_dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += mfp_dpp_f<0xB1>(v); v += mfp_dpp_f<0x4E>(v); v += mfp_dpp_f<0x141>(v); v += mfp_dpp_f<0x140>(v);
+  const int vi = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, mfp_dpp_f<0xB1>(v)); v = fmaxf(v, mfp_dpp_f<0x4E>(v)); v = fmaxf(v, mfp_dpp_f<0x141>(v)); v = fmaxf(v, mfp_dpp_f<0x140>(v));
+  const int vi = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // ----------------------------------------------------------------------------- per-device caches
