@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+#ifndef LN_BWD_DEPTH
+#define LN_BWD_DEPTH 2
+#endif
 constexpr int LN_BWD_ROWS = 32;  // rows per workgroup (4 waves x 8 rows); 64 and 16 measured 6-15 % slower
 
 // Optional fused consumer: the LN-backward output dx is, in the DeepSVG block, immediately fed to
@@ -199,17 +202,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
       }
     }
   };
-  // two named buffers, rows handled in pairs: no copies between the in-flight and the current row
-  RowIn bufA, bufB;
+  // LN_BWD_DEPTH rows in flight per wave (statically indexed buffers: the 8-row walk of a wave is fully unrolled)
+  constexpr int DEPTH = LN_BWD_DEPTH, PER_WAVE = LN_BWD_ROWS / 4;
+  RowIn buf[DEPTH];
   const int rlast = min(LN_BWD_ROWS, T - row0);     // rows of this workgroup
-  if (wave < rlast) load_row(row0 + wave, bufA);
-  for (int rr = wave; rr < rlast; rr += 8) {
-    const bool hasB = rr + 4 < rlast;
-    if (hasB) load_row(row0 + rr + 4, bufB);
-    process(bufA, row0 + rr);
-    if (hasB) {
-      if (rr + 8 < rlast) load_row(row0 + rr + 8, bufA);
-      process(bufB, row0 + rr + 4);
+#pragma unroll
+  for (int k = 0; k < DEPTH; ++k)
+    if (wave + 4 * k < rlast) load_row(row0 + wave + 4 * k, buf[k]);
+#pragma unroll
+  for (int k = 0; k < PER_WAVE; ++k) {
+    const int rr = wave + 4 * k;
+    if (rr < rlast) {
+      process(buf[k % DEPTH], row0 + rr);
+      if (k + DEPTH < PER_WAVE && rr + 4 * DEPTH < rlast) load_row(row0 + rr + 4 * DEPTH, buf[k % DEPTH]);
     }
   }
   // cross-wave reduction of the dgamma/dbeta(/colsum) partials
