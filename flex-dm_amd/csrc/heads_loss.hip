@@ -23,7 +23,8 @@
 //      (ds_read_b64_tr_b16; row swizzle ((row & 7) << 1 | (row >> 3) & 1 keeps both read patterns conflict-free).
 // Per-key sums leave as per-workgroup partials (no global atomics): the caller reduces them (mfp_reduce_partials).
 // Every iteration issues the same vector-memory operations (out-of-range offsets / zero-sized buffers where a chunk has
-// nothing to load or store), so "chunk c has landed" is s_waitcnt vmcnt(24) in every iteration.
+// nothing to load or store), so "chunk c has landed" is s_waitcnt vmcnt(24) in every iteration (16 in the variant
+// that does not write the logits).
 #include "common.h"
 #ifndef HL_ABL
 #define HL_ABL 0
@@ -96,6 +97,7 @@ __device__ __forceinline__ int row16_min(int v) {
 __device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int dsw(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
 
+template <bool LOGITS>      // LOGITS: the f32 logits are written (4 more stores per thread and chunk in the counted schedule)
 __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Ws = smem;
@@ -230,8 +232,9 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   tload(0, tg);
 
   for (int c = 0; c < nch; ++c) {
-    // chunk c has landed: younger than its four loads are the 10 other operations of iteration c - 2 and the 14 of c - 1
-    asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    // chunk c has landed: younger than its four loads are the 10 (6) other operations of iteration c - 2 and the 14 (10) of c - 1
+    if (LOGITS) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                    // B1
     HL_TR(4 * c);
     // (opaque copies per iteration: loop-invariant address arithmetic is not hoisted out of the loop and kept in registers)
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         for (int rt = 0; rt < 2; ++rt) {
           acc[nt][rt] += bb;
           const int row = rp * 32 + rt * 16 + li_c;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt][rt]), rs_lg,
+          if (LOGITS) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt][rt]), rs_lg,
                                                  cc < ncols ? (unsigned int)(row0 + row) * ldb4 + (unsigned int)(col0 + cc) * 4u : OOB, 0, 0);   // 4 stores
         }
       }
@@ -584,14 +587,16 @@ extern "C" int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float*
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
     if (e != hipSuccess) {
       mfp_set_error("mfp_heads_loss_fwd_bwd: cannot raise dynamic LDS to %d: %s", HL_LDS, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(heads_loss_kernel, dim3((p.T + HL_ROWS - 1) / HL_ROWS), dim3(512), HL_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  if (logits != nullptr) hipLaunchKernelGGL(heads_loss_kernel<true>, dim3((p.T + HL_ROWS - 1) / HL_ROWS), dim3(512), HL_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(heads_loss_kernel<false>, dim3((p.T + HL_ROWS - 1) / HL_ROWS), dim3(512), HL_LDS, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
