@@ -196,12 +196,12 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(bf16x8, r);   // four v_cvt_pk_bf16_f32
 }
 __device__ __forceinline__ float xlane_max4(float v) {  // across the 4 lane groups (same li)
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  v = fmaxf(v, lane_xor16(v));
+  return fmaxf(v, lane_xor32(v));
 }
 __device__ __forceinline__ float xlane_sum4(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  v += lane_xor16(v);
+  return v + lane_xor32(v);
 }
 
 // Stage the head slice of `nmat` matrices (each [S][HD] inside rows of `stride` elements) into

@@ -186,16 +186,16 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     }
     __syncthreads();      // gamma / beta are in LDS
     AB_TR(1);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s += lane_xor16(s);
+    s += lane_xor32(s);
     const float mu = s * (1.0f / AB_D);
     float qq = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[ks][e] -= mu; qq += v[ks][e] * v[ks][e]; }
-    qq += __shfl_xor(qq, 16, 64);
-    qq += __shfl_xor(qq, 32, 64);
+    qq += lane_xor16(qq);
+    qq += lane_xor32(qq);
     const float rs = rsqrtf(qq * (1.0f / AB_D) + p.eps);
     if (g == 0) { p.mean[row] = mu; p.rstd[row] = rs; }
 #pragma unroll
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fmaf(sa[r], c2, mb4[r]));
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = fmaxf(m, lane_xor16(m));
+        m = fmaxf(m, lane_xor32(m));
         float l = 0.f;
         f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
             oo[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, bp, oo[dt], 0, 0, 0);
           }
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l += lane_xor16(l);
+        l += lane_xor32(l);
         const float inv = 1.f / l;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -472,8 +472,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
             const float d = pass == 0 ? acc2[ct][rt][r] : acc2[ct][rt][r] - mu[rt];
             sacc += pass == 0 ? d : d * d;
           }
-        sacc += __shfl_xor(sacc, 16, 64);
-        sacc += __shfl_xor(sacc, 32, 64);
+        sacc += lane_xor16(sacc);
+        sacc += lane_xor32(sacc);
         if (g_m == 0) St[nh * 128 + rp * 32 + rt * 16 + li_m] = sacc;
       }
       __syncthreads();

@@ -160,16 +160,16 @@ __global__ __launch_bounds__(512) void mlp_fused_kernel(MlpParams p) {
       for (int e = 0; e < 4; ++e) { v[ks][e] = a[e]; v[ks][4 + e] = b[e]; s += a[e] + b[e]; }
     }
     __syncthreads();      // gamma / beta are in LDS
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s += lane_xor16(s);
+    s += lane_xor32(s);
     const float mu = s * (1.0f / MLP_D);
     float qq = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[ks][e] -= mu; qq += v[ks][e] * v[ks][e]; }
-    qq += __shfl_xor(qq, 16, 64);
-    qq += __shfl_xor(qq, 32, 64);
+    qq += lane_xor16(qq);
+    qq += lane_xor32(qq);
     const float rs = rsqrtf(qq * (1.0f / MLP_D) + p.eps);
     if (g == 0 && rok) { p.mean[row] = mu; p.rstd[row] = rs; }
 #pragma unroll
@@ -418,16 +418,16 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(QkvParams p) {
       for (int e = 0; e < 4; ++e) { v[ks][e] = a[e]; v[ks][4 + e] = b[e]; s += a[e] + b[e]; }
     }
     __syncthreads();      // gamma / beta are in LDS
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s += lane_xor16(s);
+    s += lane_xor32(s);
     const float mu = s * (1.0f / MLP_D);
     float qq = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[ks][e] -= mu; qq += v[ks][e] * v[ks][e]; }
-    qq += __shfl_xor(qq, 16, 64);
-    qq += __shfl_xor(qq, 32, 64);
+    qq += lane_xor16(qq);
+    qq += lane_xor32(qq);
     const float rs = rsqrtf(qq * (1.0f / MLP_D) + p.eps);
     if (g == 0 && rok) { p.mean[row] = mu; p.rstd[row] = rs; }
 #pragma unroll

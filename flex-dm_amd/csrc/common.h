@@ -84,6 +84,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// The value of the lane 16 / 32 lanes away (lane ^ 16, lane ^ 32) by a row / half-wave swap on the VALU
+// (v_permlane16_swap / v_permlane32_swap, gfx950) instead of a ds_bpermute round trip through the LDS crossbar.
+__device__ __forceinline__ float lane_xor16(float v) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // r[0] = rows {0,0,2,2}, r[1] = rows {1,1,3,3}
+  const unsigned int mine_odd = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 4) & 1u;
+  return __builtin_bit_cast(float, mine_odd ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // r[0] = halves {lo, lo}, r[1] = halves {hi, hi}
+  const unsigned int mine_hi = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 5) & 1u;
+  return __builtin_bit_cast(float, mine_hi ? r[0] : r[1]);
+}
+
 // ----------------------------------------------------------------------------- per-device caches
 // hipFuncSetAttribute and the CU count are properties of (function, device): a process that drives
 // several devices must not reuse what it learnt on the first one.  Host-side caches are indexed by

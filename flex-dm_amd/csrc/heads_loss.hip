@@ -407,8 +407,8 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            ms[rt][q] += __shfl_xor(ms[rt][q], 16, 64);
-            ms[rt][q] += __shfl_xor(ms[rt][q], 32, 64);
+            ms[rt][q] += lane_xor16(ms[rt][q]);
+            ms[rt][q] += lane_xor32(ms[rt][q]);
           }
         if (nh == 1 && g_c == 0) {
 #pragma unroll
