@@ -629,6 +629,35 @@ def test_layernorm_bwd_deferred_partials():
         assert torch.equal(a, b)
 
 
+def test_layernorm_bwd_res16():
+    """mfp_layernorm_bwd_res16 (residual gradient stream in bf16: dres read and dx written as bf16) against
+    mfp_layernorm_bwd on the same bf16-valued residual: dx equal to bf16 rounding, the masked copy, the parameter-gradient
+    and bias-gradient sums identical (they are formed from the f32 values before the store)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(22)
+    T, D = 1000, 256
+    x = torch.randn(T, D, generator=g).to(DEV)
+    gamma, beta = (torch.rand(D, generator=g) + 0.5).to(DEV), torch.randn(D, generator=g).to(DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, torch.bfloat16)
+    dy = torch.randn(T, D, generator=g).to(DEV, torch.bfloat16)
+    dres16 = torch.randn(T, D, generator=g).to(DEV, torch.bfloat16)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    outs = []
+    for dres in (dres16.float(), dres16):
+        dg, db, cs = torch.empty(D, device=DEV), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+        dx, dd = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dg, db, drop=(cs, 0.1, 7, 3, step))
+        outs.append((dx, dd, dg, db, cs))
+    (dx32, dd32, dg32, db32, cs32), (dx16, dd16, dg16, db16, cs16) = outs
+    assert dx16.dtype == torch.bfloat16 and dx32.dtype == torch.float32
+    assert torch.equal(dx16, dx32.to(torch.bfloat16))
+    assert torch.equal(dd16, dd32) and torch.equal(dg16, dg32) and torch.equal(db16, db32) and torch.equal(cs16, cs32)
+    # no residual: the plain bf16 output
+    dxn = ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, torch.empty(D, device=DEV), torch.empty(D, device=DEV),
+                            dx=torch.empty(T, D, dtype=torch.bfloat16, device=DEV))
+    dxf = ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, torch.empty(D, device=DEV), torch.empty(D, device=DEV))
+    assert torch.equal(dxn, dxf.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("M,N,T,sk", [(256, 512, 4096, 8), (344, 256, 4096, 16), (1384, 256, 2048, 8), (136, 72, 1100, 8)])
 def test_gemm_streaming_wgrad(M, N, T, sk):
     """gemm_wg_kernel (bf16, splitk % 8 == 0): C = A^T B over the token dimension with ragged last
