@@ -19,15 +19,28 @@ N grows = weak scaling):
   c5  Crello Ours-EXP-FT shape: d_model 512, 8 blocks, seq_len 256, 64 documents/GPU, "fp8": bf16 with
       e4m3 QKV / FFN1 forward products (per-tensor scales, v_mfma_f32_16x16x32_fp8_fp8)
 
+Timed region: K hipGraph replays of the captured step between two device synchronisations (+ barriers for N > 1);
+`value` = elements of all ranks / that wall time; `ms_per_step_median` = median of the per-step HIP-event intervals of
+the same loop (SURVEY.md section 8d asks for the median; the two agree within the run-to-run jitter).  The loop ROTATES
+`--resident` (default 4) input batches that sit in HBM, each with its own capture of the same step: 4 x 136 MB of f32
+embeddings do not fit the 256 MB infinity cache, so every step's inputs are read from HBM like a loader-fed run's
+(`input_residency` on the line; `--resident 1` = the single re-masked batch of rounds 1-3).
+
 Extra objects on the line (prompt section 4):
-  roofline     - the kernel FAMILY with the largest summed duration in a step, measured with HIP events
-                 on the launch stream in instrumented eager steps of the same workload: algorithmic
-                 bytes (and FLOPs) per launch / average launch duration against the HBM (and MFMA) roof;
-                 `traffic` = PMC HBM bytes per launch of the same family (profiles/r02_pmc_traffic.json,
-                 collected by tools/pmc_step.sh over this same command); `encoder_block` = all kernels
-                 of the DeepSVG blocks (forward, backward, weight gradients) summed -- the quantity
-                 north_star's MFMA-utilisation target is stated on; `step` = whole-step MFMA fraction
+  roofline     - the kernel FAMILY with the largest summed duration in a step.  Durations: the tracer's device times
+                 (torch.profiler = roctracer) of the step AS TIMED (hipGraph replay), reported raw
+                 (`avg_launch_us_traced`, `frac_traced`) and normalised so that the families sum to the timed step
+                 (`avg_launch_us`, `frac`: the tracer stretches kernels by a few percent); algorithmic bytes / FLOPs per
+                 launch: the library calls of instrumented eager steps of the same workload (ops._timed);
+                 `traffic` = PMC HBM bytes per launch of the same family (profiles/r04_pmc_traffic.json, collected by
+                 tools/pmc_step.sh over this same command; falls back to the newest profiles/r*_pmc_traffic.json);
+                 `encoder_block` = all kernels of the DeepSVG blocks (forward, backward, weight gradients) summed -- the
+                 quantity north_star's MFMA-utilisation target is stated on; `step` = whole-step MFMA fraction
                  (17 320 960 algorithmic FLOP per element at c2).
+  fused_path   - false when the configuration falls off the document-tile / activation-stationary kernels
+                 (d_model != 256 or seq_len != 128) onto the generic tile kernels.
+  dp           - N > 1: ranks seen by a real all-reduce on the nccl (= RCCL) backend, the gradient bucket plan
+                 (bytes per bucket, carrier dtype) and `params_in_sync` after the timed steps.
   cpu_baseline - the oracle's eager torch-CPU restatement of the same train step (kind "port"; the
                  TensorFlow reference cannot run here) on a bounded sample, host cores.
   bf16_loss_rel_dev - |loss(bf16 path) - loss(f32 path)| / loss(f32 path) on the first timed-size batch
@@ -55,7 +68,15 @@ CONFIGS = {
 }
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+def _pmc_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    return files[-1] if files else None
+
+
+PMC_FILE = _pmc_file()
 
 
 def train_flops_per_element(D, L, S, U, n_num):
@@ -80,6 +101,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--masking_method", default=None, help="override the configuration's task mix")
     ap.add_argument("--batch", type=int, default=None, help="documents per GPU (override)")
+    ap.add_argument("--resident", type=int, default=4, help="input batches resident in HBM that the timed loop rotates")
     return ap.parse_args()
 
 
@@ -139,7 +161,7 @@ def pmc_traffic(fam):
     file).  Bytes and launches come from the SAME file: one denominator.  None when not collected."""
     try:
         table = json.load(open(PMC_FILE))["kernels"]
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         return None, None
     tot, calls = 0.0, 0.0
     for k, v in table.items():
@@ -300,10 +322,17 @@ def main():
     dp.broadcast_parameters(model.model.store.w)
     model.model.store.refresh_shadow()
     graphed = not args.no_graph
+    nres = max(1, args.resident) if world == 1 else 1     # (the N > 1 step is several graphs per step: one buffer set)
+    batches = [batch]
     if graphed:
         try:
-            model.capture_train_step(batch, warmup=2)
+            model.capture_train_step(batch, warmup=2, resident=nres)
             batch = model.static_batch   # the graph's input buffers: inputs are already resident there
+            batches = list(getattr(model, "static_batches", [batch]))
+            for i, b in enumerate(batches[1:], 1):      # distinct documents in every resident buffer set
+                fresh = synthetic_batch(ic, B, S, seed=1000 * i + rank, ragged=False, device=device)
+                for k, v in fresh.items():
+                    b[k].copy_(v)
         except RuntimeError as e:   # a failed capture must not cost the whole run: step eagerly, say so
             if world == 1:
                 raise
@@ -322,16 +351,23 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        model.train_step(batch)
+    if not graphed:
+        batches = [batch]
+    for i in range(args.warmup):
+        model.train_step(batches[i % len(batches)])
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sums = model.train_step(batch)
+    marks[0].record()
+    for i in range(args.steps):
+        sums = model.train_step(batches[i % len(batches)])
+        marks[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,12 +375,17 @@ def main():
     metrics = model.metrics_dict(sums)
     assert metrics["loss"] == metrics["loss"] and abs(metrics["loss"]) < 1e9, "loss is not finite"
     in_sync = True
+    dp_info = None
     if world > 1:   # replicas must hold identical parameters after identical averaged updates
         w = model.model.store.w
         lo, hi = w.clone(), w.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(torch.equal(lo, hi)) and bool(torch.isfinite(w).all())
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                      # a real collective on the data-path backend: counts the ranks
+        dp_info = dp.describe_plan(model.model.layout, graphed)
+        dp_info.update({"backend": dist.get_backend(), "rccl_ranks": int(ones.item()), "world_size": dist.get_world_size()})
 
     value = world * B * S * args.steps / elapsed
     lay = model.model.layout
@@ -353,7 +394,8 @@ def main():
     out = {
         "metric": "elements_per_sec_train_step", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": median_ms,
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8 (e4m3 QKV/FFN1 forward products; bf16 elsewhere)"}[dtype],
         "data": "synthetic",
         "config": {"workload": "%s (%s) train step, masking_method=%s: d_model=%d, %d DeepSVG blocks, seq_len=%d, "
@@ -364,7 +406,13 @@ def main():
                    "params": lay.numel, "train_flop_per_element": fpe},
         "final_loss": metrics["loss"],
         "params_in_sync": in_sync,
+        "input_residency": ("%d batches resident in HBM, rotated (%.0f MB of inputs per batch: beyond the 256 MB infinity cache)"
+                            % (len(batches), sum(v.numel() * v.element_size() for v in batch.values()) / 1e6)
+                            if len(batches) > 1 else "one batch, re-masked every step (its inputs can sit in the infinity cache)"),
+        "fused_path": bool(dtype in ("bf16", "fp8") and D == 256 and S == 128),
     }
+    if dp_info is not None:
+        out["dp"] = dp_info
     out.update(extra)
 
     # ---------------- roofline of the dominant kernel family.  Durations: the tracer's device times of the step as
@@ -379,6 +427,7 @@ def main():
             except Exception as exc:   # measurement aid: never fail the bench line over it
                 print("bench.py: tracer unavailable (%s); event-timed eager durations" % exc, file=sys.stderr)
         model._graph = None
+        batch = batches[0]
         model.train_step(batch)
         torch.cuda.synchronize()
         ops.start_profile()
@@ -403,6 +452,7 @@ def main():
             # the replayed kernels run back to back: profiles/r03_step_dump.txt): normalised to the timed step.
             traced = sum(v[0] for v in replay.values())
             norm = min(1.0, out["ms_per_step"] * 1e3 / traced)
+            out["tracer_normalisation"] = norm
             blk[2] = sum(replay[k][0] * norm * 1e-3 * nprof * blk_ms.get(k, 0.0) / agg[k][3] for k in agg if agg[k][3] > 0)
             for k in agg:
                 agg[k][3] = replay[k][0] * norm * 1e-3 * nprof
@@ -424,6 +474,9 @@ def main():
             roof = {"bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": f_mfma, "hbm_frac": f_hbm}
         roof["algorithmic_bytes_per_launch"] = nbytes / cnt
+        if "tracer_normalisation" in out:      # the same fraction from the tracer's raw durations
+            roof["frac_traced"] = roof["frac"] * out["tracer_normalisation"]
+            roof["avg_launch_us_traced"] = 1e3 * ms / cnt / out["tracer_normalisation"]
         roof["launches_per_step"] = cnt / nprof
         traffic, pmc_calls = pmc_traffic(name) if args.config == "c2" and dtype == "bf16" else (None, None)
         roof["traffic"] = traffic

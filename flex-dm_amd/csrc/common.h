@@ -65,6 +65,9 @@ template <> struct cdt_traits<unsigned short> {
 // All-reduce over the 64 lanes: four DPP steps inside each 16-lane row (quad xor 1, quad xor 2, half-row mirror, row
 // mirror), then the four row results through scalar registers.  (`__shfl_xor` is a ds_bpermute round trip of ~100+ clocks:
 // a chain of six per sum was what a LayerNorm-backward row spent most of its time in.)
+// PRECONDITION (wave_sum, wave_max, lane_xor16, lane_xor32): all 64 lanes active and the call site convergent -- a DPP
+// step with an inactive source lane keeps the lane's own value (it would be counted twice) and readlane of an inactive
+// row returns stale data.  Every caller sits at wave-uniform control flow; row loops are bounded per wave, not per lane.
 template <int CTRL>
 __device__ __forceinline__ float mfp_dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));

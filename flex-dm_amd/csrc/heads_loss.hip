@@ -516,6 +516,10 @@ extern "C" int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float*
   MFP_CHECK_ARG(x && W && bias && keys && nvalid && part && dlogits && (dx || dx_bf16));
   MFP_CHECK_ARG(B > 0 && S > 0 && D == HL_D && U > 0 && U % 8 == 0 && U <= HL_MAXU && nkeys > 0 && nkeys <= MFP_MAX_LOSS_KEYS);
   MFP_CHECK_ARG((long long)B * S <= (1 << 20) && dropout_p >= 0.f && dropout_p < 1.f);
+  // the kernel addresses logits / dlogits / targets with 32-bit byte offsets and buffer sizes (num_records)
+  MFP_CHECK_ARG((long long)B * S * U * (logits != nullptr ? 4 : 2) < 0xFFFFFFF0ll);
+  for (int i = 0; i < nkeys; ++i)
+    MFP_CHECK_ARG(!keys[i].is_numerical || (long long)B * S * keys[i].n_class * 4 < 0xFFFFFFF0ll);
   MFP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)dlogits % 16) == 0 && ((uintptr_t)logits % 16) == 0 &&
                 ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dx_bf16 % 16) == 0 && ((uintptr_t)dx_drop % 16) == 0 && ((uintptr_t)bias % 16) == 0);
   HlParams p;

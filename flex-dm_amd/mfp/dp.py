@@ -82,6 +82,32 @@ def bucket_slices(offsets: List[int], numel: int) -> List[slice]:
     return out
 
 
+def describe_plan(layout, graphed: bool = True) -> dict:
+    """The gradient all-reduce plan of the step as it will run (bench.py prints it on the N > 1 line): buckets in
+    backward order with their bytes on the wire, the carrier dtype, and which part is exposed."""
+    mode = os.environ.get("MFP_DP_BUCKETS", "blocks")
+    carrier = "bf16" if os.environ.get("MFP_DP_GRAD_DTYPE", "f32") in ("bf16", "bfloat16") else "f32"
+    esize = 2 if carrier == "bf16" else 4
+    cuts = bucket_cut_blocks(layout.L, mode) if graphed else []
+    slices = bucket_slices([layout.block_offset(i) for i in cuts], layout.numel)
+    names = []
+    for k, sl in enumerate(slices):
+        if not cuts:
+            names.append("all parameters")
+        elif k == 0:
+            names.append("heads + block %d" % cuts[0] + ("..%d" % (layout.L - 1) if cuts[0] < layout.L - 1 else ""))
+        elif k == len(slices) - 1:
+            names.append("encoder + block 0" + ("..%d" % (cuts[-1] - 1) if cuts[-1] > 1 else ""))
+        else:
+            names.append("block %d" % cuts[k] + ("..%d" % (cuts[k - 1] - 1) if cuts[k - 1] - 1 > cuts[k] else ""))
+    return {"buckets": mode if graphed else "none (eager step: one all-reduce after the backward pass)",
+            "carrier": carrier,
+            "plan": [{"bucket": n, "params": sl.stop - sl.start, "bytes": (sl.stop - sl.start) * esize}
+                     for n, sl in zip(names, slices)],
+            "bytes_per_step": layout.numel * esize,
+            "exposed": "the last bucket's all-reduce + Adam" if cuts else "the whole all-reduce + Adam"}
+
+
 class BucketReducer:
     """Sum all-reduce of one gradient bucket, optionally carried as bf16 (MFP_DP_GRAD_DTYPE=bf16: half the xGMI bytes;
     every rank receives the same bf16 sums, so the replicas stay bit-identical; default f32).  ``launch`` is

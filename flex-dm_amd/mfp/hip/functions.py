@@ -652,7 +652,7 @@ class DecoderLossFn(torch.autograd.Function):
         ctx.tail["x_c"] = None
         st, L = ctx.store, ctx.store.layout
         if (HEADS_FUSED and ctx.cdt == torch.bfloat16 and ctx.loss_sort is None and MLP_FUSE
-                and ops.heads_loss_fused_ok(keys, L.Upad, L.D)):
+                and ops.heads_loss_fused_ok(keys, L.Upad, L.D, ctx.T, ctx.tail.get("want_logits", True))):
             # heads + losses + d(loss)/d(h) in ONE launch (csrc/heads_loss.hip): the f32 logits are written only when
             # somebody wants them, the per-key sums come back as per-workgroup partials
             first = L.head_order[0]

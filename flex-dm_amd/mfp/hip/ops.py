@@ -625,10 +625,13 @@ def _loss_key_array(keys: Sequence[dict]):
     return arr
 
 
-def heads_loss_fused_ok(keys: Sequence[dict], U: int, D: int) -> bool:
+def heads_loss_fused_ok(keys: Sequence[dict], U: int, D: int, T: int = 0, want_logits: bool = True) -> bool:
     """Shapes mfp_heads_loss_fwd_bwd takes: d_model 256, 8-aligned heads, categorical items of <= 64 classes on 8-column
-    boundaries, numerical widths % 8 == 0, at most 16 (key, feature) items and 40 column chunks."""
+    boundaries, numerical widths % 8 == 0, at most 16 (key, feature) items and 40 column chunks, and a token count whose
+    logits / d(logits) rows stay inside the kernel's 32-bit byte offsets (beyond: the four-launch path)."""
     if D != 256 or U % 8 != 0 or U > 1536 or len(keys) > 16:
+        return False
+    if T > (1 << 20) or T * U * (4 if want_logits else 2) >= 0xFFFFFFF0:
         return False
     items = chunks = 0
     for k in keys:

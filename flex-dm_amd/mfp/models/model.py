@@ -76,7 +76,9 @@ class Model:
 
     def forward_loss(self, inputs: Dict, loss_keys, training: bool = True, premasked=None, ctx=None,
                      loss_sort=None):
-        """Train-step path: heads + LossLayer fused.  Returns (loss_total, sums, outputs).
+        """Train-step path: heads + LossLayer fused.  Returns (loss_total, sums, outputs).  When ``ctx.tail["sums"]``
+        carries the step prologue's accumulator (MFP._forward) ``loss_total`` is a placeholder root and ``sums`` becomes
+        valid with the end-of-backward reduction (``ctx.flush_ln_jobs``); every other caller gets both at once.
         ``premasked`` = (idx_all, codes, xs) from the fused masking kernel replaces ``inputs``."""
         if premasked is not None:
             # the last block feeds the heads directly (no context token to strip): its MLP kernel writes the heads'

@@ -228,3 +228,96 @@ def test_bucketed_allreduce_equals_single_allreduce():
     assert np.array_equal(ref, f32)
     assert all(np.array_equal(gathered[0], t) for t in gathered)
     assert np.allclose(bf16, ref, rtol=2 ** -7, atol=1e-2)
+
+
+def _plan_worker(rank, world, port, q):
+    """Three data-parallel train steps of the oracle's model on a rank-local shard under three all-reduce plans."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "flex-dm_amd")]
+    from oracle import np_ref, torch_ref
+    from mfp import dp
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    assert dp.init_from_env("gloo") == world
+    ic = make_input_columns("rico")
+    B, S, D, L = 4, 6, 16, 2
+    params = np_ref.init_params(ic, D, L, seed=-7)
+    keys = [k for k, c in ic.items() if c.get("is_sequence")]
+    names = sorted(torch_ref.TrainState(params).p)
+    sizes = [int(np.prod(params[n].shape)) for n in names]
+    numel = sum(sizes)
+    result = {}
+    for plan, carrier in (("blocks", "f32"), ("none", "f32"), ("blocks", "bf16")):
+        state = torch_ref.TrainState(params, lr=1e-2, l2=1e-2, clipnorm=1.0, dtype=torch.float64)
+        cuts = [numel * 3 // 4, numel // 2, numel // 5] if plan == "blocks" else []      # descending, like the backward pass
+        for step in range(3):
+            batch = dp.shard_batch(synthetic_batch(ic, B, S, seed=20 + step, ragged=True))
+            g = torch.Generator().manual_seed(step)
+            masks = dp.shard_batch({k: torch.rand(B, S, generator=g) < 0.6 for k in keys})
+            loc = torch_ref.TrainState({k: v.detach().numpy() for k, v in state.p.items()}, l2=None, clipnorm=None, dtype=torch.float64)
+            _, grads = torch_ref.loss_and_grads(loc, ic, batch, batch, masks, L, maxlen=S)
+            flat = torch.cat([grads[n].reshape(-1) for n in names]).float()
+            red = dp.BucketReducer(carrier)
+            for sl in dp.bucket_slices(cuts, numel):
+                red.launch(flat[sl])
+            red.finish()
+            flat = flat.double() / world
+            avg, pos = {}, 0
+            for n, sz in zip(names, sizes):
+                avg[n] = flat[pos:pos + sz].reshape(state.p[n].shape) + 2.0 * state.l2 * state.p[n].detach() * (0.0 if n.split("/")[-1] in ("gamma", "beta") else 1.0)
+                pos += sz
+            torch_ref.apply_gradients(state, avg)
+        result[(plan, carrier)] = torch.cat([state.p[n].detach().reshape(-1) for n in names])
+    gathered = {}
+    for key, w in result.items():
+        parts = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(parts, w)
+        gathered[key] = [p.numpy() for p in parts]
+    if rank == 0:
+        w0 = torch.cat([torch.as_tensor(np.asarray(params[n], dtype=np.float64)).reshape(-1) for n in names]).numpy()
+        q.put((w0, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_plans_give_the_same_parameters_after_three_steps():
+    """the default plan (per-block buckets, f32), the MFP_DP_BUCKETS=none fallback (one all-reduce)
+    and the bf16 carrier (MFP_DP_GRAD_DTYPE=bf16) after 3 data-parallel steps: replicas bit-identical under every plan,
+    bucketed == single all-reduce bit for bit, and the bf16 carrier's parameters within bf16 rounding of the gradients
+    (the update direction agrees; Keras Adam's first steps are sign-like, so single entries may differ by ~lr)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    w0, gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for key, parts in gathered.items():
+        assert all(np.array_equal(parts[0], t) for t in parts), key            # replicas in sync
+    ref = gathered[("blocks", "f32")][0]
+    assert np.array_equal(ref, gathered[("none", "f32")][0])
+    b16 = gathered[("blocks", "bf16")][0]
+    d_ref, d_b16 = ref - w0, b16 - w0
+    cos = float(d_ref @ d_b16 / (np.linalg.norm(d_ref) * np.linalg.norm(d_b16)))
+    assert cos > 0.995, cos
+    assert np.abs(b16 - ref).max() <= 2 * 3 * 1e-2        # never further apart than the steps themselves
+
+
+def test_describe_plan_covers_every_parameter_once():
+    from mfp import dp
+    from mfp.data.spec import make_input_columns
+    from mfp.models.params import ModelLayout
+    lay = ModelLayout(make_input_columns("crello"), 256, 4)
+    for mode, nb in (("blocks", 4), ("halves", 2), ("none", 1)):
+        os.environ["MFP_DP_BUCKETS"] = mode
+        try:
+            plan = dp.describe_plan(lay)
+        finally:
+            os.environ.pop("MFP_DP_BUCKETS")
+        assert len(plan["plan"]) == nb and sum(b["params"] for b in plan["plan"]) == lay.numel
+        assert plan["bytes_per_step"] == 4 * lay.numel and plan["carrier"] == "f32"
+    assert dp.describe_plan(lay, graphed=False)["plan"][0]["params"] == lay.numel

@@ -417,6 +417,8 @@ BF16_LOSS_BUDGET = 1e-3  # north_star's bound, on the TOTAL loss; measured 4.7e-
 # Single keys: a key's loss is the mean of a few hundred masked fields at B = 4-5, and its bf16
 # deviation is dominated by a handful of near-tie logits; measured worst key 1.85e-3 (c2) / 2.42e-3 (c3), budget 3e-3
 BF16_KEY_BUDGET = 3e-3
+# cosine of the first Adam step (a sign pattern) of the bf16 replay with the f64 oracle's, significant variables
+ADAM_STEP_COS_BF16 = 0.9
 
 
 def _timed_shape_case(mix, B, S=128, D=256, L=4):
@@ -488,14 +490,63 @@ def _record(name, value):
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+class _route:
+    """Force a kernel route of mfp/hip/functions.py for the duration of a test.  The defaults pick by grid size
+    (one document per CU or not), so at oracle-sized batches the route bench.py times would never meet the oracle:
+    "timed" = what 256 documents per GPU run (attn_block_bwd_kernel, 128-row workgroups everywhere), "three" = the
+    attention half's input gradients as three launches with 128-row dgrad workgroups, "half" = three launches with
+    the half-size dgrad workgroups of c4's per-GPU shape (the default at B < #CUs)."""
+    ROUTES = {"timed": ("1", "0"), "three": ("0", "0"), "half": ("0", "1"), "default": ("", None)}
+
+    def __init__(self, name):
+        self.bwd, self.half = self.ROUTES[name]
+
+    def __enter__(self):
+        import os
+        from mfp.hip import functions
+        self.old = (functions.ATTN_BLOCK_BWD, os.environ.get("MFP_FUSED_HALF"))
+        functions.ATTN_BLOCK_BWD = self.bwd
+        if self.half is None:
+            os.environ.pop("MFP_FUSED_HALF", None)
+        else:
+            os.environ["MFP_FUSED_HALF"] = self.half
+
+    def __exit__(self, *exc):
+        import os
+        from mfp.hip import functions
+        functions.ATTN_BLOCK_BWD = self.old[0]
+        if self.old[1] is None:
+            os.environ.pop("MFP_FUSED_HALF", None)
+        else:
+            os.environ["MFP_FUSED_HALF"] = self.old[1]
+
+
+def _kernel_names(fn):
+    """Names (template arguments kept, parameter lists cut) of the device kernels ``fn`` launches, through the
+    HIP activity tracer behind torch.profiler."""
+    import re
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    names = []
+    for ev in prof.events():
+        if str(getattr(ev, "device_type", "")).endswith("CUDA") and not ev.name.startswith(("Memcpy", "Memset", "hip")):
+            n = re.sub(r"^void ", "", ev.name.replace("(anonymous namespace)::", ""))
+            names.append(re.sub(r"\(.*$", "", n))
+    return names
+
+
+@pytest.mark.parametrize("dtype,route", [("fp32", "default"), ("bf16", "default"), ("bf16", "timed"), ("bf16", "three")])
 @pytest.mark.parametrize("mix,B", [("c2", 4), ("c3", 5)])
-def test_timed_shape_parity_vs_oracle(dtype, mix, B):
+def test_timed_shape_parity_vs_oracle(dtype, route, mix, B):
     S, D, L = 128, 256, 4
     ic, params, batch, modified, masks, torch_ref, keys = _timed_shape_case(mix, B, S, D, L)
     state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S)
     model = _model(ic, params, D, L, dtype)
-    loss, sums, outputs = _run(model, ic, batch, modified, masks)
+    with _route(route):
+        loss, sums, outputs = _run(model, ic, batch, modified, masks)
     want = float(info["data_loss"])
     rel = abs(float(loss) - want) / want
     sums = sums.cpu().double()
@@ -506,7 +557,7 @@ def test_timed_shape_parity_vs_oracle(dtype, mix, B):
         assert abs(sums[i, 2].item() - float(info["scores"][k + "_score_den"])) < 1e-6, k      # counts: exact
     logit_err = max((outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item() for k in keys)
     worst_cos, excess = _bf16_grad_report(model.store.grads_state_dict(), grads)
-    _record("%s_%s" % (mix, dtype), dict(B=B, S=S, D=D, L=L, loss=float(loss), oracle_loss=want, loss_rel_dev=rel,
+    _record("%s_%s%s" % (mix, dtype, "" if route == "default" else "_" + route), dict(B=B, S=S, D=D, L=L, loss=float(loss), oracle_loss=want, loss_rel_dev=rel,
                                          worst_key_loss_rel_dev=max(key_rel.values()), max_logit_abs_err=logit_err,
                                          worst_grad_cosine=worst_cos, worst_grad_rms_err_over_budget=excess))
     print("timed shape %s %s: loss rel dev %.2e, worst key %.2e, logits %.2e, worst grad cos %.6f"
@@ -518,6 +569,137 @@ def test_timed_shape_parity_vs_oracle(dtype, mix, B):
         assert rel <= BF16_LOSS_BUDGET, rel
         assert max(key_rel.values()) <= BF16_KEY_BUDGET, key_rel
         assert worst_cos > 0.98 and excess <= 1.0, (worst_cos, excess)
+
+
+def _masker_output_as_oracle_inputs(model, ic, batch, dbatch, B, S):
+    """What the fused masking kernel draws at the model's CURRENT step counter, in the reference's
+    (modified_inputs, masks) form: the draws are inferred from the kernel's output and replayed through the oracle's
+    preprocess_for_train, which must reproduce masks and tokens bit for bit (tests/test_gpu_callers.py does the same
+    for every task type)."""
+    from oracle import np_masking as om
+    from test_gpu_callers import _infer_draws
+    nd = {k: v for k, v in ic.items() if not v.get("demo_only")}
+    lay = model.model.layout
+    tasks = np.zeros(B, np.int32)
+    ctx = model.model.make_ctx(dbatch, True)
+    idx_all, codes, xs, masks = model._masker(dbatch, torch.from_numpy(tasks).to(DEV), ctx.nvalid, B, S, model.model.step_ptr)
+    torch.cuda.synchronize()
+    got_x, pos = {}, 0
+    for k in lay.cat_keys:
+        n = lay.columns[k]["shape"][-1]
+        got_x[k] = idx_all[:, pos:pos + n].reshape(B, S, n).cpu().numpy()
+        pos += n
+    for j, k in enumerate(lay.num_keys):
+        got_x[k] = xs[j].reshape(B, S, -1).float().cpu().numpy()
+    got_m = {k: v.bool().cpu().numpy() for k, v in masks.items()}
+    nb = {k: v.numpy() for k, v in batch.items()}
+    seq_mask = om.get_seq_mask(nb["length"], S)
+    filtered = om.filter_padding(nb, nd, seq_mask)
+    # numerical rows reach the kernel's output rounded to bf16; the oracle gets the unrounded rows wherever the kernel
+    # left them alone (the rounding is part of the bf16 path's deviation, not of the masking)
+    for k in lay.num_keys:
+        same = (got_x[k] == torch.from_numpy(filtered[k]).bfloat16().float().numpy()).all(-1, keepdims=True)
+        got_x[k] = np.where(same, filtered[k], got_x[k])
+    draws = _infer_draws(nd, filtered, got_x, got_m, tasks == 0)
+    _, want_x, want_m = om.preprocess_for_train(nb, nd, tasks, draws, None, maxlen=S)
+    for k, c in nd.items():
+        if c["is_sequence"]:
+            assert np.array_equal(got_m[k], want_m[k]) and np.array_equal(got_x[k], want_x[k]), k
+    want_x.pop("task")
+    modified = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in want_x.items()}
+    modified["length"] = batch["length"]
+    return modified, {k: torch.from_numpy(v) for k, v in want_m.items() if nd[k]["is_sequence"]}
+
+
+def test_train_step_timed_route_vs_oracle():
+    """The step bench.py times, as it is timed -- ``MFP.train_step`` replaying the captured hipGraph in bf16 on the route
+    256 documents per GPU take: fused masking, one-launch block forward, ``heads_loss_kernel<false>`` (no logits), the
+    per-key sums riding the end-of-backward reduction, the hand-off of the last block's masked gradient, ``mlp_bwd``,
+    ``attn_block_bwd_kernel``, grouped weight gradients, clipnorm + L2 + Keras Adam -- for ONE step against the f64
+    oracle's train step (oracle/torch_ref.py: loss_and_grads + apply_gradients; reference mfp.py:298-340,
+    metrics.py:213-299, train.py:71-77) on the very masks the step drew (dropout 0: TF's stream cannot be replayed).
+    Also pins the SET of kernels of that step to the committed list the profiles were taken on."""
+    import os
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.metrics import loss_key_names
+    from mfp.models.mfp import MFP
+    S, D, L, B, lr, l2 = 128, 256, 4, 6, 1e-3, 1e-2
+    ic = make_input_columns("crello")
+    keys = loss_key_names(ic)
+    params = np_ref.init_params(ic, D, L, seed=-11)
+    batch = synthetic_batch(ic, B, S, seed=31, ragged=True)
+    dbatch = {k: v.to(DEV) for k, v in batch.items()}
+    with _route("timed"):
+        model = MFP(ic, num_blocks=L, latent_dim=D, dropout=0.0, l2=l2, masking_method="random", dtype="bf16",
+                    device=DEV, seed=5)
+        model.compile(learning_rate=lr)
+        eager_names = _kernel_names(lambda: model.train_step(dbatch))
+        model.capture_train_step(dbatch, warmup=1)
+        # rewind to the oracle's starting point: its weights, empty Adam slots, step counter 0
+        store, opt = model.model.store, model.optimizer
+        store.load_state_dict(params)
+        opt.m.zero_(), opt.v.zero_(), opt.step_t.zero_()
+        modified, masks = _masker_output_as_oracle_inputs(model, ic, batch, dbatch, B, S)
+        before = store.state_dict()
+        sums = model.train_step(dbatch)          # ONE replay
+        torch.cuda.synchronize()
+        assert int(opt.step_t.item()) == 1
+        sums = sums.cpu().double()
+        after = store.state_dict()
+        grads_got = store.grads_state_dict()
+    # ---- the oracle's step
+    state = torch_ref.TrainState(params, lr=lr, l2=l2, clipnorm=1.0, dtype=torch.float64)
+    cast = lambda d: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+    info, grads = torch_ref.loss_and_grads(state, ic, cast(batch), cast(modified), masks, L, maxlen=S)
+    w_before = {k: v.detach().clone() for k, v in state.p.items()}
+    torch_ref.apply_gradients(state, grads)
+    want = float(info["data_loss"])
+    rel = abs(float(sums[:, 0].sum()) - want) / want
+    key_rel = {}
+    for i, k in enumerate(keys):
+        w = float(info["losses"][k])
+        key_rel[k] = abs(sums[i, 0].item() - w) / max(abs(w), 1e-3 * want)
+        assert abs(sums[i, 2].item() - float(info["scores"][k + "_score_den"])) < 1e-6, k      # counts: exact
+        assert abs(sums[i, 1].item() - float(info["scores"][k + "_score_num"])) <= 0.02 * max(1.0, sums[i, 2].item()), k
+    # data-loss gradients: the oracle's include the L2 term, the engine adds it inside the Adam kernel
+    data_grads = {k: g - (2.0 * l2 * w_before[k] if not k.split("/")[-1] in ("gamma", "beta") else 0.0) for k, g in grads.items()}
+    worst_cos, excess = _bf16_grad_report(grads_got, data_grads)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    step_cos = {}
+    for name in w_before:
+        if float(grads[name].abs().max()) < 1e-3 * gmax:
+            continue
+        d_want = (state.p[name].detach() - w_before[name]).reshape(-1)
+        d_got = (after[name].double() - before[name].double()).reshape(-1)
+        step_cos[name] = float(torch.dot(d_want, d_got) / (d_want.norm() * d_got.norm() + 1e-300))
+    _record("c2_bf16_train_step_replay", dict(B=B, S=S, D=D, L=L, oracle_loss=want, loss_rel_dev=rel,
+                                              worst_key_loss_rel_dev=max(key_rel.values()), worst_grad_cosine=worst_cos,
+                                              worst_grad_rms_err_over_budget=excess,
+                                              worst_adam_step_cosine=min(step_cos.values()),
+                                              mean_adam_step_cosine=sum(step_cos.values()) / len(step_cos)))
+    print("train step (replay, timed route): loss rel dev %.2e, worst key %.2e, worst grad cos %.6f, Adam step cos min %.4f mean %.4f"
+          % (rel, max(key_rel.values()), worst_cos, min(step_cos.values()), sum(step_cos.values()) / len(step_cos)))
+    assert rel <= BF16_LOSS_BUDGET, rel
+    assert max(key_rel.values()) <= BF16_KEY_BUDGET, key_rel
+    assert worst_cos > 0.98 and excess <= 1.0, (worst_cos, excess)
+    # the first Keras-Adam step moves every weight by lr * g / (|g| + eps): a SIGN pattern, so its cosine counts the
+    # entries whose bf16 gradient has the other sign than the f64 one (|g| within the bf16 noise of zero)
+    assert min(step_cos.values()) > ADAM_STEP_COS_BF16, step_cos
+    # ---- the kernels of this step are the kernels of the profiled step
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "step_kernels_c2.txt")
+    want_names = sorted(set(l.strip() for l in open(path) if l.strip() and not l.startswith("#")))
+    with _route("timed"):
+        timed = MFP(ic, num_blocks=L, latent_dim=D, dropout=0.1, l2=l2, masking_method="random", dtype="bf16", device=DEV, seed=5)
+        timed.compile(learning_rate=lr)
+        timed.train_step(dbatch)
+        got_names = sorted(set(_kernel_names(lambda: timed.train_step(dbatch))))
+    _record("c2_step_kernel_names", got_names)
+    assert got_names == want_names, (sorted(set(got_names) - set(want_names)), sorted(set(want_names) - set(got_names)))
+    # ... and the dropout-0 step that met the oracle above runs the same kernels (compile-time dropout variants aside)
+    import re
+    bare = lambda names: sorted(set(re.sub(r"<.*$", "", n) for n in names))
+    assert bare(eager_names) == bare(got_names), (bare(eager_names), bare(got_names))
 
 
 def test_grouped_wgrad_equals_per_product_path():
