@@ -731,10 +731,11 @@ extern "C" size_t mfp_wgrad_group_workspace_bytes(const mfp_wgrad_job* jobs, int
   return (size_t)splitk * ((size_t)wgg_tiles(jobs, njobs) * (128 * 128 + 128) + WGG_ZPAD) * sizeof(float);
 }
 
-extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int32_t splitk,
-                               void* workspace, size_t workspace_bytes, uint32_t* tickets, mfp_stream_t stream) {
+namespace {
+int wgrad_group_launch(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int32_t splitk,
+                       void* workspace, size_t workspace_bytes, uint32_t* tickets, bool defer, mfp_stream_t stream) {
   MFP_CHECK_ARG(jobs != nullptr && njobs >= 1 && njobs <= MFP_MAX_WGRAD_JOBS && K > 0);
-  MFP_CHECK_ARG(splitk >= 8 && splitk % 8 == 0 && tickets != nullptr && workspace != nullptr);
+  MFP_CHECK_ARG(splitk >= 8 && splitk % 8 == 0 && (defer || tickets != nullptr) && workspace != nullptr);
   WggParams p;
   int tile0 = 0;
   bool rowskip = false;
@@ -773,8 +774,52 @@ extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t
   p.trace = g_trace;
 #endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int rc = rowskip ? launch_wgg_t<true>(p, st) : launch_wgg_t<false>(p, st);
+  const int rc = defer ? (rowskip ? launch_wgg_t<true, true>(p, st) : launch_wgg_t<false, true>(p, st))
+                       : (rowskip ? launch_wgg_t<true, false>(p, st) : launch_wgg_t<false, false>(p, st));
   if (rc != MFP_OK) return rc;
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+}  // namespace
+
+extern "C" int mfp_wgrad_group(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int32_t splitk,
+                               void* workspace, size_t workspace_bytes, uint32_t* tickets, mfp_stream_t stream) {
+  return wgrad_group_launch(jobs, njobs, K, splitk, workspace, workspace_bytes, tickets, false, stream);
+}
+
+extern "C" int mfp_wgrad_group_partial(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int32_t splitk,
+                                       void* workspace, size_t workspace_bytes, mfp_stream_t stream) {
+  return wgrad_group_launch(jobs, njobs, K, splitk, workspace, workspace_bytes, nullptr, true, stream);
+}
+
+extern "C" int mfp_wgrad_reduce(const mfp_wgrad_pending* groups, int32_t ngroups, mfp_stream_t stream) {
+  MFP_CHECK_ARG(groups != nullptr && ngroups >= 1 && ngroups <= MFP_MAX_WGRAD_PENDING);
+  WgrParams p;
+  int unit0 = 0;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    const mfp_wgrad_pending& s = groups[gi];
+    MFP_CHECK_ARG(s.jobs != nullptr && s.njobs >= 1 && s.njobs <= MFP_MAX_WGRAD_JOBS && s.splitk >= 8 && s.splitk % 8 == 0);
+    MFP_CHECK_ARG(s.workspace != nullptr && ((uintptr_t)s.workspace % 16) == 0);
+    WgrGroup& G = p.g[gi];
+    int tile0 = 0;
+    for (int i = 0; i < s.njobs; ++i) {
+      const mfp_wgrad_job& j = s.jobs[i];
+      MFP_CHECK_ARG(j.C && j.M > 0 && j.N > 0 && j.N % 8 == 0 && j.ldc % 4 == 0 && j.ldc >= j.N && ((uintptr_t)j.C % 16) == 0);
+      WgrJob& d = G.job[i];
+      d.C = j.C; d.colsum = j.colsum; d.M = j.M; d.N = j.N; d.ldc = j.ldc;
+      d.tiles_n = (j.N + 127) / 128; d.tile0 = tile0; d.pad_ = 0;
+      tile0 += ((j.M + 127) / 128) * d.tiles_n;
+    }
+    for (int i = s.njobs; i < WGG_MAX_JOBS; ++i) { G.job[i] = G.job[0]; G.job[i].tile0 = 0x7FFFFFFF; }
+    G.njobs = s.njobs; G.ntiles = tile0; G.splitk = s.splitk; G.unit0 = unit0;
+    G.zstride = (long long)tile0 * 128 * 128 + WGG_ZPAD;
+    G.ws = reinterpret_cast<const float*>(s.workspace);
+    G.ws_col = G.ws + (size_t)s.splitk * G.zstride;
+    unit0 += tile0 * 8;
+  }
+  for (int gi = ngroups; gi < WGR_MAX_GROUPS; ++gi) { p.g[gi] = p.g[0]; p.g[gi].unit0 = 0x7FFFFFFF; }
+  p.ngroups = ngroups; p.nunits = unit0;
+  hipLaunchKernelGGL(wgg_reduce_kernel, dim3(unit0), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

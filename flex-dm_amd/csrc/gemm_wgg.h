@@ -68,7 +68,11 @@ struct WggParams {
 #ifndef MFP_WGG_OCC
 #define MFP_WGG_OCC 2
 #endif
-template <int XD, bool ROWSKIP>
+// DEFER: the workgroup only publishes its partial slab (plain stores: the kernel boundary makes them visible) and exits;
+// wgg_reduce_kernel sums the slabs of every deferred group of the step in ONE launch at the end of the backward pass.
+// Per launch that removes the write-through drain, the ticket and the last arriver's serial read of splitk slabs
+// (~10 us of the ~18 us a grouped launch costs beside its k-loop).
+template <int XD, bool ROWSKIP, bool DEFER>
 __global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p) {
   constexpr int BM = 128, BN = 128, BK = 64, PAD = 8, LDS_S = BM + PAD;
   constexpr int TILE_E = BK * LDS_S;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p)
     for (int i = 0; i < BM / 16; ++i) {
       const int row = r0 + 16 * i;
       __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&Cs[row * CS_LD + c4]), rss,
-                                             (unsigned int)((row * BN + c4) * 4), 0, 16 /* sc1 */);
+                                             (unsigned int)((row * BN + c4) * 4), 0, DEFER ? 0 : 16 /* sc1 */);
     }
     if (do_colsum && tid < BM) {
       float s = 0.f;
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p)
       __hip_atomic_store(&p.ws_col[((long long)kz * p.ntiles + tile) * BM + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if (DEFER) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
   __syncthreads();
   WGG_STAMP();   // slab drained
@@ -314,13 +319,13 @@ __global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p)
 #endif
 }
 
-template <bool ROWSKIP>
+template <bool ROWSKIP, bool DEFER>
 inline int launch_wgg_t(const WggParams& p, hipStream_t st) {
   constexpr int lds = 2 * (2 * 64 * 136 * 2);
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgg_kernel<WGG_XD, ROWSKIP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgg_kernel<WGG_XD, ROWSKIP, DEFER>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_wgrad_group: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
@@ -328,6 +333,61 @@ inline int launch_wgg_t(const WggParams& p, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_wgg_kernel<WGG_XD, ROWSKIP>), dim3(p.ntiles * p.splitk), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((gemm_wgg_kernel<WGG_XD, ROWSKIP, DEFER>), dim3(p.ntiles * p.splitk), dim3(512), lds, st, p);
   return MFP_OK;
+}
+
+// ------------------------------------------------------------------ deferred split-K reduction, all groups of a step
+constexpr int WGR_MAX_GROUPS = 8;
+struct WgrJob { float* C; float* colsum; int M, N, ldc, tiles_n, tile0, pad_; };
+struct WgrGroup {
+  const float* ws; const float* ws_col;
+  long long zstride;
+  int splitk, ntiles, unit0, njobs;
+  WgrJob job[WGG_MAX_JOBS];
+};
+struct WgrParams { WgrGroup g[WGR_MAX_GROUPS]; int ngroups, nunits; };
+
+// One workgroup per (tile, 16-row slice): 8 KB of the gradient = the sum of `splitk` slab pieces in FIXED order
+// kz = 0 .. splitk-1 (bit-identical to the in-launch last-arriver sum), all of a thread's loads in flight.
+__global__ __launch_bounds__(256) void wgg_reduce_kernel(WgrParams p) {
+  const int unit = blockIdx.x, tid = threadIdx.x;
+  int gi = 0;
+  for (int q = 1; q < p.ngroups; ++q) gi = unit >= p.g[q].unit0 ? q : gi;
+  const WgrGroup& G = p.g[gi];
+  const int local = unit - G.unit0, tile = local >> 3, slice = local & 7;
+  int ji = 0;
+  for (int q = 1; q < G.njobs; ++q) ji = tile >= G.job[q].tile0 ? q : ji;
+  const WgrJob& jb = G.job[ji];
+  const int bid = tile - jb.tile0, tm = bid / jb.tiles_n, tn = bid % jb.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int c4 = (tid & 31) * 4;
+  const float* src = G.ws + (long long)tile * (128 * 128) + c4;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  for (int z0 = 0; z0 < G.splitk; z0 += 8) {
+    f32x4 v[8][2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = slice * 16 + (tid >> 5) + 8 * h;
+        v[u][h] = z0 + u < G.splitk ? *reinterpret_cast<const f32x4*>(src + (z0 + u) * G.zstride + row * 128) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z0 + u < G.splitk) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { acc[h][0] += v[u][h][0]; acc[h][1] += v[u][h][1]; acc[h][2] += v[u][h][2]; acc[h][3] += v[u][h][3]; }
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = slice * 16 + (tid >> 5) + 8 * h;
+    if (m0 + row < jb.M && n0 + c4 < jb.N) *reinterpret_cast<f32x4*>(jb.C + (long long)(m0 + row) * jb.ldc + n0 + c4) = acc[h];
+  }
+  if (slice == 0 && jb.colsum != nullptr && tn == 0 && tid < 128 && m0 + tid < jb.M) {
+    float s = 0.f;
+    for (int z = 0; z < G.splitk; ++z) s += G.ws_col[((long long)z * G.ntiles + tile) * 128 + tid];
+    jb.colsum[m0 + tid] = s;
+  }
 }

@@ -49,6 +49,10 @@ class WgradJob(Structure):
     ]
 
 
+class WgradPending(Structure):
+    _fields_ = [("jobs", POINTER(WgradJob)), ("njobs", c_int32), ("splitk", c_int32), ("workspace", c_void_p)]
+
+
 class ReduceJob(Structure):
     _fields_ = [
         ("part", c_void_p), ("out0", c_void_p), ("out1", c_void_p), ("out2", c_void_p),
@@ -85,6 +89,8 @@ SIGNATURES = {
     "mfp_wgrad_group_splitk": (c_int32, [POINTER(WgradJob), c_int32, c_int32]),
     "mfp_wgrad_group_workspace_bytes": (c_size_t, [POINTER(WgradJob), c_int32, c_int32]),
     "mfp_wgrad_group": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mfp_wgrad_group_partial": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
+    "mfp_wgrad_reduce": (c_int32, [POINTER(WgradPending), c_int32, c_void_p]),
     "mfp_absmax": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "mfp_quantize_fp8": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mfp_gemm_fp8": (c_int32, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p]),

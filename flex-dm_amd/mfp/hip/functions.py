@@ -24,6 +24,10 @@ NUM_HEADS = 8
 # bf16 path: the weight gradients of a block (of the heads, of the encoder) as ONE grouped launch with the
 # split-K reduction inside it (csrc/gemm_wgg.h); 0 = one mfp_gemm + reduce kernel per product (A/B switch)
 WGRAD_GROUP = os.environ.get("MFP_WGRAD_GROUP", "1") == "1"
+# ... with the split-K reduction of every grouped launch of a backward pass (or of a data-parallel bucket) deferred into ONE
+# launch at its end (mfp_wgrad_group_partial + mfp_wgrad_reduce: ~10 us less per grouped launch, bit-identical
+# gradients); 0 = every grouped launch reduces in place (tickets + last arriver)
+WGRAD_DEFER = os.environ.get("MFP_WGRAD_DEFER", "1") == "1"
 # bf16 path, d_model 256: LN2 + FFN1 + ReLU + FFN2 + dropout + residual of a block as ONE launch, and the two
 # input-gradient products of the same half as one launch (csrc/block_fused.hip); 0 = ln_fwd + two products,
 # two dgrad products (A/B switch)
@@ -103,6 +107,9 @@ class StepCtx:
                             # step cuts its backward pass at some of them, MFP.capture_train_step)
         # pending LayerNorm parameter-gradient reductions (flush_ln_jobs); None = reduce in line
         self.ln_jobs = [] if os.environ.get("MFP_LN_BATCH_REDUCE", "1") == "1" else None
+        # grouped weight-gradient launches whose split-K reduction is still pending (flush_ln_jobs); None = reduce in place
+        # (side streams: the groups' slab buffers are per stream, and a deferred reduction would have to join them first)
+        self.wgrad_pending = [] if (WGRAD_DEFER and not self.sides) else None
         self.loss_sort = None   # RICO position-sorted loss: dict(flag, labels, heads, ignore_sort)
         self.handoff = {}   # block index -> pre-masked bf16 gradient of its second Dropout (fused LN bwd)
         self.res_grad = None   # the bf16 gradient of the residual stream on its way down (RES_GRAD_BF16), else None
@@ -163,6 +170,8 @@ class StepCtx:
         if self.ln_jobs:
             ops.reduce_partials_batch(self.ln_jobs)
             self.ln_jobs.clear()      # (in place: the context-token view of the step shares the list)
+        if self.wgrad_pending:
+            ops.wgrad_reduce(self.wgrad_pending)      # (clears the list in place)
 
     def join_side(self):
         for side in self.sides:
@@ -211,7 +220,8 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
         if onehot and WGRAD_GROUP:
             # the last products of the backward pass -- both encoder Dense gradients (+ biases) and the
             # table gradient -- as ONE grouped launch on the main stream (nothing is left to overlap)
-            ctx.flush_ln_jobs()
+            if ctx.wgrad_pending is None:      # (deferred split-K reductions: ONE flush behind this last group instead)
+                ctx.flush_ln_jobs()
             if ctx.onehot is None:
                 ctx.onehot = ops.embed_onehot(idx_all, st.rowoff, L.table_rows_pad)
             elif len(ctx.sides) > 2:   # built on side stream 2 during the forward pass
@@ -220,9 +230,10 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
                          rowskip=codes[j], colsum=st.grad("encoder/input_%s/bias" % k))
                     for j, k in enumerate(L.num_keys)]
             jobs.append(dict(A=ctx.onehot, B=dh_c, out=st.tables_padded(st.g), M=L.table_rows_pad, N=D))
-            ops.wgrad_group(jobs, T)
+            ops.wgrad_group(jobs, T, defer=ctx.wgrad_pending)
             ctx.onehot = None
             ctx.join_side()
+            ctx.flush_ln_jobs()      # the deferred split-K reductions of the whole backward pass: one launch
             return
 
         # the last products of the backward pass: nothing on the main stream overlaps them any more,
@@ -499,6 +510,8 @@ class BlockFn(torch.autograd.Function):
                      out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D),
                      colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D), splitk=sk(T, 3 * D, D))
         def wgrads_block():   # the four weight gradients (+ two bias gradients) of the block: one launch
+            if ctx.wgrad_pending is not None and len(ctx.wgrad_pending) >= ops.WGRAD_MAX_PENDING - 2:
+                ops.wgrad_reduce(ctx.wgrad_pending)      # (more than 6 blocks: reduce what has accumulated)
             ops.wgrad_group([
                 dict(A=dqkv, B=y1, out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D), M=3 * D, N=D,
                      colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D)),
@@ -506,7 +519,7 @@ class BlockFn(torch.autograd.Function):
                      colsum=st.grad(p + "mlp/dense_0/bias")),
                 dict(A=d_o2, B=h, out=st.grad(p + "mlp/dense_1/kernel"), M=D, N=2 * D,
                      colsum=st.grad(p + "mlp/dense_1/bias") if i in ctx.tail["bias_wgg"] else None),
-                dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)], T)
+                dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)], T, defer=ctx.wgrad_pending)
         if grouped:
             ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1, hold=True)
         else:
@@ -565,7 +578,8 @@ def _heads_wgrad(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> None:
     def wgrad_heads():
         if WGRAD_GROUP and dl_c.dtype == torch.bfloat16:
             ops.wgrad_group([dict(A=dl_c, B=h_c, out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
-                                  M=U, N=D, colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U))], T)
+                                  M=U, N=D, colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U))], T,
+                            defer=ctx.wgrad_pending)
             return
         ops.gemm(dl_c, h_c, U, D, T, a_kmajor=False, b_kmajor=False,
                  out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),

@@ -14,7 +14,7 @@ import torch
 
 from . import (GEMM_ACCUM, GEMM_BIAS, GEMM_COLSUM_A, GEMM_DROPOUT, GEMM_RELU, GEMM_RELU_BWD,
                GEMM_RESIDUAL, GEMM_ROWSKIP, GEMM_ROWSKIP_A, MFP_BF16, MFP_F32, GemmArgs, LossKey,
-               MaskCol, WgradJob, check, load)
+               MaskCol, WgradJob, WgradPending, check, load)
 
 _DT = {torch.float32: MFP_F32, torch.bfloat16: MFP_BF16}
 LN_EPS = 1e-3  # Keras LayerNormalization() default [TF-EXT]
@@ -243,10 +243,47 @@ def _wgrad_tickets(device) -> torch.Tensor:
     return t
 
 
-def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None) -> None:
+_deferred_ws: Dict = {}
+
+
+def _deferred_workspace(nbytes: int, device, slot: int) -> torch.Tensor:
+    """Slab buffer number ``slot`` of a step's deferred weight-gradient groups: each pending group keeps its partial
+    tiles until the reduction launch, so (unlike ``workspace``) the groups of one step must not share a buffer.
+    Grow-only per (device, stream, slot); old buffers stay alive for captured graphs."""
+    key = (torch.device(device), torch.cuda.current_stream().cuda_stream, slot)
+    lst = _deferred_ws.setdefault(key, [])
+    if not lst or lst[-1].numel() < nbytes:
+        lst.append(torch.empty(int(nbytes), dtype=torch.uint8, device=device))
+    return lst[-1]
+
+
+WGRAD_MAX_PENDING = 8
+
+
+def _wgrad_jobs_array(jobs: Sequence[dict]):
+    arr = (WgradJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        a = arr[i]
+        a.A, a.B, a.C = _ptr(j["A"]), _ptr(j["B"]), _ptr(j["out"])
+        a.colsum, a.rowcode = _ptr(j.get("colsum")), _ptr(j.get("rowskip"))
+        a.M, a.N = j["M"], j["N"]
+        a.lda, a.ldb = j["A"].stride(0), j["B"].stride(0)
+        a.ldc = j["out"].stride(0) if j["out"].dim() == 2 else j["N"]
+    return arr
+
+
+def wgrad_group_splitk(jobs: Sequence[dict], K: int) -> int:
+    """The token split ``mfp_wgrad_group_splitk`` picks for this group on this device."""
+    return int(load().mfp_wgrad_group_splitk(_wgrad_jobs_array(jobs), len(jobs), K))
+
+
+def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defer: Optional[list] = None) -> None:
     """``out_j[M_j, N_j] = A_j[K, M_j]^T @ B_j[K, N_j]`` (+ ``colsum_j[M_j] = sum_k A_j``) for up to 8 jobs
     in ONE launch -- see ``mfp_wgrad_group`` in include/mfp_hip.h.  jobs: dicts with A, B (bf16
-    [K, ld]), out (f32 [M, ldc] view), M, N and optionally colsum (f32 [M]), rowskip (u8 [K])."""
+    [K, ld]), out (f32 [M, ldc] view), M, N and optionally colsum (f32 [M]), rowskip (u8 [K]).
+
+    ``defer`` (a list): the launch only leaves its split-K partial tiles (``mfp_wgrad_group_partial``) and appends a
+    record to the list; ``wgrad_reduce(defer)`` later writes the gradients of every recorded group in one launch."""
     lib = load()
     n = len(jobs)
     arr = (WgradJob * n)()
@@ -267,10 +304,36 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None) -> N
     if splitk is None:
         splitk = lib.mfp_wgrad_group_splitk(arr, n, K)
     assert lib.mfp_wgrad_group_tiles(arr, n) <= WGRAD_MAX_TILES
-    ws = workspace(lib.mfp_wgrad_group_workspace_bytes(arr, n, splitk), dev)
+    need = lib.mfp_wgrad_group_workspace_bytes(arr, n, splitk)
+    if defer is not None:
+        assert len(defer) < WGRAD_MAX_PENDING, "flush the pending weight-gradient groups first (wgrad_reduce)"
+        ws = _deferred_workspace(need, dev, len(defer))
+        with _timed("gemm_wgg_kernel", flops, nbytes):
+            check(lib.mfp_wgrad_group_partial(arr, n, K, splitk, ws.data_ptr(), ws.numel(), _stream()), "mfp_wgrad_group_partial")
+        defer.append(dict(arr=arr, n=n, splitk=splitk, ws=ws, keep=[(j["A"], j["B"], j["out"], j.get("colsum")) for j in jobs],
+                          nbytes=need + sum(j["M"] * j["N"] * 4 for j in jobs)))
+        return
+    ws = workspace(need, dev)
     with _timed("gemm_wgg_kernel", flops, nbytes):
         check(lib.mfp_wgrad_group(arr, n, K, splitk, ws.data_ptr(), ws.numel(), _wgrad_tickets(dev).data_ptr(),
                                   _stream()), "mfp_wgrad_group")
+
+
+def wgrad_reduce(pending: list) -> None:
+    """The gradients of every group ``wgrad_group(..., defer=pending)`` recorded: ONE launch (``mfp_wgrad_reduce``) sums each
+    group's split-K slabs in the fixed order of the in-launch reduction.  Empties the list."""
+    if not pending:
+        return
+    lib = load()
+    n = len(pending)
+    arr = (WgradPending * n)()
+    nbytes = 0
+    for i, rec in enumerate(pending):
+        arr[i].jobs, arr[i].njobs, arr[i].splitk, arr[i].workspace = rec["arr"], rec["n"], rec["splitk"], rec["ws"].data_ptr()
+        nbytes += rec["nbytes"]
+    with _timed("wgg_reduce_kernel", 0, nbytes):
+        check(lib.mfp_wgrad_reduce(arr, n, _stream()), "mfp_wgrad_reduce")
+    pending.clear()
 
 
 # ------------------------------------------------------------------------------- LayerNorm

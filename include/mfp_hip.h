@@ -124,6 +124,20 @@ int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs /*host*/, int32_t njobs
 size_t mfp_wgrad_group_workspace_bytes(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t splitk);
 int mfp_wgrad_group(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t splitk,
                     void* workspace, size_t workspace_bytes, uint32_t* tickets, mfp_stream_t stream);
+/* The same launch WITHOUT its split-K reduction: every workgroup leaves its partial tile in `workspace` and the
+ * gradients are NOT written.  mfp_wgrad_reduce then sums the slabs of up to MFP_MAX_WGRAD_PENDING such launches (each with
+ * its OWN workspace, untouched in between; same jobs / splitk as the launch that filled it) in one launch, in the fixed
+ * order of the in-launch reduction (bit-identical results).  The train step defers the block / heads / encoder groups
+ * of a backward pass (or of a data-parallel bucket) this way: ~10 us less per grouped launch. */
+#define MFP_MAX_WGRAD_PENDING 8
+typedef struct mfp_wgrad_pending {
+  const mfp_wgrad_job* jobs;   /* host */
+  int32_t njobs, splitk;
+  const void* workspace;       /* device: what mfp_wgrad_group_partial filled */
+} mfp_wgrad_pending;
+int mfp_wgrad_group_partial(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t splitk,
+                            void* workspace, size_t workspace_bytes, mfp_stream_t stream);
+int mfp_wgrad_reduce(const mfp_wgrad_pending* groups /*host*/, int32_t ngroups, mfp_stream_t stream);
 
 /* ------------------------------------------------------------------------ fp8 forward Dense
  * BASELINE config c5 ("fp8 MFMA"): the QKV / FFN1 products of a block (transformer.py:85-90,161-166)

@@ -735,6 +735,26 @@ def test_wgrad_group(T, splitk):
         for (o0, c0), (o, c) in zip(runs[0], r):
             assert torch.equal(o0, o) and (c0 is None or torch.equal(c0, c))
     assert int(ops._wgrad_tickets(DEV).abs().sum()) == 0
+    # the deferred form (mfp_wgrad_group_partial + mfp_wgrad_reduce: what the train step runs): two groups pending at
+    # once, each in its own slab buffer, ONE reduction launch -- bit-identical to the in-launch reduction
+    pending = []
+    for j in jobs:
+        j["out"].fill_(7.0)
+        if "colsum" in j:
+            j["colsum"].fill_(7.0)
+    half = max(1, len(jobs) // 2)
+    sk = splitk or ops.wgrad_group_splitk(jobs, T)        # (the split chosen for the whole group above: same summation order)
+    ops.wgrad_group(jobs[:half], T, sk, defer=pending)
+    ops.wgrad_group(jobs[half:], T, sk, defer=pending)
+    assert len(pending) == 2 and all((j["out"] == 7.0).all() for j in jobs)      # nothing written yet
+    ops.wgrad_reduce(pending)
+    torch.cuda.synchronize()
+    assert pending == []
+    for j, (o0, c0) in zip(jobs, runs[0]):
+        assert torch.equal(j["out"], o0), (j["M"], j["N"])
+        if c0 is not None:
+            assert torch.equal(j["colsum"], c0)
+        assert (j["out"]._base[:, j["N"]:] == 7.0).all()
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(1000, 1536, 512, False), (2050, 1024, 512, True), (300, 768, 256, False), (64, 8, 16, True)])

@@ -418,7 +418,7 @@ BF16_LOSS_BUDGET = 1e-3  # north_star's bound, on the TOTAL loss; measured 4.7e-
 # deviation is dominated by a handful of near-tie logits; measured worst key 1.85e-3 (c2) / 2.42e-3 (c3), budget 3e-3
 BF16_KEY_BUDGET = 3e-3
 # cosine of the first Adam step (a sign pattern) of the bf16 replay with the f64 oracle's, significant variables
-ADAM_STEP_COS_BF16 = 0.9
+ADAM_STEP_COS_BF16 = 0.95     # measured: min 0.971, mean 0.995 over the significant variables
 
 
 def _timed_shape_case(mix, B, S=128, D=256, L=4):
@@ -624,7 +624,7 @@ def test_train_step_timed_route_vs_oracle():
     from mfp.data.spec import make_input_columns, synthetic_batch
     from mfp.models.metrics import loss_key_names
     from mfp.models.mfp import MFP
-    S, D, L, B, lr, l2 = 128, 256, 4, 6, 1e-3, 1e-2
+    S, D, L, B, lr, l2 = 128, 256, 4, 32, 1e-3, 1e-2     # T = 4096: every kernel of the timed step is selected (the tables-in-LDS gather from there on)
     ic = make_input_columns("crello")
     keys = loss_key_names(ic)
     params = np_ref.init_params(ic, D, L, seed=-11)
@@ -634,6 +634,7 @@ def test_train_step_timed_route_vs_oracle():
         model = MFP(ic, num_blocks=L, latent_dim=D, dropout=0.0, l2=l2, masking_method="random", dtype="bf16",
                     device=DEV, seed=5)
         model.compile(learning_rate=lr)
+        model.train_step(dbatch)          # (first call: one-time scratch fills)
         eager_names = _kernel_names(lambda: model.train_step(dbatch))
         model.capture_train_step(dbatch, warmup=1)
         # rewind to the oracle's starting point: its weights, empty Adam slots, step counter 0
