@@ -713,11 +713,13 @@ extern "C" int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs, int32_t njo
   for (int i = 0; i < njobs; ++i) rowskip |= jobs[i].rowcode != nullptr;
   int best = 8;
   long long best_cost = -1;
-  for (int sk = 8; sk <= 512; sk += 8) {
+  for (int sk = 1; sk <= 512; sk = sk < 8 ? sk * 2 : sk + 8) {
     const int kchunk = (((K + 63) / 64 + sk - 1) / sk) * 64;      // tokens of the longest cyclic k-slice
     if (sk > 8 && kchunk < 256) break;
     if (rowskip && kchunk > WG_MAX_KCHUNK) continue;
-    const long long waves = ((long long)tiles * sk + ncu - 1) / ncu;
+    if (sk < 8 && (long long)tiles * sk < ncu) continue;          // fewer workgroups than CUs: split further
+    const long long nwg = sk >= 8 ? (long long)tiles * sk : 8ll * ((tiles * sk + 7) / 8);
+    const long long waves = (nwg + ncu - 1) / ncu;
     // measured (tools/bench_wgrad.py, block group at T = 32768): 1.1 us per k-tile + 11 us per workgroup
     // (pipeline fill, 64 KB slab store, ticket, the last arriver's read of `sk` slabs)
     const long long cost = waves * (kchunk / 64 + 10) + sk / 8;
@@ -735,7 +737,7 @@ namespace {
 int wgrad_group_launch(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int32_t splitk,
                        void* workspace, size_t workspace_bytes, uint32_t* tickets, bool defer, mfp_stream_t stream) {
   MFP_CHECK_ARG(jobs != nullptr && njobs >= 1 && njobs <= MFP_MAX_WGRAD_JOBS && K > 0);
-  MFP_CHECK_ARG(splitk >= 8 && splitk % 8 == 0 && (defer || tickets != nullptr) && workspace != nullptr);
+  MFP_CHECK_ARG((splitk == 1 || splitk == 2 || splitk == 4 || (splitk >= 8 && splitk % 8 == 0)) && (defer || tickets != nullptr) && workspace != nullptr);
   WggParams p;
   int tile0 = 0;
   bool rowskip = false;
@@ -759,6 +761,7 @@ int wgrad_group_launch(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int3
   for (int i = njobs; i < WGG_MAX_JOBS; ++i) { p.job[i] = p.job[0]; p.job[i].tile0 = 0x7FFFFFFF; }
   p.njobs = njobs; p.ntiles = tile0; p.K = K; p.splitk = splitk;
   p.nk_max = ((K + 63) / 64 + splitk - 1) / splitk;
+  p.tpg = splitk < 8 ? (tile0 * splitk + 7) / 8 : 0;
   if (rowskip) MFP_CHECK_ARG(p.nk_max * 64 <= WG_MAX_KCHUNK);
   const size_t need = mfp_wgrad_group_workspace_bytes(jobs, njobs, splitk);
   if (workspace_bytes < need) {
@@ -798,7 +801,7 @@ extern "C" int mfp_wgrad_reduce(const mfp_wgrad_pending* groups, int32_t ngroups
   int unit0 = 0;
   for (int gi = 0; gi < ngroups; ++gi) {
     const mfp_wgrad_pending& s = groups[gi];
-    MFP_CHECK_ARG(s.jobs != nullptr && s.njobs >= 1 && s.njobs <= MFP_MAX_WGRAD_JOBS && s.splitk >= 8 && s.splitk % 8 == 0);
+    MFP_CHECK_ARG(s.jobs != nullptr && s.njobs >= 1 && s.njobs <= MFP_MAX_WGRAD_JOBS && (s.splitk == 1 || s.splitk == 2 || s.splitk == 4 || (s.splitk >= 8 && s.splitk % 8 == 0)));
     MFP_CHECK_ARG(s.workspace != nullptr && ((uintptr_t)s.workspace % 16) == 0);
     WgrGroup& G = p.g[gi];
     int tile0 = 0;

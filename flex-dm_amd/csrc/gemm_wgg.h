@@ -60,6 +60,7 @@ struct WggParams {
   unsigned int* tickets;        // [ntiles], zero on entry, zero on exit
   long long zstride;            // floats between the slabs of consecutive k-slices
   int njobs, ntiles, K, nk_max, splitk;   // nk_max = k-tiles of the longest k-slice
+  int tpg;                                // splitk < 8: tiles per XCD group = ceil(ntiles * splitk / 8)
 #ifdef MFP_GEMM_TRACE
   unsigned long long* trace;   // [workgroup][24] s_memrealtime stamps (100 MHz) of thread 0
 #endif
@@ -95,7 +96,13 @@ __global__ __launch_bounds__(512, MFP_WGG_OCC) void gemm_wgg_kernel(WggParams p)
 #endif
   WGG_STAMP();   // 0: start
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int kz = (j / p.ntiles) * 8 + xcd, tile = j % p.ntiles;          // splitk % 8 == 0 (host)
+  int kz, tile;
+  if (p.splitk >= 8) {          // splitk % 8 == 0 (host): XCD x runs the k-slices x, x + 8, ... of every tile
+    kz = (j / p.ntiles) * 8 + xcd; tile = j % p.ntiles;
+  } else {                      // splitk 1 | 2 | 4 (many tiles: c5): an XCD runs ONE k-slice of a contiguous group of tiles
+    kz = xcd % p.splitk; tile = (xcd / p.splitk) * p.tpg + j;       // (neighbouring tiles share operand panels)
+    if (tile >= p.ntiles || tile >= (xcd / p.splitk + 1) * p.tpg) return;
+  }
   int ji = 0;
   for (int q = 1; q < p.njobs; ++q) ji = tile >= p.job[q].tile0 ? q : ji;
   const WggJob& jb = p.job[ji];
@@ -333,7 +340,7 @@ inline int launch_wgg_t(const WggParams& p, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_wgg_kernel<WGG_XD, ROWSKIP, DEFER>), dim3(p.ntiles * p.splitk), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((gemm_wgg_kernel<WGG_XD, ROWSKIP, DEFER>), dim3(p.splitk >= 8 ? p.ntiles * p.splitk : 8 * p.tpg), dim3(512), lds, st, p);
   return MFP_OK;
 }
 

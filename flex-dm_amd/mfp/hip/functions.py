@@ -42,7 +42,7 @@ BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
 # stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  Measured:
 # 1.547 vs 1.559 ms per c2 step (the LayerNorm backward is not purely bandwidth-bound at 3 KB per element) for eight more
 # bf16 roundings on the way down -- OFF by default ("1" = on)
-RES_GRAD_BF16 = os.environ.get("MFP_RES_GRAD_BF16", "0") == "1"
+RES_GRAD_BF16 = os.environ.get("MFP_RES_GRAD_BF16", "1") == "1"
 
 
 def _res16_ok(ctx) -> bool:
@@ -345,7 +345,8 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(fctx, dh):
-        _encoder_bwd(fctx.ctx, *fctx.saved, dh.contiguous())
+        # (RES_GRAD_BF16: dh is a stride-0 placeholder -- the gradient arrived as ctx.dh_c; never materialise it)
+        _encoder_bwd(fctx.ctx, *fctx.saved, dh if (dh.dim() > 1 and dh.stride(0) == 0) else dh.contiguous())
         fctx.saved = None
         return None, None, None, None
 
@@ -362,7 +363,8 @@ class EncoderPreFn(torch.autograd.Function):
 
     @staticmethod
     def backward(fctx, dh):
-        _encoder_bwd(fctx.ctx, *fctx.saved, dh.contiguous())
+        # (RES_GRAD_BF16: dh is a stride-0 placeholder -- the gradient arrived as ctx.dh_c; never materialise it)
+        _encoder_bwd(fctx.ctx, *fctx.saved, dh if (dh.dim() > 1 and dh.stride(0) == 0) else dh.contiguous())
         fctx.saved = None
         return None, None, None, None, None
 

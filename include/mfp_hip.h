@@ -106,7 +106,7 @@ const char* mfp_gemm_kernel_family(const mfp_gemm_args* args /*host*/);
  *   A bf16 [K][lda] (gradient side), B bf16 [K][ldb] (activation side), C f32 [M][ldc];
  *   colsum f32 [M] or NULL: column sums of A (bias gradient); rowcode u8 [K] or NULL: rows of A
  *   whose code is non-zero count as zero rows (encoder.py:174-175).
- *   M, N, lda, ldb % 8 == 0; ldc % 4 == 0; splitk % 8 == 0 (mfp_wgrad_group_splitk picks it);
+ *   M, N, lda, ldb % 8 == 0; ldc % 4 == 0; splitk 1, 2, 4 or a multiple of 8 (mfp_wgrad_group_splitk picks it);
  *   tickets: uint32 [>= mfp_wgrad_group_tiles()] owned by the caller, ALL ZERO before the first
  *   launch that uses them; the launch leaves them zero.  Launches that may run concurrently (other
  *   streams) need their own workspace and tickets. */

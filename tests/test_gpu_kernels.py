@@ -681,7 +681,7 @@ def test_gemm_streaming_wgrad(M, N, T, sk):
     assert_close(out2, A.double().t() @ Bm.double(), 2e-4 * math.sqrt(T), 1e-5, "streaming wgrad plain")
 
 
-@pytest.mark.parametrize("T,splitk", [(4096, None), (1100, 8), (32768, None), (8192, 16)])
+@pytest.mark.parametrize("T,splitk", [(4096, None), (1100, 8), (32768, None), (8192, 16), (2048, 2), (1100, 4), (512, 1)])
 def test_wgrad_group(T, splitk):
     """mfp_wgrad_group: several products over the same tokens in one launch with the split-K reduction
     inside it (last arriver per tile sums the slabs).  Ragged tiles (M = 344, 1384, N = 72), ragged
