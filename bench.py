@@ -112,7 +112,7 @@ def family(kernel_name):
 # device-kernel name (as the tracer reports it) -> the family name the library calls are booked under (ops._timed)
 _KERNEL_FAMILY = (("attn_bwd", "attn_bwd"), ("attn_fwd", "attn_fwd"), ("ce_tile_kernel", "loss_kernels"),
                   ("mse_kernel", "loss_kernels"), ("zero_sums_kernel", "loss_kernels"),
-                  ("dgrad_half_kernel", "dgrad_qkv_kernel"), ("adam_norm_kernel", "adam_kernels"),
+                  ("dgrad_half_kernel", "dgrad_qkv_kernel"), ("gemm_wgm_kernel", "gemm_wgg_kernel"), ("adam_norm_kernel", "adam_kernels"),
                   ("adam_update_kernel", "adam_kernels"), ("transpose_cast_kernel", "cast_kernel"),
                   ("embed_fwd_lds_kernel", "embed_fwd_kernel"), ("embed_onehot_kernel", "embed_fwd_kernel"),
                   ("reduce_rows", "reduce_partials_batch"), ("step_prologue_kernel", "mask_kernel"))
@@ -436,9 +436,9 @@ def main():
             model.train_step(batch)
         recs = ops.stop_profile()
         agg, blk, blk_ms = {}, [0.0, 0.0, 0.0], {}
-        for name, flops, nbytes, ms, scope in recs:
+        for name, flops, nbytes, ms, scope, share in recs:      # share < 1: one launch booked under several scopes
             a = agg.setdefault(family(name), [0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += flops; a[2] += nbytes; a[3] += ms
+            a[0] += share; a[1] += flops; a[2] += nbytes; a[3] += ms
             if scope == "block":
                 blk[0] += flops; blk[1] += nbytes; blk[2] += ms
                 blk_ms[family(name)] = blk_ms.get(family(name), 0.0) + ms

@@ -351,6 +351,7 @@ struct WgrGroup {
   const float* ws; const float* ws_col;
   long long zstride;
   int splitk, ntiles, unit0, njobs;
+  int layout, pad_;             // 0: slabs are row-major tiles (gemm_wgg_kernel); 1: accumulator order (gemm_wgm_kernel)
   WgrJob job[WGG_MAX_JOBS];
 };
 struct WgrParams { WgrGroup g[WGR_MAX_GROUPS]; int ngroups, nunits; };
@@ -368,18 +369,28 @@ __global__ __launch_bounds__(256) void wgg_reduce_kernel(WgrParams p) {
   const WgrJob& jb = G.job[ji];
   const int bid = tile - jb.tile0, tm = bid / jb.tiles_n, tn = bid % jb.tiles_n;
   const int m0 = tm * 128, n0 = tn * 128;
-  const int c4 = (tid & 31) * 4;
-  const float* src = G.ws + (long long)tile * (128 * 128) + c4;
+  // this thread's two float4 of the tile: slab offsets (floats) and the (row, column) they belong to
+  int off[2], rowh[2], colh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (G.layout == 0) {
+      rowh[h] = slice * 16 + (tid >> 5) + 8 * h; colh[h] = (tid & 31) * 4;
+      off[h] = rowh[h] * 128 + colh[h];
+    } else {      // float4 f = ((wave * 16 + a * 4 + b) * 64 + lane) of gemm_wgm_kernel's accumulator dump
+      const int f = slice * 512 + h * 256 + tid, q = f >> 10, a = (f >> 8) & 3, b = (f >> 6) & 3, ln = f & 63;
+      rowh[h] = (q >> 1) * 64 + a * 16 + (ln & 15); colh[h] = (q & 1) * 64 + (ln >> 4) * 16 + b * 4;
+      off[h] = f * 4;
+    }
+  }
+  const float* src = G.ws + (long long)tile * (128 * 128);
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
   for (int z0 = 0; z0 < G.splitk; z0 += 8) {
     f32x4 v[8][2];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = slice * 16 + (tid >> 5) + 8 * h;
-        v[u][h] = z0 + u < G.splitk ? *reinterpret_cast<const f32x4*>(src + (z0 + u) * G.zstride + row * 128) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+      for (int h = 0; h < 2; ++h)
+        v[u][h] = z0 + u < G.splitk ? *reinterpret_cast<const f32x4*>(src + (z0 + u) * G.zstride + off[h]) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (z0 + u < G.splitk) {
@@ -388,10 +399,9 @@ __global__ __launch_bounds__(256) void wgg_reduce_kernel(WgrParams p) {
       }
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int row = slice * 16 + (tid >> 5) + 8 * h;
-    if (m0 + row < jb.M && n0 + c4 < jb.N) *reinterpret_cast<f32x4*>(jb.C + (long long)(m0 + row) * jb.ldc + n0 + c4) = acc[h];
-  }
+  for (int h = 0; h < 2; ++h)
+    if (m0 + rowh[h] < jb.M && n0 + colh[h] < jb.N)
+      *reinterpret_cast<f32x4*>(jb.C + (long long)(m0 + rowh[h]) * jb.ldc + n0 + colh[h]) = acc[h];
   if (slice == 0 && jb.colsum != nullptr && tn == 0 && tid < 128 && m0 + tid < jb.M) {
     float s = 0.f;
     for (int z = 0; z < G.splitk; ++z) s += G.ws_col[((long long)z * G.ntiles + tile) * 128 + tid];

@@ -50,7 +50,8 @@ class WgradJob(Structure):
 
 
 class WgradPending(Structure):
-    _fields_ = [("jobs", POINTER(WgradJob)), ("njobs", c_int32), ("splitk", c_int32), ("workspace", c_void_p)]
+    _fields_ = [("jobs", POINTER(WgradJob)), ("njobs", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
+                ("layout", c_int32)]
 
 
 class ReduceJob(Structure):
@@ -91,6 +92,7 @@ SIGNATURES = {
     "mfp_wgrad_group": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mfp_wgrad_group_partial": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "mfp_wgrad_reduce": (c_int32, [POINTER(WgradPending), c_int32, c_void_p]),
+    "mfp_wgrad_merged": (c_int32, [POINTER(WgradPending), c_int32, c_int32, c_void_p]),
     "mfp_absmax": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "mfp_quantize_fp8": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mfp_gemm_fp8": (c_int32, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p]),

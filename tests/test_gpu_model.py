@@ -714,7 +714,8 @@ def test_grouped_wgrad_equals_per_product_path():
     B, S = 64, 128
     batch = synthetic_batch(ic, B, S, seed=3, ragged=True, device=DEV)
     grads = []
-    old = functions.WGRAD_GROUP
+    old, old16 = functions.WGRAD_GROUP, functions.RES_GRAD_BF16
+    functions.RES_GRAD_BF16 = False      # (the bf16 residual-gradient stream needs the grouped launches: same stream in both runs)
     try:
         for grouped in (False, True):
             functions.WGRAD_GROUP = grouped
@@ -726,7 +727,7 @@ def test_grouped_wgrad_equals_per_product_path():
             torch.cuda.synchronize()
             grads.append((model.model.store.grads_state_dict(), sums.clone()))
     finally:
-        functions.WGRAD_GROUP = old
+        functions.WGRAD_GROUP, functions.RES_GRAD_BF16 = old, old16
     (g0, s0), (g1, s1) = grads
     assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-5)
     for name, a in g0.items():
