@@ -1,65 +1,33 @@
 // fp8 (OCP e4m3) forward Dense for BASELINE config c5 ("fp8 MFMA"): the QKV and FFN1 products of a
-// DeepSVG block (reference architecture/transformer.py:85-90,161-166) with per-tensor scaling.
+// DeepSVG block (reference architecture/transformer.py:85-90,161-166) as MX block-scaled products.
 //
-//   C[M][N] = relu?( (Xq Wq^T) / (sx * sw) + bias ),   Xq = e4m3(sx * X),  Wq = e4m3(sw * W)
+//   C[M][N] = relu?( sum_blocks  sx[m][blk] sw[n][blk] (Xq[m][blk] . Wq[n][blk])  + bias )
 //
-//   * weights: quantised once per optimizer step from the f32 master copy (mfp_quantize_fp8: scale
-//     sw = 448 / amax(W) per Keras variable, kept on the device);
-//   * activations: X is the bf16 LayerNorm output; its amax comes from mfp_absmax (256 block maxima, no
-//     atomics, no zero fill -- the consumer reduces them), sx = 448 / amax, and X is quantised ON THE FLY
-//     while the tile is staged into LDS (16 k-values = 32 B of bf16 -> one 16-byte fp8 chunk);
-//   * v_mfma_f32_16x16x32_fp8_fp8 (f32 accumulation).  A lane's 16-byte LDS fragment feeds TWO
-//     consecutive k-steps (low / high 8 bytes): the induced permutation of k is the same for both
-//     operands, so the contraction is unchanged and the fragment reads stay 16 bytes wide (8-byte LDS
-//     reads from one wave per SIMD run at a fifth of the LDS rate);
+// OCP Microscaling (MX) format, block size 32 along k: a block shares one e8m0 scale -- the smallest power of two that
+// brings its largest magnitude to <= 448 (mx_scale_byte) -- and holds 32 e4m3 elements = round-to-nearest-even(v / scale).
+//   * weights: quantised once per optimizer step from the f32 master copy (mfp_quantize_mxfp8: fp8 [N][K] + e8m0
+//     [N][K / 32]);
+//   * activations: X is the bf16 LayerNorm output, quantised ON THE FLY while a tile is staged into LDS: a thread holds 16
+//     k-values, the block maximum is one DPP step with its neighbour, the scale byte goes to a small LDS table -- no
+//     amax pass over the tensor, no per-tensor scale (round 2's form: two extra launches per product, and one outlier row
+//     cost every other row its mantissa range);
+//   * v_mfma_scale_f32_16x16x128_f8f6f4: lane (row, group g) holds k = 16 g .. + 15 and 64 + 16 g .. + 15 of its row (two
+//     16-byte LDS reads) and the scale byte of the contiguous block k = 32 g .. + 31 -- the hardware applies
+//     2^(sa + sb - 254) per block, f32 accumulation; one instruction = 128 k = four times the k of
+//     v_mfma_f32_16x16x32_fp8_fp8 at twice its rate;
 //   * the backward pass is unchanged (bf16 operands from the saved bf16 activations: straight-through).
-//
-// This path exists for the c5 precision mode; it is an LDS-tiled kernel (128 x 128 x 128, 4 waves), not
-// the weight-stationary design: non-scaled fp8 MFMA runs at the bf16 rate on gfx950 and these products
-// are HBM-bound, so fp8 buys accuracy measurements here, not time.
+// An LDS-tiled kernel (128 x 128 x 128, 4 waves): these products are HBM-bound (bf16 in, bf16 out), so the mode matches
+// the bf16 step time at best; it exists for the configuration and its measured deviation.  An
+// activation-stationary form (64-row tile quantised once, all operand fragments in registers, weights streamed in
+// 64-column chunks four deep) was built and measured at the same 60 us per c5 Q|K|V product (42 us with the weight loads
+// removed: one wave per SIMD runs its LDS / barrier / store phases back to back) against 36 us for the bf16
+// weight-stationary kernel -- removed again.
 #include "common.h"
 
 namespace {
 
-constexpr int ABSMAX_PARTS = 256;
 constexpr float FP8_MAX = 448.0f;   // e4m3fn
-
-__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ x, long long n, int is_bf16,
-                                                     float* __restrict__ parts) {
-  __shared__ float red[4];
-  float m = 0.f;
-  const long long stride = (long long)gridDim.x * 256 * 8;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
-    if (is_bf16) {
-      if (i + 8 <= n) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(x) + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          m = fmaxf(m, fabsf(bf16_to_f32((unsigned short)(v[e] & 0xffffu))));
-          m = fmaxf(m, fabsf(bf16_to_f32((unsigned short)(v[e] >> 16))));
-        }
-      } else {
-        for (long long j = i; j < n; ++j) m = fmaxf(m, fabsf(bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[j])));
-      }
-    } else {
-      for (long long j = i; j < n && j < i + 8; ++j) m = fmaxf(m, fabsf(reinterpret_cast<const float*>(x)[j]));
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-
-__device__ __forceinline__ float scale_from_parts(const float* __restrict__ parts) {
-  // every lane reduces the 256 block maxima (4 loads per lane + wave reduction)
-  const int lane = threadIdx.x & 63;
-  float m = fmaxf(fmaxf(parts[lane], parts[64 + lane]), fmaxf(parts[128 + lane], parts[192 + lane]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  return m > 0.f ? FP8_MAX / m : 1.0f;
-}
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // 8 floats -> 8 e4m3 bytes (saturating at +-448)
 __device__ __forceinline__ u32x2 cvt8_fp8(const float (&v)[8]) {
@@ -74,36 +42,55 @@ __device__ __forceinline__ u32x2 cvt8_fp8(const float (&v)[8]) {
   return (u32x2){(unsigned int)lo, (unsigned int)hi};
 }
 
-__global__ __launch_bounds__(256) void quantize_fp8_kernel(const float* __restrict__ w, long long n,
-                                                           const float* __restrict__ parts, unsigned char* __restrict__ out,
-                                                           float* __restrict__ scale_out) {
-  const float s = scale_from_parts(parts);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
-  const long long stride = (long long)gridDim.x * 256 * 8;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i + 8 <= n; i += stride) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(w + i), b = *reinterpret_cast<const f32x4*>(w + i + 4);
-    const float v[8] = {a[0] * s, a[1] * s, a[2] * s, a[3] * s, b[0] * s, b[1] * s, b[2] * s, b[3] * s};
-    *reinterpret_cast<u32x2*>(out + i) = cvt8_fp8(v);
+// e8m0 scale byte of a block whose largest magnitude has the f32 bit pattern `amax_bits` (sign cleared): the smallest
+// power of two that maps the maximum to <= 448, i.e. 2^(floor(log2 amax) - 8), one step more when amax / that exceeds 448
+// (mantissa above 1.75).  The OCP reference rule stops at the first form and SATURATES such maxima (up to -12.5 % on the
+// largest element of every fifth block: measured 3.2e-2 on the c5 loss against 1.3e-2 for per-tensor scales); floored at 0
+// (= 2^-127: zero / denormal blocks).
+__device__ __forceinline__ unsigned int mx_scale_byte(unsigned int amax_bits) {
+  const int e = (int)(amax_bits >> 23) - 8 + ((amax_bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+  return (unsigned int)(e < 0 ? 0 : e);
+}
+// 1 / scale as a float: 2^(127 - byte)
+__device__ __forceinline__ float mx_inv_scale(unsigned int sb) { return __uint_as_float((254u - sb) << 23); }
+
+// Weights: one 16-lane group per row walks its 32-blocks; w f32 [rows][K] -> out fp8 [rows][K], scales e8m0 [rows][K / 32]
+__global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const float* __restrict__ w, long long nblk,
+                                                             unsigned char* __restrict__ out, unsigned char* __restrict__ scales) {
+  // one thread per 8 elements, 4 threads per block
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nblk * 4; i += stride) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + i * 8), b = *reinterpret_cast<const f32x4*>(w + i * 8 + 4);
+    float m = fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))),
+                    fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    const unsigned int sb = mx_scale_byte(__float_as_uint(m));
+    const float inv = mx_inv_scale(sb);
+    const float v[8] = {a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv, b[0] * inv, b[1] * inv, b[2] * inv, b[3] * inv};
+    *reinterpret_cast<u32x2*>(out + i * 8) = cvt8_fp8(v);
+    if ((i & 3) == 0) scales[i >> 2] = (unsigned char)sb;
   }
 }
 
-// C[M][N] (bf16) = relu?((Xq Wq^T) / (sx sw) + bias); X bf16 [M][lda], Wq fp8 [N][K]
+// C[M][N] (bf16) = relu?(MX product + bias); X bf16 [M][lda], Wq fp8 [N][K], Ws e8m0 [N][K / 32]; K % 128 == 0
 template <bool RELU>
-__global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned short* __restrict__ X, const unsigned char* __restrict__ Wq,
-                                                       const float* __restrict__ x_parts, const float* __restrict__ w_scale,
-                                                       const float* __restrict__ bias, unsigned short* __restrict__ C,
-                                                       int M, int N, int K, int lda, int ldc) {
-  constexpr int BM = 128, BN = 128, BK = 128, ROWB = BK + 16;   // LDS row: 128 fp8 + 16 B pad (36 words: 16 rows hit 16 bank quads)
-  __shared__ __attribute__((aligned(16))) unsigned char As[BM * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROWB];
+__global__ __launch_bounds__(256) void gemm_mxfp8_kernel(const unsigned short* __restrict__ X, const unsigned char* __restrict__ Wq,
+                                                         const unsigned char* __restrict__ Ws, const float* __restrict__ bias,
+                                                         unsigned short* __restrict__ C, int M, int N, int K, int lda, int ldc) {
+  constexpr int BM = 128, BN = 128, BK = 128, ROWB = BK + 16;   // LDS row: 128 fp8 + 16 B pad
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * ROWB + 2 * BM * 4];
+  unsigned char* const As = lds;
+  unsigned char* const Bs = lds + BM * ROWB;
+  unsigned int* const Sx = reinterpret_cast<unsigned int*>(lds + 2 * BM * ROWB);      // [row]: the 4 block scales of the k-tile
+  unsigned int* const Sw = Sx + BM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (N + BN - 1) / BN;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;      // the column tiles of a row tile are neighbours: X from L2
   const int m0 = tm * BM, n0 = tn * BN;
-  const float sx = scale_from_parts(x_parts), sw = *w_scale;
-  const float inv = 1.0f / (sx * sw);
-  // staging plan: chunk = 16 k-values; thread -> chunk column q = tid & 7, rows (tid >> 3) + 32 c
+  const int kb = K >> 5;
+  // staging plan: chunk = 16 k-values; thread -> chunk column q = tid & 7, rows (tid >> 3) + 32 c; a 32-block = chunks q, q ^ 1
   const int q = tid & 7, r0 = tid >> 3;
   f32x4 acc[4][4];
 #pragma unroll
@@ -111,35 +98,54 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned short* __r
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   u32x4 xr[4][2], wr[4];
+  unsigned int wsr[4];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = r0 + 32 * c, k = k0 + q * 16;
-      const bool xok = m0 + row < M && k < K, wok = n0 + row < N && k < K;
+      const bool xok = m0 + row < M, wok = n0 + row < N;
       const u32x4 z = {0u, 0u, 0u, 0u};
       xr[c][0] = xok ? *reinterpret_cast<const u32x4*>(X + (long long)(m0 + row) * lda + k) : z;
       xr[c][1] = xok ? *reinterpret_cast<const u32x4*>(X + (long long)(m0 + row) * lda + k + 8) : z;
       wr[c] = wok ? *reinterpret_cast<const u32x4*>(Wq + (long long)(n0 + row) * K + k) : z;
+      wsr[c] = (wok && q == 0) ? *reinterpret_cast<const unsigned int*>(Ws + (long long)(n0 + row) * kb + (k0 >> 5)) : 0u;
     }
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = r0 + 32 * c;
+      // block maximum: this thread's 16 values and its neighbour's (lane ^ 1 holds chunk q ^ 1 of the same row)
+      unsigned int mb = 0u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned int wv = xr[c][h][e];
+          const unsigned int lo = (wv << 16) & 0x7fffffffu, hi = wv & 0x7fff0000u;
+          mb = mb > lo ? mb : lo;
+          mb = mb > hi ? mb : hi;
+        }
+      const unsigned int other = (unsigned int)__builtin_amdgcn_update_dpp((int)mb, (int)mb, 0xB1, 0xf, 0xf, false);
+      mb = mb > other ? mb : other;
+      const unsigned int sb = mx_scale_byte(mb);
+      const float inv = mx_inv_scale(sb);
       float v[8];
       u32x4 o;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * e] = bf16_to_f32((unsigned short)(xr[c][h][e] & 0xffffu)) * sx;
-          v[2 * e + 1] = bf16_to_f32((unsigned short)(xr[c][h][e] >> 16)) * sx;
+          v[2 * e] = bf16_to_f32((unsigned short)(xr[c][h][e] & 0xffffu)) * inv;
+          v[2 * e + 1] = bf16_to_f32((unsigned short)(xr[c][h][e] >> 16)) * inv;
         }
         const u32x2 pk = cvt8_fp8(v);
         o[2 * h] = pk[0]; o[2 * h + 1] = pk[1];
       }
       *reinterpret_cast<u32x4*>(As + row * ROWB + q * 16) = o;
       *reinterpret_cast<u32x4*>(Bs + row * ROWB + q * 16) = wr[c];
+      if ((q & 1) == 0) reinterpret_cast<unsigned char*>(Sx)[row * 4 + (q >> 1)] = (unsigned char)sb;
+      if (q == 0) Sw[row] = wsr[c];
     }
   };
   gload(0);
@@ -148,25 +154,26 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned short* __r
     lstore();
     __syncthreads();
     if (k0 + BK < K) gload(k0 + BK);      // in flight while this tile is multiplied
+    // operand layout of the instruction (pinned by tests/test_gpu_kernels.py::test_mx_mfma_layout through mfp_debug_mx_probe):
+    // lane (row li, group lg) holds k = 16 lg .. + 15 in bytes 0-15 and k = 64 + 16 lg .. + 15 in bytes 16-31, and its
+    // scale register's byte 0 is the scale of the CONTIGUOUS block k = 32 lg .. + 31 of its row
+    i32x8 xf[4], wf[4];
+    int xs[4], ws[4];
 #pragma unroll
-    for (int sp = 0; sp < BK / 64; ++sp) {      // a 16-byte fragment = the operands of two k-steps
-      u32x4 xf[4], wf[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        xf[a] = *reinterpret_cast<const u32x4*>(As + (wm * 64 + a * 16 + li) * ROWB + (sp * 4 + lg) * 16);
-        wf[a] = *reinterpret_cast<const u32x4*>(Bs + (wn * 64 + a * 16 + li) * ROWB + (sp * 4 + lg) * 16);
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const long wa = (long)(((unsigned long long)wf[b][2 * h + 1] << 32) | wf[b][2 * h]);
-            const long xa = (long)(((unsigned long long)xf[a][2 * h + 1] << 32) | xf[a][2 * h]);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wa, xa, acc[a][b], 0, 0, 0);
-          }
+    for (int a = 0; a < 4; ++a) {
+      const int xrow = wm * 64 + a * 16 + li, wrow = wn * 64 + a * 16 + li;
+      const u32x4 x0 = *reinterpret_cast<const u32x4*>(As + xrow * ROWB + lg * 16), x1 = *reinterpret_cast<const u32x4*>(As + xrow * ROWB + 64 + lg * 16);
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(Bs + wrow * ROWB + lg * 16), w1 = *reinterpret_cast<const u32x4*>(Bs + wrow * ROWB + 64 + lg * 16);
+      xf[a] = (i32x8){(int)x0[0], (int)x0[1], (int)x0[2], (int)x0[3], (int)x1[0], (int)x1[1], (int)x1[2], (int)x1[3]};
+      wf[a] = (i32x8){(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+      xs[a] = (int)((Sx[xrow] >> (8 * lg)) & 0xffu);
+      ws[a] = (int)((Sw[wrow] >> (8 * lg)) & 0xffu);
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[b], xf[a], acc[a][b], 0, 0, 0, ws[b], 0, xs[a]);
   }
   // acc[a][b][r] = C[m = 16 a + li][n = 16 b + 4 lg + r] of the wave's 64 x 64 block
 #pragma unroll
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned short* __r
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc[a][b][r] * inv + bb[r];
+        v[r] = acc[a][b][r] + bb[r];
         if (RELU) v[r] = fmaxf(v[r], 0.f);
       }
       *reinterpret_cast<u32x2*>(C + (long long)m * ldc + n) = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -191,40 +198,29 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned short* __r
 
 }  // namespace
 
-extern "C" int mfp_absmax(const void* x, int64_t n, int32_t dtype, float* parts, mfp_stream_t stream) {
-  MFP_CHECK_ARG(x && parts && n > 0 && (dtype == MFP_F32 || dtype == MFP_BF16));
-  MFP_CHECK_ARG(((uintptr_t)x % 16) == 0);
-  hipLaunchKernelGGL(absmax_kernel, dim3(ABSMAX_PARTS), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     (long long)n, dtype == MFP_BF16 ? 1 : 0, parts);
-  MFP_CHECK_LAUNCH();
-  return MFP_OK;
-}
-
-extern "C" int mfp_quantize_fp8(const float* w, int64_t n, const float* parts, uint8_t* out, float* scale_out,
-                                mfp_stream_t stream) {
-  MFP_CHECK_ARG(w && parts && out && scale_out && n > 0 && n % 8 == 0);
+extern "C" int mfp_quantize_mxfp8(const float* w, int64_t rows, int64_t K, uint8_t* out, uint8_t* scales, mfp_stream_t stream) {
+  MFP_CHECK_ARG(w && out && scales && rows > 0 && K > 0 && K % 32 == 0);
   MFP_CHECK_ARG(((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 8) == 0);
-  const int blocks = (int)((n / 8 + 255) / 256 < 1024 ? (n / 8 + 255) / 256 : 1024);
-  hipLaunchKernelGGL(quantize_fp8_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
-                     (long long)n, parts, out, scale_out);
+  const long long nblk = rows * (K / 32);
+  const int blocks = (int)((nblk * 4 + 255) / 256 < 1024 ? (nblk * 4 + 255) / 256 : 1024);
+  hipLaunchKernelGGL(quantize_mxfp8_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, nblk, out, scales);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
 
-extern "C" int mfp_gemm_fp8(const void* X, const uint8_t* Wq, const float* x_parts, const float* w_scale,
-                            const float* bias, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
-                            int32_t relu, mfp_stream_t stream) {
-  MFP_CHECK_ARG(X && Wq && x_parts && w_scale && C && M > 0 && N > 0 && K > 0);
-  MFP_CHECK_ARG(K % 16 == 0 && N % 8 == 0 && lda % 8 == 0 && ldc % 4 == 0 && lda >= K && ldc >= N);
-  MFP_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wq % 16) == 0 && ((uintptr_t)C % 8) == 0);
+extern "C" int mfp_gemm_mxfp8(const void* X, const uint8_t* Wq, const uint8_t* Ws, const float* bias, void* C, int32_t M,
+                              int32_t N, int32_t K, int32_t lda, int32_t ldc, int32_t relu, mfp_stream_t stream) {
+  MFP_CHECK_ARG(X && Wq && Ws && C && M > 0 && N > 0 && K > 0);
+  MFP_CHECK_ARG(K % 128 == 0 && N % 8 == 0 && lda % 8 == 0 && ldc % 4 == 0 && lda >= K && ldc >= N);
+  MFP_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wq % 16) == 0 && ((uintptr_t)Ws % 4) == 0 && ((uintptr_t)C % 8) == 0);
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (relu)
-    hipLaunchKernelGGL(gemm_fp8_kernel<true>, dim3(tiles), dim3(256), 0, st, (const unsigned short*)X, Wq, x_parts, w_scale,
-                       bias, (unsigned short*)C, M, N, K, lda, ldc);
+    hipLaunchKernelGGL(gemm_mxfp8_kernel<true>, dim3(tiles), dim3(256), 0, st, (const unsigned short*)X, Wq, Ws, bias,
+                       (unsigned short*)C, M, N, K, lda, ldc);
   else
-    hipLaunchKernelGGL(gemm_fp8_kernel<false>, dim3(tiles), dim3(256), 0, st, (const unsigned short*)X, Wq, x_parts, w_scale,
-                       bias, (unsigned short*)C, M, N, K, lda, ldc);
+    hipLaunchKernelGGL(gemm_mxfp8_kernel<false>, dim3(tiles), dim3(256), 0, st, (const unsigned short*)X, Wq, Ws, bias,
+                       (unsigned short*)C, M, N, K, lda, ldc);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -93,9 +93,8 @@ SIGNATURES = {
     "mfp_wgrad_group_partial": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "mfp_wgrad_reduce": (c_int32, [POINTER(WgradPending), c_int32, c_void_p]),
     "mfp_wgrad_merged": (c_int32, [POINTER(WgradPending), c_int32, c_int32, c_void_p]),
-    "mfp_absmax": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
-    "mfp_quantize_fp8": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "mfp_gemm_fp8": (c_int32, [c_void_p] * 6 + [c_int32] * 6 + [c_void_p]),
+    "mfp_quantize_mxfp8": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mfp_gemm_mxfp8": (c_int32, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p]),
     "mfp_mlp_fused_fwd": (c_int32, [c_void_p] * 13 + [c_int32, c_int32, c_float, c_float, c_uint64, c_uint64,
                                                    c_void_p, c_void_p]),
     "mfp_attn_block_fwd": (c_int32, [c_void_p] * 15 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
@@ -153,6 +152,7 @@ SIGNATURES = {
     "mfp_mask_tokens": (c_int32, [POINTER(MaskCol), c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
                                   c_int32, c_uint64, c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_debug_tr_probe": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "mfp_debug_mx_probe": (c_int32, [c_void_p] * 6),
 }
 
 _lib = None

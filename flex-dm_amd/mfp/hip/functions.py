@@ -80,11 +80,11 @@ def _fused_ok(ctx, D) -> bool:
 
 def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False, w8=None):
     """``Dense(LayerNormalization(x))`` of a DeepSVG block (transformer.py:216-217 / 222-223): returns
-    (out, y = LN(x) in the compute dtype, mean, rstd).  ``w8`` = (fp8 kernel, scale): fp8 mode."""
+    (out, y = LN(x) in the compute dtype, mean, rstd).  ``w8`` = (fp8 kernel, its e8m0 block scales): fp8 mode."""
     cdt = ctx.cdt
-    if w8 is not None:      # e4m3 operands, per-tensor scales (csrc/gemm_fp8.hip); y stays bf16 for the backward pass
+    if w8 is not None:      # MX block-scaled e4m3 operands (csrc/gemm_fp8.hip); y stays bf16 for the backward pass
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, cdt)
-        return ops.gemm_fp8(y, w8[0], w8[1], T, N, D, bias=bias, relu=relu), y, mean, rstd
+        return ops.gemm_mxfp8(y, w8[0], w8[1], T, N, D, bias=bias, relu=relu), y, mean, rstd
     y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, cdt)
     out = ops.gemm(y, W, T, N, D, a_kmajor=True, b_kmajor=True, bias=bias, relu=relu, out_dtype=cdt)
     return out, y, mean, rstd

@@ -210,36 +210,23 @@ def wgrad_splitk(T: int, M: int, N: int) -> int:
     return sk
 
 
-# ------------------------------------------------------------------------ fp8 forward Dense
-ABSMAX_PARTS = 256
-
-
-def absmax_parts(x: torch.Tensor) -> torch.Tensor:
-    """256 block maxima of |x| (f32 or bf16); consumers turn them into the e4m3 scale 448 / max."""
+# ------------------------------------------------------------------------ fp8 forward Dense (MX block-scaled)
+def quantize_mxfp8(w: torch.Tensor, rows: int, K: int, out: torch.Tensor, scales: torch.Tensor) -> None:
+    """w f32 [rows * K] -> out (uint8) e4m3 elements, scales (uint8 [rows * K / 32]) e8m0 block scales (OCP MX, block 32)."""
     lib = load()
-    parts = torch.empty(ABSMAX_PARTS, dtype=torch.float32, device=x.device)
-    with _timed("absmax_kernel", 0, x.numel() * _esz(x)):
-        check(lib.mfp_absmax(_ptr(x), x.numel(), dt_code(x.dtype), _ptr(parts), _stream()), "mfp_absmax")
-    return parts
+    check(lib.mfp_quantize_mxfp8(_ptr(w), rows, K, _ptr(out), _ptr(scales), _stream()), "mfp_quantize_mxfp8")
 
 
-def quantize_fp8(w: torch.Tensor, out: torch.Tensor, scale_out: torch.Tensor) -> None:
-    """out (uint8 view) = e4m3(scale * w), scale_out[0] = scale = 448 / amax(w) -- per tensor."""
+def gemm_mxfp8(X: torch.Tensor, Wq: torch.Tensor, Ws: torch.Tensor, M: int, N: int, K: int, bias: Optional[torch.Tensor] = None,
+               relu: bool = False) -> torch.Tensor:
+    """bf16 [M, N] = relu?(X @ W^T + bias) as an MX product: X bf16 quantised on the fly (e4m3 elements, e8m0 scale per
+    32 k), Wq [N, K] / Ws [N, K / 32] from quantize_mxfp8."""
     lib = load()
-    parts = absmax_parts(w)
-    check(lib.mfp_quantize_fp8(_ptr(w), w.numel(), _ptr(parts), _ptr(out), _ptr(scale_out), _stream()), "mfp_quantize_fp8")
-
-
-def gemm_fp8(X: torch.Tensor, Wq: torch.Tensor, w_scale: torch.Tensor, M: int, N: int, K: int, bias: Optional[torch.Tensor] = None,
-             relu: bool = False) -> torch.Tensor:
-    """bf16 [M, N] = relu?(X @ W^T + bias) with e4m3 operands (X bf16 quantised on the fly, per-tensor scales)."""
-    lib = load()
-    assert X.dtype == torch.bfloat16 and Wq.dtype == torch.uint8 and X.stride(1) == 1
-    parts = absmax_parts(X)
+    assert X.dtype == torch.bfloat16 and X.stride(1) == 1 and Wq.dtype == torch.uint8 and Ws.dtype == torch.uint8
     out = torch.empty((M, N), dtype=torch.bfloat16, device=X.device)
-    with _timed("gemm_fp8_kernel", 2 * M * N * K, M * K * 2 + N * K + M * N * 2):
-        check(lib.mfp_gemm_fp8(_ptr(X), _ptr(Wq), _ptr(parts), _ptr(w_scale), _ptr(bias), _ptr(out), M, N, K, X.stride(0), N,
-                               int(relu), _stream()), "mfp_gemm_fp8")
+    with _timed("gemm_mxfp8_kernel", 2 * M * N * K, M * K * 2 + N * K + M * N * 2):
+        check(lib.mfp_gemm_mxfp8(_ptr(X), _ptr(Wq), _ptr(Ws), _ptr(bias), _ptr(out), M, N, K, X.stride(0), N, int(relu),
+                                 _stream()), "mfp_gemm_mxfp8")
     return out
 
 

@@ -230,7 +230,7 @@ class ParamStore:
                 q = layout.segments["blocks/seq2seq_%d/attn/dense_query/kernel" % i]
                 f = layout.segments["blocks/seq2seq_%d/mlp/dense_0/kernel" % i]
                 self._fp8_tensors += [(q.offset, 3 * D * D), (f.offset, f.size)]
-            self.scale8 = torch.ones(len(self._fp8_tensors), dtype=torch.float32, device=device)
+            self.scale8 = torch.zeros(n // 32 + 1, dtype=torch.uint8, device=device)      # e8m0 block scales, element offset / 32
         self.l2 = l2
         # (s.l2 is False for the zero pad rows / special rows that are not Keras variables)
         self.seg_l2 = torch.tensor([variable_l2(s.name, l2) if s.l2 else 0.0 for s in layout.segments.values()],
@@ -316,19 +316,23 @@ class ParamStore:
         self.refresh_fp8()
 
     def refresh_fp8(self):
-        """Re-quantise the fp8 weight copies from the f32 master weights (per-tensor scale 448 / amax)."""
+        """Re-quantise the MX fp8 weight copies (e4m3 elements + one e8m0 scale per 32 input features) from the f32
+        master weights.  Kernels are stored [out][in], so a block is 32 consecutive elements of the flat buffer; segment
+        offsets are multiples of 32 (ModelLayout pads), hence the scale of element e sits at e // 32."""
         if not self.fp8:
             return
         from mfp.hip import ops
-        for j, (off, n) in enumerate(self._fp8_tensors):
-            ops.quantize_fp8(self.w[off:off + n], self.shadow8[off:off + n], self.scale8[j:j + 1])
+        K = self.layout.D
+        for off, n in self._fp8_tensors:
+            assert off % 32 == 0 and K % 32 == 0
+            ops.quantize_mxfp8(self.w[off:off + n], n // K, K, self.shadow8[off:off + n], self.scale8[off // 32:(off + n) // 32])
 
     def w8(self, name: str, rows: int):
-        """(fp8 view [rows][in], its scale [1]) of the kernel starting at ``name`` (fp8 mode only)."""
+        """(fp8 view [rows][in], e8m0 scales [rows][in / 32]) of the kernel starting at ``name`` (fp8 mode only)."""
         s = self.layout.segments[name]
-        j = [o for o, _ in self._fp8_tensors].index(s.offset)
         cols = s.shape[-1]
-        return self.shadow8[s.offset:s.offset + rows * cols].view(rows, cols), self.scale8[j:j + 1]
+        return (self.shadow8[s.offset:s.offset + rows * cols].view(rows, cols),
+                self.scale8[s.offset // 32:s.offset // 32 + rows * cols // 32].view(rows, cols // 32))
 
     def refresh_shadow(self):
         if self.shadow is not None:

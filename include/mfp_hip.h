@@ -147,21 +147,19 @@ int mfp_wgrad_reduce(const mfp_wgrad_pending* groups /*host*/, int32_t ngroups, 
  * 6 k-tiles of 64 per k-slice.  Gradients = mfp_wgrad_reduce over the same list. */
 int mfp_wgrad_merged(const mfp_wgrad_pending* groups /*host*/, int32_t ngroups, int32_t K, mfp_stream_t stream);
 
-/* ------------------------------------------------------------------------ fp8 forward Dense
- * BASELINE config c5 ("fp8 MFMA"): the QKV / FFN1 products of a block (transformer.py:85-90,161-166)
- * with OCP e4m3 operands, per-tensor scales and f32 accumulation (v_mfma_f32_16x16x32_fp8_fp8).
- *   mfp_absmax:       parts[MFP_ABSMAX_PARTS] = block maxima of |x| (x f32 or bf16, n elements); the
- *                     consumer reduces them: scale = 448 / max(parts) (no atomics, no zero fill).
- *   mfp_quantize_fp8: out[i] = e4m3(scale * w[i]), *scale_out = scale (weights, once per optimizer step).
- *   mfp_gemm_fp8:     C[M][N] (bf16) = relu?((e4m3(sx X) Wq^T) / (sx sw) + bias), X bf16 [M][lda] quantised
- *                     on the fly with sx from x_parts, Wq fp8 [N][K], sw = *w_scale. K % 16 == 0, N % 8 == 0. */
-#define MFP_ABSMAX_PARTS 256
-int mfp_absmax(const void* x, int64_t n, int32_t dtype, float* parts, mfp_stream_t stream);
-int mfp_quantize_fp8(const float* w, int64_t n, const float* parts, uint8_t* out, float* scale_out,
-                     mfp_stream_t stream);
-int mfp_gemm_fp8(const void* X, const uint8_t* Wq, const float* x_parts, const float* w_scale,
-                 const float* bias, void* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
-                 int32_t relu, mfp_stream_t stream);
+/* ------------------------------------------------------------------------ fp8 forward Dense (MX block-scaled)
+ * BASELINE config c5 ("fp8 MFMA"): the QKV / FFN1 products of a block (transformer.py:85-90,161-166) as OCP
+ * Microscaling products: blocks of 32 consecutive k share one e8m0 scale (the smallest power of two that brings the
+ * block's largest magnitude to <= 448: no saturation) and hold 32 e4m3 elements round-to-nearest-even(v / scale);
+ * v_mfma_scale_f32_16x16x128_f8f6f4, f32 accumulation.
+ *   mfp_quantize_mxfp8: w f32 [rows][K] -> out fp8 [rows][K], scales e8m0 [rows][K / 32] (weights, once per optimizer
+ *                       step; K % 32 == 0).
+ *   mfp_gemm_mxfp8:     C[M][N] (bf16) = relu?(sum over blocks of (scale_x scale_w) (Xq . Wq) + bias): X bf16 [M][lda]
+ *                       quantised on the fly while it is staged (no amax pass), Wq / Ws from mfp_quantize_mxfp8.
+ *                       K % 128 == 0, N % 8 == 0. */
+int mfp_quantize_mxfp8(const float* w, int64_t rows, int64_t K, uint8_t* out, uint8_t* scales, mfp_stream_t stream);
+int mfp_gemm_mxfp8(const void* X, const uint8_t* Wq, const uint8_t* Ws, const float* bias, void* C, int32_t M, int32_t N,
+                   int32_t K, int32_t lda, int32_t ldc, int32_t relu, mfp_stream_t stream);
 
 /* --------------------------------------------------------------------------- fused MLP half (forward)
  * x2 = x1 + Dropout(relu(LN(x1) W1^T + b1) W2^T + b2) in one launch (transformer.py:161-171,222-225),
@@ -494,6 +492,10 @@ int mfp_step_prologue(const float* probs /*host*/, int32_t n, int32_t* tasks, co
 /* Hardware probe (tests only): lane mapping of ds_read_b64_tr_b16.  byte_addr int32 [64]
  * (8-byte aligned offsets into a 4 KiB LDS image whose b16 element e holds e); out u16 [64][4]. */
 int mfp_debug_tr_probe(const int32_t* byte_addr, uint16_t* out, mfp_stream_t stream);
+/* One v_mfma_scale_f32_16x16x128_f8f6f4 (both operands e4m3): a, b uint8 [64 lanes][32], sa, sb int32 [64] (the scale
+ * register of every lane, byte 0 used), out f32 [64 lanes][4]. */
+int mfp_debug_mx_probe(const uint8_t* a, const uint8_t* b, const int32_t* sa, const int32_t* sb, float* out,
+                       mfp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -757,33 +757,102 @@ def test_wgrad_group(T, splitk):
         assert (j["out"]._base[:, j["N"]:] == 7.0).all()
 
 
-@pytest.mark.parametrize("M,N,K,relu", [(1000, 1536, 512, False), (2050, 1024, 512, True), (300, 768, 256, False), (64, 8, 16, True)])
-def test_gemm_fp8(M, N, K, relu):
-    """mfp_gemm_fp8 (BASELINE config c5): e4m3 operands with per-tensor scales 448 / amax, activations
-    quantised on the fly, f32 accumulation -- against a reference that quantises the same way on the host
-    (torch.float8_e4m3fn, round to nearest even), and within the expected e4m3 error of the unquantised product."""
+def test_mx_mfma_layout():
+    """Pins the operand and scale layout of v_mfma_scale_f32_16x16x128_f8f6f4 that csrc/gemm_fp8.hip relies on (one
+    instruction through mfp_debug_mx_probe, e4m3 x e4m3): lane (i = l % 16, g = l / 16) of the A (B) operand holds row
+    (column) i, k = 16 g + t for bytes t < 16 and k = 64 + 16 g + (t - 16) for bytes t >= 16; lane (i, s) of the scale
+    register (byte 0) scales the CONTIGUOUS block k = 32 s .. 32 s + 31 of row i by 2^(byte - 127); D[i][j] sits in
+    lane j + 16 (i / 4), register i % 4."""
+    from mfp import hip
+    lib = hip.load()
+    g = torch.Generator().manual_seed(3)
+    A = (torch.randn(16, 128, generator=g)).to(torch.float8_e4m3fn)
+    B = (torch.randn(16, 128, generator=g)).to(torch.float8_e4m3fn)
+    sa = torch.randint(120, 135, (16, 4), generator=g)
+    sb = torch.randint(120, 135, (16, 4), generator=g)
+
+    def pack(M):      # [16 rows][128 k] -> [64 lanes][32 bytes]
+        Mb = M.view(torch.uint8)
+        out = torch.zeros(64, 32, dtype=torch.uint8)
+        for l in range(64):
+            i, gg = l % 16, l // 16
+            out[l, :16] = Mb[i, 16 * gg:16 * gg + 16]
+            out[l, 16:] = Mb[i, 64 + 16 * gg:64 + 16 * gg + 16]
+        return out
+
+    def pack_scale(S):      # [16 rows][4 blocks] -> [64 lanes] int32
+        return torch.tensor([int(S[l % 16, l // 16]) for l in range(64)], dtype=torch.int32)
+
+    out = torch.zeros(64, 4, device=DEV)
+    dA, dB, dsa, dsb = pack(A).to(DEV), pack(B).to(DEV), pack_scale(sa).to(DEV), pack_scale(sb).to(DEV)
+    rc = lib.mfp_debug_mx_probe(dA.data_ptr(), dB.data_ptr(), dsa.data_ptr(), dsb.data_ptr(), out.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    Ad = (A.double().view(16, 4, 32) * torch.pow(2.0, sa.double() - 127)[:, :, None]).view(16, 128)
+    Bd = (B.double().view(16, 4, 32) * torch.pow(2.0, sb.double() - 127)[:, :, None]).view(16, 128)
+    want = Ad @ Bd.t()
+    got = torch.zeros(16, 16, dtype=torch.float64)
+    o = out.cpu().double()
+    for l in range(64):
+        for r in range(4):
+            got[4 * (l // 16) + r, l % 16] = o[l, r]
+    assert (got - want).abs().max() <= 1e-4 * want.abs().max(), (got - want).abs().max()      # (measured 2e-5: the unit's accumulation)
+
+
+def _mx_quantize_host(x):
+    """MX (block 32 along the last axis; scale = the smallest power of two with max / scale <= 448) on the host:
+    (dequantised values, e4m3 bytes, e8m0 scale bytes)."""
+    R, K = x.shape
+    xb = x.double().reshape(R, K // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    safe = torch.where(amax > 0, amax, torch.ones_like(amax))
+    e = torch.floor(torch.log2(safe))
+    e = e + (safe / torch.pow(torch.tensor(2.0, dtype=torch.float64), e) > 1.75).double()      # no saturation: max <= 448
+    sb = torch.where(amax > 0, (e + 127 - 8).clamp(min=0, max=254), torch.zeros_like(e))
+    scale = torch.pow(torch.tensor(2.0, dtype=torch.float64), sb - 127)
+    q = (xb / scale).clamp(-448, 448).float().to(torch.float8_e4m3fn)
+    return (q.double() * scale).reshape(R, K), q.reshape(R, K).view(torch.uint8), sb.reshape(R, K // 32).to(torch.uint8)
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 1536, 512, False), (2050, 1024, 512, True), (300, 768, 256, False), (64, 8, 128, True)])
+def test_gemm_mxfp8(M, N, K, relu):
+    """mfp_gemm_mxfp8 (BASELINE config c5, v_mfma_scale_f32_16x16x128_f8f6f4): OCP MX block-scaled e4m3 operands -- weights
+    quantised by mfp_quantize_mxfp8 (bytes and scales BIT-identical to the host's MX quantisation), activations quantised on
+    the fly -- against the double product of the host-quantised operands (pins the instruction's operand / scale layout),
+    and within the expected e4m3 error of the unquantised product.  Rows with very different magnitudes and an all-zero
+    block: per-block scales keep every row's mantissa range."""
     ops = _ops()
     g = torch.Generator().manual_seed(M + N + K)
-    X = bf16_round(torch.randn(M, K, generator=g) * 1.7)
-    W = torch.randn(N, K, generator=g) * 0.05
+    X = torch.randn(M, K, generator=g) * 1.7 * torch.exp2(torch.randint(-6, 7, (M, 1), generator=g).float())
+    X[:, 32:64] = 0.0
+    X = bf16_round(X)
+    W = torch.randn(N, K, generator=g) * 0.05 * torch.exp2(torch.randint(-3, 4, (N, 1), generator=g).float())
     bias = torch.randn(N, generator=g) * 0.1
-    Wd = W.to(DEV)
     Wq = torch.empty(N * K, dtype=torch.uint8, device=DEV)
-    wscale = torch.zeros(1, device=DEV)
-    ops.quantize_fp8(Wd.reshape(-1), Wq, wscale)
-    sw, sx = 448.0 / W.abs().max().item(), 448.0 / X.abs().max().item()
-    assert abs(wscale.item() - sw) <= 1e-5 * sw
-    Wq_ref = (W * sw).to(torch.float8_e4m3fn)
-    assert torch.equal(Wq.cpu().view(N, K), Wq_ref.view(torch.uint8))
-    out = ops.gemm_fp8(X.to(DEV, torch.bfloat16), Wq.view(N, K), wscale, M, N, K, bias=bias.to(DEV), relu=relu)
-    Xq_ref = (X * sx).to(torch.float8_e4m3fn)
-    want = (Xq_ref.double() @ Wq_ref.double().t()) / (sx * sw) + bias.double()
+    Ws = torch.empty(N * K // 32, dtype=torch.uint8, device=DEV)
+    ops.quantize_mxfp8(W.to(DEV).reshape(-1), N, K, Wq, Ws)
+    Wdq, Wq_ref, Ws_ref = _mx_quantize_host(W)
+    assert torch.equal(Ws.cpu().view(N, K // 32), Ws_ref)
+    assert torch.equal(Wq.cpu().view(N, K), Wq_ref)
+    out = ops.gemm_mxfp8(X.to(DEV, torch.bfloat16), Wq.view(N, K), Ws.view(N, K // 32), M, N, K, bias=bias.to(DEV), relu=relu)
+    Xdq, _, _ = _mx_quantize_host(X)
+    want = Xdq @ Wdq.t() + bias.double()
     exact = X.double() @ W.double().t() + bias.double()
     if relu:
         want, exact = want.clamp(min=0), exact.clamp(min=0)
-    assert_close(out, want, 2e-2, 1e-2, "fp8 product vs host-quantised reference")      # + one bf16 rounding of the output
-    rel = (out.float().cpu().double() - exact).norm() / exact.norm()
-    assert rel < 0.06, rel                      # e4m3: 3 mantissa bits on both operands
+    # |error| <= bf16 rounding of the output + f32 accumulation: relative to each ROW's scale (rows differ by 2^12)
+    got = out.float().cpu().double()
+    row_scale = want.abs().amax(1, keepdim=True).clamp(min=1e-30)
+    assert ((got - want).abs() / row_scale).max() < 1e-2, ((got - want).abs() / row_scale).max()
+    if N >= 64:
+        rel = ((got - exact).norm(dim=1) / exact.norm(dim=1).clamp(min=1e-30)).max()
+    else:      # (a row of 8 outputs under a ReLU is no statistic: the whole matrix, rows equalised)
+        rs = exact.abs().amax(1, keepdim=True).clamp(min=1e-30)
+        rel = ((got - exact) / rs).norm() / (exact / rs).norm()
+    # e4m3: 3 mantissa bits on both operands -> ~3.6 % rms per element, ~5 % per product term, and a sum of randomly
+    # signed terms inherits the terms' relative error; EVERY row meets it (block scales)
+    assert rel < 0.08, rel
 
 
 @pytest.mark.parametrize("T,p", [(4096, 0.1), (1000, 0.0), (33, 0.1), (128 * 3 + 5, 0.1)])
