@@ -12,6 +12,8 @@ JSON line.
 
 Configurations (BASELINE.json `configs`, SURVEY.md section 8 shorthand; documents per GPU are fixed as
 N grows = weak scaling):
+  c1  RICO masking_method=random, d_model 128, 2 blocks, seq_len 32, 8 documents (the reference's own CPU-runnable case:
+      launch-bound on a GPU; d_model 128 runs on the generic tile kernels, "fused_path": false)
   c2 (default; the configuration the metric is quoted on)  Crello Ours-IMP: masking_method=random,
      d_model 256, 4 blocks, seq_len 128, 256 documents/GPU, bf16 MFMA operands + f32 accumulation
   c3  c2 with masking_method=elem_pos_attr_img_txt (Ours-EXP: all five task types active)
@@ -59,6 +61,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "flex-dm_amd"))
 
 CONFIGS = {
+    "c1": dict(name="RICO", dataset="rico", masking_method="random", D=128, L=2, S=32, B=8, dtype="bf16"),
     "c2": dict(name="Crello Ours-IMP", masking_method="random", D=256, L=4, S=128, B=256, dtype="bf16"),
     "c3": dict(name="Crello Ours-EXP", masking_method="elem_pos_attr_img_txt", D=256, L=4, S=128, B=256, dtype="bf16"),
     "c4": dict(name="Crello Ours-IMP (global batch 1024 at 8 GPUs)", masking_method="random", D=256, L=4, S=128, B=128,
@@ -112,7 +115,7 @@ def family(kernel_name):
 # device-kernel name (as the tracer reports it) -> the family name the library calls are booked under (ops._timed)
 _KERNEL_FAMILY = (("attn_bwd", "attn_bwd"), ("attn_fwd", "attn_fwd"), ("ce_tile_kernel", "loss_kernels"),
                   ("mse_kernel", "loss_kernels"), ("zero_sums_kernel", "loss_kernels"),
-                  ("dgrad_half_kernel", "dgrad_qkv_kernel"), ("gemm_wgm_kernel", "gemm_wgg_kernel"), ("adam_norm_kernel", "adam_kernels"),
+                  ("dgrad_half_kernel", "dgrad_qkv_kernel"), ("adam_norm_kernel", "adam_kernels"),
                   ("adam_update_kernel", "adam_kernels"), ("transpose_cast_kernel", "cast_kernel"),
                   ("embed_fwd_lds_kernel", "embed_fwd_kernel"), ("embed_onehot_kernel", "embed_fwd_kernel"),
                   ("reduce_rows", "reduce_partials_batch"), ("step_prologue_kernel", "mask_kernel"))
@@ -226,12 +229,12 @@ def cpu_baseline(ic, cfg):
     from mfp.data.spec import make_input_columns
     D, L, S = cfg["D"], cfg["L"], cfg["S"]
     threads = torch.get_num_threads()
-    B = 32 if D <= 256 else 8
+    B = min(cfg["B"], 32 if D <= 256 else 8)
     v, ms, n = _cpu_steps(ic, D, L, S, B, budget_s=9.0)
     out = {"value": v, "unit": "elements/s", "cores": threads, "kind": "port", "ms_per_step": ms,
-           "sample": "%d train steps of the eager torch-CPU f32 restatement (oracle/torch_ref.py), Crello "
+           "sample": "%d train steps of the eager torch-CPU f32 restatement (oracle/torch_ref.py), %s "
                      "D=%d L=%d S=%d, B=%d documents/step (B reduced from %d to bound the sample), "
-                     "dropout 0.1, masking_method=random" % (n, D, L, S, B, cfg["B"])}
+                     "dropout 0.1, masking_method=random" % (n, cfg.get("dataset", "crello"), D, L, S, min(B, cfg["B"]), cfg["B"])}
     try:
         torch.set_num_threads(1)
         v1, ms1, n1 = _cpu_steps(ic, D, L, S, 2, budget_s=6.0, min_steps=1)
@@ -241,7 +244,8 @@ def cpu_baseline(ic, cfg):
             # eager ops this small are slowed down by the thread pool: the better CPU figure is the one-thread run;
             # quote it as the baseline and keep the all-threads run beside it
             out, allthr = dict(one, kind="port", sample=one["sample"] + " of the eager torch-CPU f32 restatement "
-                               "(oracle/torch_ref.py), Crello D=%d L=%d S=%d, dropout 0.1, masking_method=random" % (D, L, S)), out
+                               "(oracle/torch_ref.py), %s D=%d L=%d S=%d, dropout 0.1, masking_method=random"
+                               % (cfg.get("dataset", "crello"), D, L, S)), out
             out["all_threads"] = {k: allthr[k] for k in ("value", "unit", "cores", "ms_per_step", "sample")}
         else:
             out["one_thread"] = one
@@ -311,7 +315,7 @@ def main():
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     torch.manual_seed(1234 + rank)
 
-    ic = make_input_columns("crello")
+    ic = make_input_columns(cfg.get("dataset", "crello"))
     batch = synthetic_batch(ic, B, S, seed=rank, ragged=False, device=device)
     extra = {}
     if dtype in ("bf16", "fp8") and rank == 0 and not args.no_roofline:
@@ -401,6 +405,7 @@ def main():
         "config": {"workload": "%s (%s) train step, masking_method=%s: d_model=%d, %d DeepSVG blocks, seq_len=%d, "
                                "%d documents/GPU, dropout 0.1, l2 1e-2, Adam lr 1e-4 clipnorm 1.0"
                                % (cfg["name"], args.config, masking_method, D, NB, S, B),
+                   "dataset": cfg.get("dataset", "crello"),
                    "name": args.config, "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay" if graphed else "eager",
                    "params": lay.numel, "train_flop_per_element": fpe},

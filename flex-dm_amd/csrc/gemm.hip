@@ -489,7 +489,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #include "gemm_ws.h"
 #include "gemm_wg.h"
 #include "gemm_wgg.h"
-#include "gemm_wgm.h"
 
 int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
   static int ncu_of[MFP_MAX_DEVICES] = {};
@@ -815,8 +814,7 @@ extern "C" int mfp_wgrad_reduce(const mfp_wgrad_pending* groups, int32_t ngroups
       tile0 += ((j.M + 127) / 128) * d.tiles_n;
     }
     for (int i = s.njobs; i < WGG_MAX_JOBS; ++i) { G.job[i] = G.job[0]; G.job[i].tile0 = 0x7FFFFFFF; }
-    MFP_CHECK_ARG(s.layout == 0 || s.layout == 1);
-    G.njobs = s.njobs; G.ntiles = tile0; G.splitk = s.splitk; G.unit0 = unit0; G.layout = s.layout; G.pad_ = 0;
+    G.njobs = s.njobs; G.ntiles = tile0; G.splitk = s.splitk; G.unit0 = unit0;
     G.zstride = (long long)tile0 * 128 * 128 + WGG_ZPAD;
     G.ws = reinterpret_cast<const float*>(s.workspace);
     G.ws_col = G.ws + (size_t)s.splitk * G.zstride;
@@ -825,56 +823,6 @@ extern "C" int mfp_wgrad_reduce(const mfp_wgrad_pending* groups, int32_t ngroups
   for (int gi = ngroups; gi < WGR_MAX_GROUPS; ++gi) { p.g[gi] = p.g[0]; p.g[gi].unit0 = 0x7FFFFFFF; }
   p.ngroups = ngroups; p.nunits = unit0;
   hipLaunchKernelGGL(wgg_reduce_kernel, dim3(unit0), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
-  MFP_CHECK_LAUNCH();
-  return MFP_OK;
-}
-
-// Every pending group's partial tiles in ONE persistent launch (gemm_wgm.h); the gradients follow from
-// mfp_wgrad_reduce over the same groups with layout = 1.
-extern "C" int mfp_wgrad_merged(const mfp_wgrad_pending* groups, int32_t ngroups, int32_t K, mfp_stream_t stream) {
-  MFP_CHECK_ARG(groups != nullptr && ngroups >= 1 && ngroups <= WGM_MAX_GROUPS && K > 0);
-  WgmParams p;
-  const int ktiles = (K + 63) / 64;
-  int nj = 0, base = 0, total = 0;
-  int nwg = wgg_ncu() / 8 * 8;
-  if (nwg < 8) nwg = 8;
-  for (int gi = 0; gi < ngroups; ++gi) {
-    const mfp_wgrad_pending& s = groups[gi];
-    MFP_CHECK_ARG(s.jobs != nullptr && s.njobs >= 1 && s.njobs <= MFP_MAX_WGRAD_JOBS && nj + s.njobs <= WGM_MAX_JOBS);
-    MFP_CHECK_ARG(s.splitk == 1 || s.splitk == 2 || s.splitk == 4 || (s.splitk >= 8 && s.splitk % 8 == 0));
-    MFP_CHECK_ARG(s.workspace != nullptr && ((uintptr_t)s.workspace % 16) == 0 && s.layout == 1);
-    MFP_CHECK_ARG(ktiles / s.splitk >= WGG_XD + 2);      // every k-slice longer than the pipeline is deep
-    WgmGroup& G = p.grp[gi];
-    int tile0 = 0, fresh = 0;
-    for (int i = 0; i < s.njobs; ++i) {
-      const mfp_wgrad_job& j = s.jobs[i];
-      MFP_CHECK_ARG(j.A && j.B && j.M > 0 && j.N > 0);
-      MFP_CHECK_ARG(j.M % 8 == 0 && j.N % 8 == 0 && j.lda % 8 == 0 && j.ldb % 8 == 0 && j.lda >= j.M && j.ldb >= j.N);
-      MFP_CHECK_ARG(((uintptr_t)j.A % 16) == 0 && ((uintptr_t)j.B % 16) == 0);
-      MFP_CHECK_ARG((long long)K * j.lda * 2 < 0x7FFFFFF0ll && (long long)K * j.ldb * 2 < 0x7FFFFFF0ll);   // 32-bit offsets
-      WgmJob& d = p.job[nj + i];
-      d.A = reinterpret_cast<const unsigned short*>(j.A); d.B = reinterpret_cast<const unsigned short*>(j.B);
-      d.rowcode = j.rowcode; d.M = j.M; d.N = j.N; d.lda = j.lda; d.ldb = j.ldb;
-      d.tiles_n = (j.N + 127) / 128; d.tile0 = tile0; d.colsum = j.colsum != nullptr ? 1 : 0; d.pad_ = 0;
-      tile0 += ((j.M + 127) / 128) * d.tiles_n;
-      if (j.rowcode != nullptr) fresh = 1;
-    }
-    if (fresh) MFP_CHECK_ARG((ktiles + s.splitk - 1) / s.splitk * 64 <= WG_MAX_KCHUNK);
-    G.job0 = nj; G.njobs = s.njobs; G.ntiles = tile0; G.splitk = s.splitk; G.fresh = fresh;
-    G.tpg = s.splitk < 8 ? (tile0 * s.splitk + 7) / 8 : 0;
-    G.units = s.splitk >= 8 ? tile0 * s.splitk : 8 * G.tpg;
-    G.base = base % nwg;
-    G.zstride = (long long)tile0 * 128 * 128 + WGG_ZPAD;
-    G.ws = reinterpret_cast<float*>(const_cast<void*>(s.workspace));
-    G.ws_col = G.ws + (size_t)s.splitk * G.zstride;
-    base += G.units; total += G.units;
-    nj += s.njobs;
-  }
-  for (int i = nj; i < WGM_MAX_JOBS; ++i) p.job[i] = p.job[0];
-  for (int gi = ngroups; gi < WGM_MAX_GROUPS; ++gi) { p.grp[gi] = p.grp[0]; p.grp[gi].units = 0; }
-  p.ngroups = ngroups; p.K = K; p.nwg = total < nwg ? (total + 7) / 8 * 8 : nwg; p.pad_ = 0;
-  for (int gi = 0; gi < ngroups; ++gi) p.grp[gi].base %= p.nwg;
-  if (int rc = launch_wgm(p, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -351,7 +351,6 @@ struct WgrGroup {
   const float* ws; const float* ws_col;
   long long zstride;
   int splitk, ntiles, unit0, njobs;
-  int layout, pad_;             // 0: slabs are row-major tiles (gemm_wgg_kernel); 1: accumulator order (gemm_wgm_kernel)
   WgrJob job[WGG_MAX_JOBS];
 };
 struct WgrParams { WgrGroup g[WGR_MAX_GROUPS]; int ngroups, nunits; };
@@ -373,14 +372,8 @@ __global__ __launch_bounds__(256) void wgg_reduce_kernel(WgrParams p) {
   int off[2], rowh[2], colh[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (G.layout == 0) {
-      rowh[h] = slice * 16 + (tid >> 5) + 8 * h; colh[h] = (tid & 31) * 4;
-      off[h] = rowh[h] * 128 + colh[h];
-    } else {      // float4 f = ((wave * 16 + a * 4 + b) * 64 + lane) of gemm_wgm_kernel's accumulator dump
-      const int f = slice * 512 + h * 256 + tid, q = f >> 10, a = (f >> 8) & 3, b = (f >> 6) & 3, ln = f & 63;
-      rowh[h] = (q >> 1) * 64 + a * 16 + (ln & 15); colh[h] = (q & 1) * 64 + (ln >> 4) * 16 + b * 4;
-      off[h] = f * 4;
-    }
+    rowh[h] = slice * 16 + (tid >> 5) + 8 * h; colh[h] = (tid & 31) * 4;
+    off[h] = rowh[h] * 128 + colh[h];
   }
   const float* src = G.ws + (long long)tile * (128 * 128);
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};

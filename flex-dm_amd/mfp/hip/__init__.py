@@ -50,8 +50,7 @@ class WgradJob(Structure):
 
 
 class WgradPending(Structure):
-    _fields_ = [("jobs", POINTER(WgradJob)), ("njobs", c_int32), ("splitk", c_int32), ("workspace", c_void_p),
-                ("layout", c_int32)]
+    _fields_ = [("jobs", POINTER(WgradJob)), ("njobs", c_int32), ("splitk", c_int32), ("workspace", c_void_p)]
 
 
 class ReduceJob(Structure):
@@ -92,7 +91,6 @@ SIGNATURES = {
     "mfp_wgrad_group": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mfp_wgrad_group_partial": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "mfp_wgrad_reduce": (c_int32, [POINTER(WgradPending), c_int32, c_void_p]),
-    "mfp_wgrad_merged": (c_int32, [POINTER(WgradPending), c_int32, c_int32, c_void_p]),
     "mfp_quantize_mxfp8": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mfp_gemm_mxfp8": (c_int32, [c_void_p] * 5 + [c_int32] * 6 + [c_void_p]),
     "mfp_mlp_fused_fwd": (c_int32, [c_void_p] * 13 + [c_int32, c_int32, c_float, c_float, c_uint64, c_uint64,

@@ -280,12 +280,6 @@ def wgrad_group_splitk(jobs: Sequence[dict], K: int) -> int:
     return int(load().mfp_wgrad_group_splitk(_wgrad_jobs_array(jobs), len(jobs), K))
 
 
-# deferred groups are not launched one by one: wgrad_reduce runs ALL of them as one persistent launch (mfp_wgrad_merged,
-# csrc/gemm_wgm.h) in front of the reduction; "0" = one mfp_wgrad_group_partial launch per group (A/B switch)
-WGRAD_MERGE = os.environ.get("MFP_WGRAD_MERGE", "0") == "1"
-WGRAD_MERGE_MAX_JOBS = 40
-
-
 def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defer: Optional[list] = None) -> None:
     """``out_j[M_j, N_j] = A_j[K, M_j]^T @ B_j[K, N_j]`` (+ ``colsum_j[M_j] = sum_k A_j``) for up to 8 jobs
     in ONE launch -- see ``mfp_wgrad_group`` in include/mfp_hip.h.  jobs: dicts with A, B (bf16
@@ -317,14 +311,9 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defe
     if defer is not None:
         assert len(defer) < WGRAD_MAX_PENDING, "flush the pending weight-gradient groups first (wgrad_reduce)"
         ws = _deferred_workspace(need, dev, len(defer))
-        # one persistent launch for all pending groups (at the flush) when every k-slice is longer than the pipeline is
-        # deep and the job table fits; else this group's own launch now
-        lazy = (WGRAD_MERGE and ((K + 63) // 64) // splitk >= 6
-                and sum(r["n"] for r in defer) + n <= WGRAD_MERGE_MAX_JOBS and all(r["K"] == K for r in defer))
-        if not lazy:
-            with _timed("gemm_wgg_kernel", flops, nbytes):
-                check(lib.mfp_wgrad_group_partial(arr, n, K, splitk, ws.data_ptr(), ws.numel(), _stream()), "mfp_wgrad_group_partial")
-        defer.append(dict(arr=arr, n=n, splitk=splitk, ws=ws, K=K, lazy=lazy, flops=flops, opbytes=nbytes, scope=_scope[-1],
+        with _timed("gemm_wgg_kernel", flops, nbytes):
+            check(lib.mfp_wgrad_group_partial(arr, n, K, splitk, ws.data_ptr(), ws.numel(), _stream()), "mfp_wgrad_group_partial")
+        defer.append(dict(arr=arr, n=n, splitk=splitk, ws=ws, scope=_scope[-1],
                           keep=[(j["A"], j["B"], j["out"], j.get("colsum"), j.get("rowskip")) for j in jobs],
                           nbytes=need + sum(j["M"] * j["N"] * 4 for j in jobs)))
         return
@@ -345,13 +334,7 @@ def wgrad_reduce(pending: list) -> None:
     nbytes = 0
     for i, rec in enumerate(pending):
         arr[i].jobs, arr[i].njobs, arr[i].splitk, arr[i].workspace = rec["arr"], rec["n"], rec["splitk"], rec["ws"].data_ptr()
-        arr[i].layout = 1 if rec["lazy"] else 0
         nbytes += rec["nbytes"]
-    lazy = [i for i, rec in enumerate(pending) if rec["lazy"]]
-    if lazy:      # the groups that were only recorded: their partial tiles now, in one persistent launch
-        sub = (WgradPending * len(lazy))(*[arr[i] for i in lazy])
-        with _timed("gemm_wgg_kernel", split=[(pending[i]["scope"], pending[i]["flops"], pending[i]["opbytes"]) for i in lazy]):
-            check(lib.mfp_wgrad_merged(sub, len(lazy), pending[lazy[0]]["K"], _stream()), "mfp_wgrad_merged")
     with _timed("wgg_reduce_kernel", split=[(rec["scope"], 0, rec["nbytes"]) for rec in pending]):
         check(lib.mfp_wgrad_reduce(arr, n, _stream()), "mfp_wgrad_reduce")
     pending.clear()

@@ -133,19 +133,11 @@ int mfp_wgrad_group(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K
 typedef struct mfp_wgrad_pending {
   const mfp_wgrad_job* jobs;   /* host */
   int32_t njobs, splitk;
-  const void* workspace;       /* device: what mfp_wgrad_group_partial / mfp_wgrad_merged filled (or will fill) */
-  int32_t layout;              /* of the slabs: 0 = mfp_wgrad_group_partial's, 1 = mfp_wgrad_merged's */
+  const void* workspace;       /* device: what mfp_wgrad_group_partial filled */
 } mfp_wgrad_pending;
 int mfp_wgrad_group_partial(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t splitk,
                             void* workspace, size_t workspace_bytes, mfp_stream_t stream);
 int mfp_wgrad_reduce(const mfp_wgrad_pending* groups /*host*/, int32_t ngroups, mfp_stream_t stream);
-/* The partial tiles of ALL the listed groups (<= 12 groups, <= 40 jobs in total, each group with its own workspace of
- * mfp_wgrad_group_workspace_bytes(), layout = 1) in ONE persistent launch: the (tile, k-slice) units of every group are
- * dealt to one workgroup per CU, which walks them without refilling its pipeline between units -- the six grouped
- * launches of a c2 step become one (no per-launch fill / drain, and the heads / encoder groups, 176 / 112 units for 256
- * CUs, no longer leave a third of the chip idle for a launch each).  K: tokens, the same for every group, at least
- * 6 k-tiles of 64 per k-slice.  Gradients = mfp_wgrad_reduce over the same list. */
-int mfp_wgrad_merged(const mfp_wgrad_pending* groups /*host*/, int32_t ngroups, int32_t K, mfp_stream_t stream);
 
 /* ------------------------------------------------------------------------ fp8 forward Dense (MX block-scaled)
  * BASELINE config c5 ("fp8 MFMA"): the QKV / FFN1 products of a block (transformer.py:85-90,161-166) as OCP

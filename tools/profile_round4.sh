@@ -22,10 +22,11 @@ rm -rf $O/pmc_mfma
 python bench.py --steps 100 --warmup 10 2>/dev/null | tail -1 > $O/r04_bench_c2.json
 python bench.py --steps 100 --warmup 10 --config c3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_c3.json
 python bench.py --steps 100 --warmup 10 --config c4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_c4_1gpu.json
+python bench.py --steps 100 --warmup 10 --config c1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_c1.json
 python bench.py --steps 30 --warmup 5 --config c5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_c5_fp8.json
 python bench.py --steps 30 --warmup 5 --config c5 --dtype bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r04_bench_c5_bf16.json
 head -30 $O/r04_kernel_stats.csv; tail -3 $O/r04_pmc_traffic_summary.txt; tail -25 $O/r04_pmc_mfma_lds.txt; python -c "
 import json
-for n in ('c2','c3','c4_1gpu','c5_fp8','c5_bf16'):
+for n in ('c1','c2','c3','c4_1gpu','c5_fp8','c5_bf16'):
     d=json.load(open('$O/r04_bench_%s.json'%n)); print(n, round(d['ms_per_step'],3), round(d['value']), (d.get('roofline') or {}).get('encoder_block',{}).get('mfma_frac'))
 "
