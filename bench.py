@@ -23,7 +23,8 @@ N grows = weak scaling):
 
 Timed region: K hipGraph replays of the captured step between two device synchronisations (+ barriers for N > 1);
 `value` = elements of all ranks / that wall time; `ms_per_step_median` = median of the per-step HIP-event intervals of
-the same loop (SURVEY.md section 8d asks for the median; the two agree within the run-to-run jitter).  The loop ROTATES
+a second pass over the same K steps (SURVEY.md section 8d asks for the median; an event between two graph launches
+costs ~5 us of queue time, so the events stay out of the timed region; the two agree within that).  The loop ROTATES
 `--resident` (default 4) input batches that sit in HBM, each with its own capture of the same step: 4 x 136 MB of f32
 embeddings do not fit the 256 MB infinity cache, so every step's inputs are read from HBM like a loader-fed run's
 (`input_residency` on the line; `--resident 1` = the single re-masked batch of rounds 1-3).
@@ -359,17 +360,30 @@ def main():
         batches = [batch]
     for i in range(args.warmup):
         model.train_step(batches[i % len(batches)])
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # K steps = K / R replays of the graph that steps through the R resident batches (one graph-launch gap per R steps)
+    # when R divides K, else K single-step replays
+    grouped = graphed and len(batches) > 1 and args.steps % len(batches) == 0 and hasattr(model, "train_steps_resident")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        sums = model.train_step(batches[i % len(batches)])
-        marks[i + 1].record()
+    if grouped:
+        for _ in range(args.steps // len(batches)):
+            sums = model.train_steps_resident()
+    else:
+        for i in range(args.steps):
+            sums = model.train_step(batches[i % len(batches)])
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    # the median of per-step intervals: a SECOND pass of the same K steps with an event between consecutive steps (an
+    # event record between two graph launches costs ~5 us of queue time per step: not inside the timed region above)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for i in range(args.steps):
+        model.train_step(batches[i % len(batches)])
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    barrier()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if world > 1:
@@ -407,7 +421,7 @@ def main():
                                % (cfg["name"], args.config, masking_method, D, NB, S, B),
                    "dataset": cfg.get("dataset", "crello"),
                    "name": args.config, "global_batch": world * B, "seq_len": S, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay" if graphed else "eager",
+                   "launch": ("hipGraph replay, %d steps per graph" % len(batches) if grouped else "hipGraph replay") if graphed else "eager",
                    "params": lay.numel, "train_flop_per_element": fpe},
         "final_loss": metrics["loss"],
         "params_in_sync": in_sync,

@@ -344,8 +344,9 @@ class MFP:
         running under the next segment.
 
         ``resident`` > 1 (single-rank replay only): that many input buffer sets, each with its own capture of the same
-        step over the same activation pool; ``self.static_batches[i]`` are the buffers a loader fills, and the replay
-        function runs the capture whose buffers it is handed (bench.py rotates them so that a step's 4 KB per element of
+        step over the same activation pool; ``self.static_batches[i]`` are the buffers a loader fills, the replay
+        function runs the capture whose buffers it is handed, and ``self.train_steps_resident()`` runs ONE graph that steps
+        through all of them in order (bench.py rotates them so that a step's 4 KB per element of
         inputs come from HBM, not from the infinity cache a single re-masked batch would sit in)."""
         assert self.optimizer is not None, "call compile() first"
         if resident > 1 and dp.world_size() == 1:
@@ -454,6 +455,20 @@ class MFP:
                 self._apply()
             graphs.append(g)
             sums.append(s_)
+        # ... and ONE graph that steps through all the buffer sets in order: a training loop that has `resident` batches
+        # staged pays the graph-launch gap (~8-13 us of idle queue between two replays) once per `resident` steps
+        gall = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gall, stream=side, pool=graphs[0].pool()):
+            for static in statics:
+                all_sums = self._forward_backward(static)
+                self._apply()
+
+        def replay_all():
+            gall.replay()
+            self.last_sums = all_sums
+            return all_sums
+
+        self.train_steps_resident = replay_all
         by_ptr = {st["left"].data_ptr(): i for i, st in enumerate(statics)}
 
         def replay(batch):

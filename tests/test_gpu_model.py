@@ -312,25 +312,39 @@ def test_two_rank_step_on_one_gpu_over_gloo(tmp_path):
     assert d["params_in_sync"] is True
 
 
-def test_split_backward_equals_single_backward():
-    """The data-parallel step cuts the backward pass at block inputs (gradients of the segments already done are
+@pytest.mark.parametrize("B,S,D,res16", [(8, 32, 128, True), (4, 128, 256, True), (4, 128, 256, False)])
+def test_split_backward_equals_single_backward(B, S, D, res16):
+    """(Also at the timed widths -- d_model 256, S = 128: document-tile block kernels, the one-launch heads + losses with the
+    hand-off of the last block's masked gradient, deferred split-K reductions flushed per segment -- with the residual
+    gradient travelling in bf16 through StepCtx and in f32 through autograd.)
+    The data-parallel step cuts the backward pass at block inputs (gradients of the segments already done are
     all-reduced while the next segment runs; mfp.dp.bucket_cut_blocks): the chain autograd.grad(loss, x_3),
     autograd.grad(x_3, x_2, d_3), ..., x_1.backward(d_1) must leave exactly the gradients of one loss.backward(),
     and after every segment exactly that segment's bucket of the flat buffer is final."""
     from mfp import dp
     from mfp.data.spec import make_input_columns, synthetic_batch
     from mfp.models.mfp import MFP
+    from mfp.hip import functions
     ic = make_input_columns("crello")
-    B, S = 8, 32
     batch = synthetic_batch(ic, B, S, seed=3, ragged=True, device=DEV)
-    model = MFP(ic, num_blocks=4, latent_dim=128, dropout=0.1, l2=1e-2, masking_method="random",
+    model = MFP(ic, num_blocks=4, latent_dim=D, dropout=0.1, l2=1e-2, masking_method="random",
                 dtype="bf16", device=DEV)
     model.compile(learning_rate=1e-3)
     g = model.model.store.g
     layout = model.model.layout
+    old16 = functions.RES_GRAD_BF16
+    functions.RES_GRAD_BF16 = res16
+    try:
+        _split_backward_body(model, batch, g, layout)
+    finally:
+        functions.RES_GRAD_BF16 = old16
+
+
+def _split_backward_body(model, batch, g, layout):
+    from mfp import dp
     g.fill_(float("nan"))
     loss, sums, ctx = model._forward(batch)     # the step counter does not move: same masks / dropout
-    loss.backward()
+    loss.backward(model._unit_grad(loss))
     model._join_sides()
     torch.cuda.synchronize()
     ref, ref_sums = g.clone(), sums.clone()
@@ -343,7 +357,7 @@ def test_split_backward_equals_single_backward():
         loss, sums, ctx = model._forward(batch)
         assert all(i in ctx.cuts for i in cuts)
         x_prev = ctx.cuts[cuts[0]]
-        d_prev = torch.autograd.grad(loss, x_prev)[0]
+        d_prev = torch.autograd.grad(loss, x_prev, grad_outputs=model._unit_grad(loss))[0]
         for k in range(len(cuts)):
             ctx.flush_ln_jobs()          # as capture_train_step does before a bucket's all-reduce
             model._join_sides()
