@@ -169,7 +169,7 @@ def pmc_traffic(fam):
         return None, None
     tot, calls = 0.0, 0.0
     for k, v in table.items():
-        if family(k) == fam:
+        if kernel_family(k) == fam or family(k) == fam:      # (device-kernel name -> the family the library calls are booked under)
             tot += (v["read_mb"] + v["write_mb"]) * 1e6
             calls += v["calls_per_step"]
     return (tot / calls, calls) if calls else (None, None)
