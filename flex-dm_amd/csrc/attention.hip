@@ -808,8 +808,7 @@ int fwd_hd(const void* qkv, const int* nvalid, void* out, float* lse, int B, int
     constexpr int LDH = (HD < 32 ? 32 : HD) + 8;
     const int SP = (S + 31) & ~31;
     size_t lds = (size_t)3 * SP * LDH * sizeof(bf16_t) + (size_t)SP * sizeof(float);
-    static const int fwd_threads = getenv("MFP_ATTN_FWD_THREADS") ? atoi(getenv("MFP_ATTN_FWD_THREADS")) : 512;   // 8 waves: one 16-query tile each at S = 128 (measured 20.0 vs 21.0 us with 4)
-    block = dim3(fwd_threads);
+    block = dim3(512);   // 8 waves: one 16-query tile each at S = 128 (measured 20.0 vs 21.0 us with 4)
     if (SP <= 128) {
       if (int rc = set_lds(attn_fwd_bf16<HD, 8>, lds)) return rc;
       hipLaunchKernelGGL((attn_fwd_bf16<HD, 8>), grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);

@@ -498,7 +498,6 @@ int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     ncu = n;
-    if (const char* ov = getenv("MFP_WS_NCU")) ncu = atoi(ov);   // experiment: size the persistent grid for part of the chip
   }
   // narrow column slices (half the weight prologue per CU, twice the row tiles per workgroup) pay
   // off when a full-width slice would leave a workgroup only a handful of 32-row tiles
@@ -541,7 +540,6 @@ int launch_one(const GemmParams& p0, int M, int N, int splitk, hipStream_t st) {
 }
 
 // Tile choice per layout (measured with tools/bench_gemm.py on MI355X).
-// MFP_GEMM_TILE = {s,b}{1,2} overrides tile (small 64x128 / big 128x128) and LDS buffering
 // (benchmarking only).
 template <typename T, bool AK, bool BK_>
 int launch_layout(const mfp_gemm_args* a, const GemmParams& p, int splitk, hipStream_t st, bool small, bool dbuf) {
@@ -556,10 +554,6 @@ int launch_layout(const mfp_gemm_args* a, const GemmParams& p, int splitk, hipSt
 template <typename T>
 int launch_gemm(const mfp_gemm_args* a, const GemmParams& p, int splitk, hipStream_t st) {
   bool small = a->a_kmajor != 0, dbuf = !small;
-  if (const char* ov = getenv("MFP_GEMM_TILE")) {
-    small = ov[0] == 's';
-    dbuf = ov[1] == '2';
-  }
   if (a->a_kmajor && !a->b_kmajor) return launch_layout<T, true, false>(a, p, splitk, st, small, dbuf);
   if (a->a_kmajor && a->b_kmajor) return launch_layout<T, true, true>(a, p, splitk, st, small, dbuf);
   if (!a->a_kmajor && !a->b_kmajor) return launch_layout<T, false, false>(a, p, splitk, st, small, dbuf);
