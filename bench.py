@@ -438,22 +438,25 @@ def main():
     # timed (hipGraph replay); algorithmic bytes / FLOPs and the block / non-block split of each family: the library
     # calls of instrumented eager steps of the same workload (HIP events on the launch stream; the fallback for the
     # durations when the tracer is unavailable)
-    if not args.no_roofline and rank == 0:
-        replay = None
-        if graphed and world == 1:
-            try:
-                replay = replay_kernel_times(model, batch)
-            except Exception as exc:   # measurement aid: never fail the bench line over it
-                print("bench.py: tracer unavailable (%s); event-timed eager durations" % exc, file=sys.stderr)
+    eager_recs, replay = None, None
+    if not args.no_roofline and rank == 0 and graphed and world == 1:
+        try:
+            replay = replay_kernel_times(model, batch)
+        except Exception as exc:   # measurement aid: never fail the bench line over it
+            print("bench.py: tracer unavailable (%s); event-timed eager durations" % exc, file=sys.stderr)
+    if not args.no_roofline:
+        # instrumented eager steps (HIP events around the library calls): EVERY rank steps -- with N > 1 an eager step
+        # all-reduces the gradients, so rank 0 alone would wait for its peers forever -- rank 0 reports
         model._graph = None
-        batch = batches[0]
-        model.train_step(batch)
+        model.train_step(batches[0])
         torch.cuda.synchronize()
         ops.start_profile()
-        nprof = 3
-        for _ in range(nprof):
-            model.train_step(batch)
-        recs = ops.stop_profile()
+        for _ in range(3):
+            model.train_step(batches[0])
+        eager_recs = (ops.stop_profile(), 3)
+        barrier()
+    if not args.no_roofline and rank == 0:
+        recs, nprof = eager_recs
         agg, blk, blk_ms = {}, [0.0, 0.0, 0.0], {}
         for name, flops, nbytes, ms, scope, share in recs:      # share < 1: one launch booked under several scopes
             a = agg.setdefault(family(name), [0, 0.0, 0.0, 0.0])

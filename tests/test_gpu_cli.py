@@ -111,3 +111,27 @@ def test_weights_from_tensorflow_checkpoint(tmp_path, capsys):
           "--num_blocks", "2", "--batch_size", "8", "--num_epochs", "1", "--validation_freq", "1",
           "--masking_method", "random", "--dtype", "fp32", "--verbose", "0", "--weights", prefix])
     assert "total_score" in capsys.readouterr().out
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """bench.py as the driver launches it for N > 1 (``python -m torch.distributed.run ... bench.py --gpus N``), here with
+    two ranks sharing the one GPU over gloo (MFP_DIST_BACKEND): the line must come out -- every rank takes part in every
+    collective of the script, the roofline leg included (rank 0 alone stepping eagerly would wait for its peers forever) --
+    with the replicas in sync and the all-reduce plan on it."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MFP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--config", "c4", "--batch", "16"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["params_in_sync"] is True and line["value"] > 0
+    assert line["dp"]["rccl_ranks"] == 2 and sum(b["params"] for b in line["dp"]["plan"]) == line["config"]["params"]
+    assert "roofline" in line and "cpu_baseline" not in line
