@@ -308,8 +308,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16(const bf16_t* __restrict
   }
 }
 
+// Launched with 4 waves (S <= 128: two workgroups per CU) or 8 waves (S > 128: the four LDS images of one item take
+// 147 KB at S = 256, head width 64 -- one workgroup per CU, so the second wave per SIMD has to come from this workgroup:
+// with four waves a CU ran one wave per SIMD and an item took two rounds of 2 x 8 block pairs per wave).
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_bf16(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
+__global__ __launch_bounds__(512) void attn_bwd_bf16(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
                                                      const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
                                                      const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                                                      int S, int H, float scale) {
@@ -363,10 +366,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16(const bf16_t* __restrict
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
-  const int nblk = SP / 32;
+  const int nblk = SP / 32, nw = blockDim.x >> 6;
 
   // ---------------- loop A: dQ for query block qb (S^T orientation: lane = query)
-  for (int qb = wave; qb < nblk; qb += 4) {
+  for (int qb = wave; qb < nblk; qb += nw) {
     bf16x8 bq[2][KS], bdo[2][KS];
     float Lq[2], Dq[2];
 #pragma unroll
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16(const bf16_t* __restrict
   }
 
   // ---------------- loop B: dK, dV for key block kb (S orientation: lane = key)
-  for (int kb = wave; kb < nblk; kb += 4) {
+  for (int kb = wave; kb < nblk; kb += nw) {
     bf16x8 bk[2][KS], bv[2][KS];
     float madd[2];
 #pragma unroll
@@ -863,6 +866,7 @@ int bwd_hd(const void* qkv, const int* nvalid, const void* out, const void* dout
     size_t lds = (size_t)4 * SP * LDH * sizeof(bf16_t) + (size_t)3 * SP * sizeof(float);
     MFP_CHECK_ARG(lds <= 160 * 1024);
     if (int rc = set_lds(attn_bwd_bf16<HD>, lds)) return rc;
+    if (SP > 128) block = dim3(512);
     hipLaunchKernelGGL(attn_bwd_bf16<HD>, grid, block, lds, st, (const bf16_t*)qkv, nvalid, (const bf16_t*)out,
                        (const bf16_t*)dout, lse, (bf16_t*)dqkv, S, H, scale);
   }
