@@ -116,7 +116,7 @@ def family(kernel_name):
 # device-kernel name (as the tracer reports it) -> the family name the library calls are booked under (ops._timed)
 _KERNEL_FAMILY = (("attn_bwd", "attn_bwd"), ("attn_fwd", "attn_fwd"), ("ce_tile_kernel", "loss_kernels"),
                   ("mse_kernel", "loss_kernels"), ("zero_sums_kernel", "loss_kernels"),
-                  ("dgrad_half_kernel", "dgrad_qkv_kernel"), ("adam_norm_kernel", "adam_kernels"),
+                  ("dgrad_half_kernel", "dgrad_qkv_kernel"), ("gemm_wgt_kernel", "gemm_wgg_kernel"), ("adam_norm_kernel", "adam_kernels"),
                   ("adam_update_kernel", "adam_kernels"), ("transpose_cast_kernel", "cast_kernel"),
                   ("embed_fwd_lds_kernel", "embed_fwd_kernel"), ("embed_onehot_kernel", "embed_fwd_kernel"),
                   ("reduce_rows", "reduce_partials_batch"), ("step_prologue_kernel", "mask_kernel"))

@@ -679,6 +679,19 @@ int wgg_tiles(const mfp_wgrad_job* jobs, int njobs) {
   for (int i = 0; i < njobs; ++i) t += ((jobs[i].M + 127) / 128) * ((jobs[i].N + 127) / 128);
   return t;
 }
+// 256 x 128 macro tiles (gemm_wgt_kernel): groups with many tiles whose jobs all have an even number of tile rows and
+// no row masks (c5: the four products of a d_model-512 block, 128 tiles); "MFP_WGT=0" keeps 128 x 128 units (A/B switch)
+bool wgg_macro_ok(const mfp_wgrad_job* jobs, int njobs) {
+  static const bool off = getenv("MFP_WGT") != nullptr && atoi(getenv("MFP_WGT")) == 0;
+  if (off) return false;
+  int tiles = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const int tm = (jobs[i].M + 127) / 128;
+    if ((tm & 1) || jobs[i].rowcode != nullptr || jobs[i].M % 128 != 0) return false;
+    tiles += tm * ((jobs[i].N + 127) / 128);
+  }
+  return tiles >= 64;
+}
 int wgg_ncu() {
   static int ncu_of[MFP_MAX_DEVICES] = {};
   int& ncu = ncu_of[mfp_device_slot()];
@@ -702,7 +715,7 @@ extern "C" int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs, int32_t njob
 // slabs); slices of at least 256 tokens, at most WG_MAX_KCHUNK when a job masks rows (codes in LDS).
 extern "C" int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K) {
   if (jobs == nullptr || njobs < 1 || K < 1) return 8;
-  const int tiles = wgg_tiles(jobs, njobs), ncu = wgg_ncu();
+  const int tiles = wgg_macro_ok(jobs, njobs) ? wgg_tiles(jobs, njobs) / 2 : wgg_tiles(jobs, njobs), ncu = wgg_ncu();
   bool rowskip = false;
   for (int i = 0; i < njobs; ++i) rowskip |= jobs[i].rowcode != nullptr;
   int best = 8;
@@ -755,7 +768,8 @@ int wgrad_group_launch(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int3
   for (int i = njobs; i < WGG_MAX_JOBS; ++i) { p.job[i] = p.job[0]; p.job[i].tile0 = 0x7FFFFFFF; }
   p.njobs = njobs; p.ntiles = tile0; p.K = K; p.splitk = splitk;
   p.nk_max = ((K + 63) / 64 + splitk - 1) / splitk;
-  p.tpg = splitk < 8 ? (tile0 * splitk + 7) / 8 : 0;
+  const bool macro = defer && wgg_macro_ok(jobs, njobs);
+  p.tpg = splitk < 8 ? ((macro ? tile0 / 2 : tile0) * splitk + 7) / 8 : 0;
   if (rowskip) MFP_CHECK_ARG(p.nk_max * 64 <= WG_MAX_KCHUNK);
   const size_t need = mfp_wgrad_group_workspace_bytes(jobs, njobs, splitk);
   if (workspace_bytes < need) {
@@ -771,6 +785,11 @@ int wgrad_group_launch(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int3
   p.trace = g_trace;
 #endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (macro) {
+    if (int rcm = launch_wgt(p, st)) return rcm;
+    MFP_CHECK_LAUNCH();
+    return MFP_OK;
+  }
   const int rc = defer ? (rowskip ? launch_wgg_t<true, true>(p, st) : launch_wgg_t<false, true>(p, st))
                        : (rowskip ? launch_wgg_t<true, false>(p, st) : launch_wgg_t<false, false>(p, st));
   if (rc != MFP_OK) return rc;

@@ -344,6 +344,203 @@ inline int launch_wgg_t(const WggParams& p, hipStream_t st) {
   return MFP_OK;
 }
 
+// ------------------------------------------------------------------ 256 x 128 macro tiles (many-tile groups: d_model 512)
+// The same pipeline on a macro tile = two 128 x 128 tiles stacked in M (tiles t and t + tiles_n of one job: every job of the
+// group must have an even number of tile rows).  At c5 a block's four products are 128 tiles; with 128 x 128 units and a
+// split of 2 every workgroup walks 128 k-tiles at the pipeline's ~0.75 us per k-tile whatever the tile holds (100 us per
+// group), and the 12 / 4 tiles of a row / column of tiles pull 1.07 GB out of the L2s for 201 MB of operands.  A macro
+// tile does twice the products per k-tile step (A 64 x 256 + B 64 x 128 = 48 KB staged, 64 MFMAs per math wave and
+// k-tile) over half as many steps per workgroup.  Slabs are written as the two standard tiles, so the workspace layout,
+// mfp_wgrad_reduce and the column sums are those of gemm_wgg_kernel.  Deferred reduction only, no row masks.
+template <int XD>
+__global__ __launch_bounds__(512, 2) void gemm_wgt_kernel(WggParams p) {
+  constexpr int BN = 128, BK = 64, LDA_S = 256 + 8, LDB_S = 128 + 8;
+  constexpr int A_E = BK * LDA_S, B_E = BK * LDB_S;
+  constexpr int STAGE_B = (A_E + B_E) * 2;
+  constexpr int CS_LD = BN + 4;
+  static_assert(128 * CS_LD * 4 <= 2 * STAGE_B, "output stage aliases the two operand stages");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* const colsum_s = reinterpret_cast<float*>(smem_raw + 2 * STAGE_B);      // [16][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int mtiles = p.ntiles >> 1;
+  int kz, mt_i;
+  if (p.splitk >= 8) { kz = (j / mtiles) * 8 + xcd; mt_i = j % mtiles; }
+  else {
+    kz = xcd % p.splitk; mt_i = (xcd / p.splitk) * p.tpg + j;       // (p.tpg: MACRO tiles per XCD group)
+    if (mt_i >= mtiles) return;
+  }
+  int ji = 0;
+  for (int q = 1; q < p.njobs; ++q) ji = mt_i >= (p.job[q].tile0 >> 1) ? q : ji;
+  const WggJob& jb = p.job[ji];
+  const int M = jb.M, N = jb.N, lda = jb.lda, ldb = jb.ldb;
+  const int bid = mt_i - (jb.tile0 >> 1);
+  const int tm2 = bid / jb.tiles_n, tn = bid % jb.tiles_n;
+  const int tile_lo = jb.tile0 + (2 * tm2) * jb.tiles_n + tn;      // the standard tiles this macro tile is made of:
+  const int m0 = tm2 * 256, n0 = tn * BN;                            // tile_lo (rows m0 ..) and tile_lo + tiles_n (rows m0 + 128 ..)
+  const int ktiles = (p.K + BK - 1) / BK, kend = p.K;
+  const int nk = kz < ktiles ? (ktiles - kz + p.splitk - 1) / p.splitk : 0;
+  const bool do_colsum = jb.colsum != nullptr && tn == 0;
+  f32x4 acc[8][4];
+
+  if (wave < 4) {
+    // ======================================================================== MATH waves: 128 x 64 of the macro tile each
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();   // prologue barrier (stage 0 filled)
+    for (int t = 0; t < nk; ++t) {
+      const unsigned short* As = reinterpret_cast<const unsigned short*>(smem_raw + (t & 1) * STAGE_B);
+      const unsigned short* Bs = As + A_E;
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8 xf[8], wf[4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const unsigned short* ptr = &As[(ks * 32 + lg * 8 + (li >> 2)) * LDA_S + wm * 128 + a * 16 + (li & 3) * 4];
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDA_S));
+          xf[a] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const unsigned short* ptr = &Bs[(ks * 32 + lg * 8 + (li >> 2)) * LDB_S + wn * 64 + (li & 3) * 16 + b * 4];
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 4 * LDB_S));
+          wf[b] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else {
+    // ====================================================================== MEMORY waves
+    const int mt = tid - 256;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(jb.A), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(jb.B), 0, 0x7FFFFFFF, 0x00020000);
+    const int krow0 = mt >> 4, ccol = (mt & 15) * 8;
+    const unsigned int abad0 = m0 + ccol < M ? 0u : 0xFFFFFFFFu, abad1 = m0 + 128 + ccol < M ? 0u : 0xFFFFFFFFu;
+    const unsigned int bbad = n0 + ccol < N ? 0u : 0xFFFFFFFFu;
+    const unsigned int voa0 = (unsigned int)((krow0 * lda + m0 + ccol) * 2);
+    const unsigned int vob0 = (unsigned int)((krow0 * ldb + n0 + ccol) * 2);
+    const int lsa0 = (krow0 * LDA_S + ccol) * 2, lsb0 = (krow0 * LDB_S + ccol) * 2;
+    u32x4 ra[XD][2][4], rb[XD][4];
+    float csum[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csum[h][e] = 0.f;
+    auto gload = [&](int set, int t) {
+      const int k0 = (t * p.splitk + kz) * BK;
+      const int live = (t - nk) >> 31;                      // -1 while t < nk
+      const int soa = (k0 * lda * 2) & live, sob = (k0 * ldb * 2) & live;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + krow0 + 16 * c;
+        const unsigned int kbad = ~(unsigned int)(live & ((k - kend) >> 31));
+        const unsigned int oa = voa0 + (unsigned int)(16 * c * lda * 2);
+        ra[set][0][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, oa | abad0 | kbad, soa, 0));
+        ra[set][1][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, (oa + 256u) | abad1 | kbad, soa, 0));
+        rb[set][c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rsb, (vob0 + (unsigned int)(16 * c * ldb * 2)) | bbad | kbad, sob, 0));
+      }
+    };
+    auto lstore = [&](int set, int stage) {
+      unsigned char* st = smem_raw + stage * STAGE_B;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        *reinterpret_cast<u32x4*>(st + lsa0 + 16 * c * LDA_S * 2) = ra[set][0][c];
+        *reinterpret_cast<u32x4*>(st + lsa0 + 256 + 16 * c * LDA_S * 2) = ra[set][1][c];
+        *reinterpret_cast<u32x4*>(st + A_E * 2 + lsb0 + 16 * c * LDB_S * 2) = rb[set][c];
+        if (do_colsum) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned int w = ra[set][h][c][e];
+              csum[h][2 * e] += bf16_to_f32((unsigned short)(w & 0xffffu));
+              csum[h][2 * e + 1] += bf16_to_f32((unsigned short)(w >> 16));
+            }
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < XD; ++i) gload(i, i);
+    lstore(0, 0);
+    gload(0, XD);
+    __syncthreads();   // prologue barrier
+    auto step = [&](auto tc, int t) {
+      constexpr int xi = (decltype(tc)::value + 1) % XD;
+      lstore(xi, (t + 1) & 1);
+      gload(xi, t + 1 + XD);
+      __syncthreads();
+    };
+    int t = 0;
+    for (; t + XD - 1 < nk; t += XD) wgg_static_for<0, XD>([&](auto ic) { step(ic, t + decltype(ic)::value); });
+    wgg_static_for<0, XD - 1>([&](auto ic) { if (t + decltype(ic)::value < nk) step(ic, t + decltype(ic)::value); });
+    if (do_colsum) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colsum_s[krow0 * 256 + h * 128 + ccol + e] = csum[h][e];
+    }
+  }
+  // ---- publish: the two standard tiles one after the other through the output stage (128 x 128 f32, aliases the stages)
+  const int r0 = tid >> 5, c4 = (tid & 31) * 4;
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+  for (int hs = 0; hs < 2; ++hs) {
+    __syncthreads();      // k-loop done (hs = 0) / the previous half has left the stage (hs = 1)
+    if (wave < 4 && (wave >> 1) == hs) {
+      const int wn = wave & 1;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          *reinterpret_cast<f32x4*>(&Cs[(a * 16 + li) * CS_LD + wn * 64 + lg * 16 + b * 4]) = acc[a][b];
+    }
+    __syncthreads();
+    float* slab = p.ws + kz * p.zstride + (long long)(tile_lo + hs * jb.tiles_n) * (128 * BN);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(slab, 0, 128 * BN * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = r0 + 16 * i;
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&Cs[row * CS_LD + c4]), rss,
+                                             (unsigned int)((row * BN + c4) * 4), 0, 0);
+    }
+  }
+  if (do_colsum && tid < 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int gI = 0; gI < 16; ++gI) s += colsum_s[gI * 256 + tid];
+    p.ws_col[((long long)kz * p.ntiles + tile_lo + (tid >> 7) * jb.tiles_n) * 128 + (tid & 127)] = s;
+  }
+}
+
+inline int launch_wgt(const WggParams& p, hipStream_t st) {
+  constexpr int lds = 2 * ((64 * 264 + 64 * 136) * 2) + 16 * 256 * 4;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgt_kernel<WGG_XD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_wgrad_group_partial: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int mtiles = p.ntiles / 2;
+  hipLaunchKernelGGL((gemm_wgt_kernel<WGG_XD>), dim3(p.splitk >= 8 ? mtiles * p.splitk : 8 * p.tpg), dim3(512), lds, st, p);
+  return MFP_OK;
+}
+
 // ------------------------------------------------------------------ deferred split-K reduction, all groups of a step
 constexpr int WGR_MAX_GROUPS = 8;
 struct WgrJob { float* C; float* colsum; int M, N, ldc, tiles_n, tile0, pad_; };

@@ -757,6 +757,38 @@ def test_wgrad_group(T, splitk):
         assert (j["out"]._base[:, j["N"]:] == 7.0).all()
 
 
+@pytest.mark.parametrize("T,splitk", [(4096, 4), (3000, 2), (16384, None)])
+def test_wgrad_group_macro_tiles(T, splitk):
+    """Groups with many tiles (a d_model-512 block's four products: 128 tiles of 128 x 128) take gemm_wgt_kernel in the
+    deferred form: 256 x 128 macro tiles, slabs written as the two standard tiles.  Against a double reference, and -- same
+    split, same k order per tile -- BIT-identical to the 128 x 128 kernel with the in-launch reduction."""
+    ops = _ops()
+    D = 512
+    g = torch.Generator().manual_seed(T)
+    rnd = lambda n: bf16_round(torch.randn(T, n, generator=g)).to(DEV, torch.bfloat16)
+    ops_ab = [(rnd(3 * D), rnd(D)), (rnd(2 * D), rnd(D)), (rnd(D), rnd(2 * D)), (rnd(D), rnd(D))]
+    def jobs():
+        return [dict(A=a, B=b, out=torch.full((a.shape[1], b.shape[1]), 7.0, device=DEV), M=a.shape[1], N=b.shape[1],
+                     **({"colsum": torch.full((a.shape[1],), 7.0, device=DEV)} if i != 2 else {})) for i, (a, b) in enumerate(ops_ab)]
+    j0 = jobs()
+    sk = splitk or ops.wgrad_group_splitk(j0, T)
+    assert sk in (1, 2, 4) or sk % 8 == 0
+    ops.wgrad_group(j0, T, sk)                       # 128 x 128 units, reduction inside the launch
+    j1 = jobs()
+    pending = []
+    ops.wgrad_group(j1, T, sk, defer=pending)        # macro tiles + mfp_wgrad_reduce
+    ops.wgrad_reduce(pending)
+    torch.cuda.synchronize()
+    tol = 2e-4 * math.sqrt(T)
+    for (a, b), x0, x1 in zip(ops_ab, j0, j1):
+        want = a.cpu().double().t() @ b.cpu().double()
+        assert_close(x1["out"], want, tol, 1e-5, "macro-tile wgrad %dx%d" % (x1["M"], x1["N"]))
+        assert torch.equal(x0["out"], x1["out"]), (x1["M"], x1["N"])
+        if "colsum" in x1:
+            assert_close(x1["colsum"], a.cpu().double().sum(0), tol, 1e-5, "bias gradient")
+            assert torch.equal(x0["colsum"], x1["colsum"])
+
+
 def test_mx_mfma_layout():
     """Pins the operand and scale layout of v_mfma_scale_f32_16x16x128_f8f6f4 that csrc/gemm_fp8.hip relies on (one
     instruction through mfp_debug_mx_probe, e4m3 x e4m3): lane (i = l % 16, g = l / 16) of the A (B) operand holds row
