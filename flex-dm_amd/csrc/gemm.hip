@@ -554,6 +554,9 @@ int launch_layout(const mfp_gemm_args* a, const GemmParams& p, int splitk, hipSt
 template <typename T>
 int launch_gemm(const mfp_gemm_args* a, const GemmParams& p, int splitk, hipStream_t st) {
   bool small = a->a_kmajor != 0, dbuf = !small;
+  // long-K forward / input-gradient products (d_model 512: FFN2 forward and the FFN1 / Q|K|V input gradients, K = 1024 /
+  // 1536): 128 x 128 tiles -- a third less operand traffic out of the L2s than 64 x 128 (c5: 4.64 -> 4.56 ms per step)
+  if (a->a_kmajor && a->K >= 1024 && sizeof(T) == 2) { small = false; dbuf = false; }
   if (a->a_kmajor && !a->b_kmajor) return launch_layout<T, true, false>(a, p, splitk, st, small, dbuf);
   if (a->a_kmajor && a->b_kmajor) return launch_layout<T, true, true>(a, p, splitk, st, small, dbuf);
   if (!a->a_kmajor && !a->b_kmajor) return launch_layout<T, false, false>(a, p, splitk, st, small, dbuf);
