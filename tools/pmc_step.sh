@@ -10,4 +10,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o pmc -- \
     python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-roofline > $OUT/$c.log 2>&1 || true
 done
-python tools/pmc_step_summary.py $OUT $((STEPS + 3)) | tee $OUT/summary.txt
+python tools/pmc_step_summary.py $OUT $((2 * STEPS + 3)) | tee $OUT/summary.txt   # 2 capture warm-ups + 1 warm-up + K timed + K median pass

@@ -9,7 +9,7 @@ OUT=$O/prof_r04; rm -rf $OUT; mkdir -p $OUT
 STEPS=50; WARM=5
 rocprofv3 --kernel-trace --stats -d $OUT -o t -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1 || true
 DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
-python tools/rocprof_summary.py $DB $O/r04_kernel_stats.csv $((STEPS + WARM + 2))
+python tools/rocprof_summary.py $DB $O/r04_kernel_stats.csv $((2 * STEPS + WARM + 2))   # 2 capture warm-ups + W + K timed + K for the median pass
 python tools/step_dump.py $DB > $O/r04_step_dump.txt
 rm -rf $OUT
 STEPS=6 bash tools/pmc_step.sh > $O/r04_pmc_step.log 2>&1 || true
