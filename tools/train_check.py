@@ -7,7 +7,7 @@ ic = make_input_columns("crello")
 dev = "cuda:0"
 model = MFP(ic, num_blocks=4, latent_dim=256, dropout=0.1, l2=1e-2, masking_method="random", dtype="bf16", device=dev, seed=0)
 model.compile(learning_rate=1e-3, clipnorm=1.0)
-batches = [synthetic_batch(ic, 64, 64, seed=s, ragged=True, device=dev) for s in range(4)]
+batches = [synthetic_batch(ic, 64, 128, seed=s, ragged=True, device=dev) for s in range(4)]   # S = 128: the document-tile kernels
 model.capture_train_step(batches[0], warmup=1)
 for it in range(401):
     sums = model.train_step(batches[it % 4])
