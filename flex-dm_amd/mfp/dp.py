@@ -23,6 +23,9 @@ def init_from_env(backend: Optional[str] = None) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 1
+    # the plan switches are read when the step is captured: a typo should fail here, not minutes into a run
+    bucket_cut_blocks(2)
+    BucketReducer()
     if not dist.is_initialized():
         # MFP_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests of the multi-rank step logic);
         # production is "nccl" (= RCCL on ROCm), one rank per GPU over xGMI.

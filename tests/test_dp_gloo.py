@@ -321,3 +321,16 @@ def test_describe_plan_covers_every_parameter_once():
         assert len(plan["plan"]) == nb and sum(b["params"] for b in plan["plan"]) == lay.numel
         assert plan["bytes_per_step"] == 4 * lay.numel and plan["carrier"] == "f32"
     assert dp.describe_plan(lay, graphed=False)["plan"][0]["params"] == lay.numel
+
+
+def test_plan_switches_are_validated_at_init(monkeypatch):
+    """MFP_DP_BUCKETS / MFP_DP_GRAD_DTYPE are read at capture time; init_from_env rejects a bad value up front."""
+    from mfp import dp
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("MFP_DP_BUCKETS", "quarters")
+    with pytest.raises(ValueError):
+        dp.init_from_env("gloo")
+    monkeypatch.setenv("MFP_DP_BUCKETS", "blocks")
+    monkeypatch.setenv("MFP_DP_GRAD_DTYPE", "fp8")
+    with pytest.raises(ValueError):
+        dp.init_from_env("gloo")
