@@ -360,15 +360,17 @@ def main():
         batches = [batch]
     for i in range(args.warmup):
         model.train_step(batches[i % len(batches)])
-    # K steps = K / R replays of the graph that steps through the R resident batches (one graph-launch gap per R steps)
-    # when R divides K, else K single-step replays
-    grouped = graphed and len(batches) > 1 and args.steps % len(batches) == 0 and hasattr(model, "train_steps_resident")
+    # K steps = K // R replays of the graph that steps through the R resident batches (one graph-launch gap per R steps)
+    # + K % R single-step replays
+    grouped = graphed and len(batches) > 1 and args.steps >= len(batches) and hasattr(model, "train_steps_resident")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if grouped:
         for _ in range(args.steps // len(batches)):
             sums = model.train_steps_resident()
+        for i in range(args.steps % len(batches)):      # (K not a multiple of R: the rest as single-step replays)
+            sums = model.train_step(batches[i])
     else:
         for i in range(args.steps):
             sums = model.train_step(batches[i % len(batches)])
