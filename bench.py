@@ -505,6 +505,9 @@ def main():
         traffic, pmc_calls = pmc_traffic(name) if args.config == "c2" and dtype == "bf16" else (None, None)
         roof["traffic"] = traffic
         if traffic is not None:
+            # PMC counters cannot be read from inside the process: the bytes come from the committed rocprofv3 --pmc passes
+            # over this same command (tools/pmc_step.sh), not from this run
+            roof["traffic_source"] = os.path.relpath(PMC_FILE, ROOT)
             roof["traffic_launches_per_step"] = pmc_calls   # must equal launches_per_step (same command)
         block_fl = block_flops_per_element(D, NB, S) * B * S
         roof.update({"avg_launch_us": 1e3 * ms / cnt, "timing": timing,
