@@ -19,7 +19,8 @@ N grows = weak scaling):
   c3  c2 with masking_method=elem_pos_attr_img_txt (Ours-EXP: all five task types active)
   c4  c2 with 128 documents/GPU (global batch 1024 at --gpus 8)
   c5  Crello Ours-EXP-FT shape: d_model 512, 8 blocks, seq_len 256, 64 documents/GPU, "fp8": bf16 with
-      e4m3 QKV / FFN1 forward products (per-tensor scales, v_mfma_f32_16x16x32_fp8_fp8)
+      e4m3 QKV / FFN1 forward products as OCP-MX block-scaled products (one e8m0 scale per 32 input features,
+      v_mfma_scale_f32_16x16x128_f8f6f4)
 
 Timed region: K hipGraph replays of the captured step between two device synchronisations (+ barriers for N > 1);
 `value` = elements of all ranks / that wall time; `ms_per_step_median` = median of the per-step HIP-event intervals of
@@ -333,7 +334,7 @@ def main():
         try:
             model.capture_train_step(batch, warmup=2, resident=nres)
             batch = model.static_batch   # the graph's input buffers: inputs are already resident there
-            batches = list(getattr(model, "static_batches", [batch]))
+            batches = list(getattr(model, "static_batches", None) or [batch])
             for i, b in enumerate(batches[1:], 1):      # distinct documents in every resident buffer set
                 fresh = synthetic_batch(ic, B, S, seed=1000 * i + rank, ragged=False, device=device)
                 for k, v in fresh.items():
@@ -362,7 +363,7 @@ def main():
         model.train_step(batches[i % len(batches)])
     # K steps = K // R replays of the graph that steps through the R resident batches (one graph-launch gap per R steps)
     # + K % R single-step replays
-    grouped = graphed and len(batches) > 1 and args.steps >= len(batches) and hasattr(model, "train_steps_resident")
+    grouped = graphed and len(batches) > 1 and args.steps >= len(batches) and getattr(model, "train_steps_resident", None) is not None
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -405,7 +406,7 @@ def main():
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)                      # a real collective on the data-path backend: counts the ranks
         dp_info = dp.describe_plan(model.model.layout, graphed)
-        dp_info.update({"backend": dist.get_backend(), "rccl_ranks": int(ones.item()), "world_size": dist.get_world_size()})
+        dp_info.update({"backend": dist.get_backend(), "collective_ranks": int(ones.item()), "world_size": dist.get_world_size()})
 
     value = world * B * S * args.steps / elapsed
     lay = model.model.layout
@@ -416,7 +417,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median": median_ms,
         "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8 (e4m3 QKV/FFN1 forward products; bf16 elsewhere)"}[dtype],
+        "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8 (MX e4m3 + e8m0 per 32: QKV/FFN1 forward products; bf16 elsewhere)"}[dtype],
         "data": "synthetic",
         "config": {"workload": "%s (%s) train step, masking_method=%s: d_model=%d, %d DeepSVG blocks, seq_len=%d, "
                                "%d documents/GPU, dropout 0.1, l2 1e-2, Adam lr 1e-4 clipnorm 1.0"

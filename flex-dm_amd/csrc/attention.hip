@@ -844,14 +844,7 @@ int bwd_hd(const void* qkv, const int* nvalid, const void* out, const void* dout
     static const bool single_pass = !(getenv("MFP_ATTN_BWD_SINGLE") && atoi(getenv("MFP_ATTN_BWD_SINGLE")) == 0);   // A/B switch
     if (HD == 32 && S <= 128 && single_pass && (long long)B * S * H * 32 * 3 * 2 < 0xFFFFFF00LL) {
       // persistent single-pass kernel: two workgroups per CU, each a contiguous run of (document, head) items
-      static int ncu_dev[MFP_MAX_DEVICES] = {};
-      int& ncu = ncu_dev[mfp_device_slot()];
-      if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) ncu = 256;
-        else ncu = prop.multiProcessorCount;
-      }
+      const int ncu = mfp_ncu_launch();
       const int items = B * H;
       const int ipw = (items + 2 * ncu - 1) / (2 * ncu);
       const int nwg = (items + ipw - 1) / ipw;

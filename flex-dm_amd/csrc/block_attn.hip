@@ -44,6 +44,7 @@ struct AttnBlockParams {
   const unsigned short* W2; const float* b2;           // [256][512] bf16, f32 [256]
   unsigned short* y2; float* mean2; float* rstd2; unsigned short* h; float* x2; unsigned short* x2c;
   unsigned long long offset2;                          // dropout stream of the MLP half
+  int stash;                                           // 0 = inference form (mfp_block_infer, template flag STASH): y1, qkv, a, lse, y2, h are not written
 };
 
 constexpr int AB_D = 256, AB_ROWS = 128, AB_CHUNKS = 16;
@@ -82,7 +83,7 @@ __device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool DROPOUT, bool MLP>
+template <bool DROPOUT, bool MLP, bool STASH = true>
 __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) {
   constexpr int NCH = MLP ? 2 * AB_CHUNKS : AB_CHUNKS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,16 +106,19 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(doc * 8 + wave) * 64;
   AB_TR(0);
   const unsigned int xbytes = (unsigned int)p.T * (AB_D * 4);
+  // inference form: the saved tensors are zero-sized buffers -- their stores are issued all the same (the counted waits
+  // of the chunk loop stay exact) and dropped by the bounds check, so nothing but x1 and x2 reaches HBM
+  constexpr unsigned int sm = STASH ? 0xFFFFFFFFu : 0u;
   const __amdgpu_buffer_rsrc_t rs_wq = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wqkv), 0, 768 * AB_D * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wo), 0, AB_D * AB_D * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(p.x1, 0, xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y1, 0, xbytes / 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(p.qkv, 0, (unsigned int)p.T * (768 * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(p.a, 0, xbytes / 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y1, 0, (xbytes / 2) & sm, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(p.qkv, 0, ((unsigned int)p.T * (768 * 2)) & sm, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(p.a, 0, (xbytes / 2) & sm, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(MLP ? p.W1 : p.Wqkv), 0, AB_F * AB_D * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(MLP ? p.W2 : p.Wqkv), 0, AB_F * AB_D * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(p.lse, 0, (unsigned int)(p.T / AB_ROWS) * (unsigned int)p.H * AB_ROWS * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(p.lse, 0, ((unsigned int)(p.T / AB_ROWS) * (unsigned int)p.H * AB_ROWS * 4u) & sm, 0x00020000);
 
   // ---- weight chunk c = 4 p + t.  t = 0, 1, 2 (q, k, v): Wqkv rows t * 256 + 64 p .. + 63, all 256 k -> image [64][512 B],
   // slot ^ (row & 15) (2 rows per 1 KB piece).  t = 3 (o): Wo rows 0 .. 255, k = 64 p .. + 63 -> image [256][128 B],
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     const float* const G2s = B2s + AB_D;
     const float* const Be2s = G2s + AB_D;
     float* const St = reinterpret_cast<float*>(smem + AB_VEC2_OFF + (AB_F + 3 * AB_D) * 4);      // [2 (nh)][128 rows]
-    const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, xbytes / 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, (unsigned int)p.T * (AB_F * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y2 = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, (xbytes / 2) & sm, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, ((unsigned int)p.T * (AB_F * 2)) & sm, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(p.x2, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2c = __builtin_amdgcn_make_buffer_rsrc(p.x2c ? p.x2c : p.y2, 0, (p.x2c && AB_ABL != 9) ? xbytes / 2 : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_m2 = __builtin_amdgcn_make_buffer_rsrc(p.mean2, 0, (unsigned int)p.T * 4u, 0x00020000);
@@ -666,6 +670,7 @@ static int launch_block(AttnBlockParams& p, bool mlp, int B, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
     if (e != hipSuccess) {
       mfp_set_error("mfp_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS_MLP, hipGetErrorString(e));
       return MFP_ELAUNCH;
@@ -673,7 +678,9 @@ static int launch_block(AttnBlockParams& p, bool mlp, int B, hipStream_t st) {
     attr_set = true;
   }
   const bool drop = p.dropout_p > 0.f;
-  if (mlp) {
+  if (mlp && !p.stash) {
+    hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, false>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
+  } else if (mlp) {
     if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
     else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
   } else {
@@ -701,6 +708,7 @@ static int fill_attn(AttnBlockParams& p, const float* x, const float* gamma, con
   p.dropout_p = dropout_p; p.seed = seed; p.offset = offset; p.step_ptr = step_ptr;
   p.gamma2 = p.beta2 = p.b1 = p.b2 = nullptr; p.W1 = p.W2 = nullptr;
   p.y2 = p.h = p.x2c = nullptr; p.mean2 = p.rstd2 = p.x2 = nullptr; p.offset2 = 0;
+  p.stash = 1;
   return MFP_OK;
 }
 
@@ -737,6 +745,33 @@ extern "C" int mfp_block_fwd(const float* x, const float* gamma, const float* be
   p.y2 = reinterpret_cast<unsigned short*>(y2); p.mean2 = mean2; p.rstd2 = rstd2;
   p.h = reinterpret_cast<unsigned short*>(h); p.x2 = x2; p.x2c = reinterpret_cast<unsigned short*>(x2_bf16);
   p.offset2 = offset_mlp;
+  if (int rc = launch_block(p, true, B, reinterpret_cast<hipStream_t>(stream))) return rc;
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+// Inference form of mfp_block_fwd (MFP.__call__(training=False), iterative_decode, eval.py: reference mfp.py:141-207,
+// eval.py:35-118): the same launch with nothing saved for a backward pass.  x1 still passes through HBM (the MLP half
+// re-reads it as its residual); `stats` is a [4 T] f32 scratch for the four LayerNorm statistics vectors.
+extern "C" int mfp_block_infer(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                               const void* Wo, const float* bo, const int32_t* nvalid, const float* gamma2, const float* beta2,
+                               const void* W1, const float* b1, const void* W2, const float* b2, float* x1, float* stats,
+                               float* x2, int32_t B, int32_t S, int32_t D, int32_t H, float eps, mfp_stream_t stream) {
+  MFP_CHECK_ARG(x && x1 && stats && x2 && gamma2 && beta2 && W1 && b1 && W2 && b2);
+  AttnBlockParams p;
+  // (the argument check wants non-null saved tensors: x1 stands in -- their buffers are zero-sized in the kernel)
+  void* dummy = x1;
+  const int T = B * S;
+  if (int rc = fill_attn(p, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, dummy, stats, stats + T, dummy, dummy,
+                         reinterpret_cast<float*>(dummy), x1, B, S, D, H, eps, 0.f, 0, 0, nullptr)) return rc;
+  MFP_CHECK_ARG(((uintptr_t)W1 % 16) == 0 && ((uintptr_t)W2 % 16) == 0 && ((uintptr_t)x2 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 &&
+                ((uintptr_t)b2 % 16) == 0 && ((uintptr_t)gamma2 % 16) == 0 && ((uintptr_t)beta2 % 16) == 0);
+  p.gamma2 = gamma2; p.beta2 = beta2;
+  p.W1 = reinterpret_cast<const unsigned short*>(W1); p.b1 = b1;
+  p.W2 = reinterpret_cast<const unsigned short*>(W2); p.b2 = b2;
+  p.y2 = reinterpret_cast<unsigned short*>(dummy); p.mean2 = stats + 2 * T; p.rstd2 = stats + 3 * T;
+  p.h = reinterpret_cast<unsigned short*>(dummy); p.x2 = x2; p.x2c = nullptr;
+  p.stash = 0;
   if (int rc = launch_block(p, true, B, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;

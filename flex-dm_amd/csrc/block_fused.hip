@@ -1388,13 +1388,7 @@ extern "C" int mfp_qkv_fused_fwd(const float* x, const float* gamma, const float
 static int half_mode(int T) {
   const char* env = getenv("MFP_FUSED_HALF");      // (read per call: the tests flip it)
   if (env != nullptr && env[0] != 0) return atoi(env) != 0;
-  static int ncu_of[MFP_MAX_DEVICES] = {};
-  int& ncu = ncu_of[mfp_device_slot()];
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    ncu = n;
-  }
+  const int ncu = mfp_ncu_physical();
   return (T + MLP_ROWS - 1) / MLP_ROWS < ncu;
 }
 

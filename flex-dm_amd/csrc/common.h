@@ -172,6 +172,11 @@ __device__ __forceinline__ void drop_keep4(unsigned int rowh, unsigned int col, 
   keep[2] = (b & 0xffffu) >= thr16; keep[3] = (b >> 16) >= thr16;
 }
 
+// CU count of the current device (csrc/error.cpp): physical, and what a persistent launch sizes its grid for
+// (physical - mfp_set_reserved_cus)
+int mfp_ncu_physical();
+int mfp_ncu_launch();
+
 // ----------------------------------------------------------------------------- XCD-aware block order
 // Hardware places block b on XCD b % 8 (speed only, never correctness).  This bijective remap gives
 // every XCD a CONTIGUOUS range of logical ids, so neighbouring logical ids (tiles sharing an operand

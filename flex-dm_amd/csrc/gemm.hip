@@ -491,14 +491,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #include "gemm_wgg.h"
 
 int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
-  static int ncu_of[MFP_MAX_DEVICES] = {};
-  int& ncu = ncu_of[mfp_device_slot()];
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    ncu = n;
-  }
+  const int ncu = mfp_ncu_launch();
   // narrow column slices (half the weight prologue per CU, twice the row tiles per workgroup) pay
   // off when a full-width slice would leave a workgroup only a handful of 32-row tiles
   static const char* nv = getenv("MFP_WS_NARROW");   // experiment switch: 0 never, 1 N <= 256, 2 always
@@ -695,17 +688,7 @@ bool wgg_macro_ok(const mfp_wgrad_job* jobs, int njobs) {
   }
   return tiles >= 64;
 }
-int wgg_ncu() {
-  static int ncu_of[MFP_MAX_DEVICES] = {};
-  int& ncu = ncu_of[mfp_device_slot()];
-  if (ncu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    ncu = n;
-  }
-  return ncu;
-}
+int wgg_ncu() { return mfp_ncu_launch(); }
 }  // namespace
 
 extern "C" int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs, int32_t njobs) {

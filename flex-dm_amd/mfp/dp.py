@@ -32,7 +32,20 @@ def init_from_env(backend: Optional[str] = None) -> int:
         backend = backend or os.environ.get("MFP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend)
+    reserve_cus_from_env()
     return dist.get_world_size()
+
+
+def reserve_cus_from_env() -> int:
+    """``MFP_DP_RESERVE_CUS=n``: with more than one rank, the persistent one-workgroup-per-CU launches (grouped weight
+    gradients, weight-stationary products, single-pass attention backward) size their grids for #CUs - n, leaving n
+    CUs to RCCL's workgroups while a bucket's all-reduce runs under the next segment of the backward pass (they cannot
+    share a CU with a 160 KB / 8-wave workgroup).  Default 0: an A/B switch for the driver's scaling run.  Returns n."""
+    n = int(os.environ.get("MFP_DP_RESERVE_CUS", "0") or 0)
+    if n and torch.cuda.is_available():
+        from mfp.hip import ops
+        ops.set_reserved_cus(n)
+    return n
 
 
 def world_size() -> int:
@@ -108,6 +121,7 @@ def describe_plan(layout, graphed: bool = True) -> dict:
             "plan": [{"bucket": n, "params": sl.stop - sl.start, "bytes": (sl.stop - sl.start) * esize}
                      for n, sl in zip(names, slices)],
             "bytes_per_step": layout.numel * esize,
+            "reserved_cus": int(os.environ.get("MFP_DP_RESERVE_CUS", "0") or 0),
             "exposed": "the last bucket's all-reduce + Adam" if cuts else "the whole all-reduce + Adam"}
 
 

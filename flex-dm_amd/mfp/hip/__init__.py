@@ -82,6 +82,8 @@ class MaskCol(Structure):
 SIGNATURES = {
     "mfp_last_error": (c_char_p, []),
     "mfp_version": (c_int32, []),
+    "mfp_cu_count": (c_int32, []),
+    "mfp_set_reserved_cus": (c_int32, [c_int32]),
     "mfp_gemm": (c_int32, [POINTER(GemmArgs), c_void_p]),
     "mfp_gemm_workspace_bytes": (c_size_t, [POINTER(GemmArgs)]),
     "mfp_gemm_kernel_family": (c_char_p, [POINTER(GemmArgs)]),
@@ -97,6 +99,7 @@ SIGNATURES = {
                                                    c_void_p, c_void_p]),
     "mfp_attn_block_fwd": (c_int32, [c_void_p] * 15 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_block_fwd": (c_int32, [c_void_p] * 27 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "mfp_block_infer": (c_int32, [c_void_p] * 17 + [c_int32] * 4 + [c_float, c_void_p]),
     "mfp_attn_block_bwd": (c_int32, [c_void_p] * 9 + [c_int32] * 4 + [c_void_p]),
     "mfp_qkv_fused_fwd": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_float, c_void_p]),
     "mfp_dgrad_d256": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

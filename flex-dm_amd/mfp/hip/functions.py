@@ -37,11 +37,13 @@ MLP_FUSE = os.environ.get("MFP_MLP_FUSE", "1") == "1"
 ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
 # ... and the MLP half behind it on the same tile: the whole block forward in one launch; 0 = attention half + mlp_fused
 BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
+# ... and its inference form (nothing saved for a backward pass) for the callers that never differentiate; 0 = the training form
+BLOCK_INFER = os.environ.get("MFP_BLOCK_INFER", "1") == "1"
 # the gradient of the residual stream (what one block's backward hands to the next) in bf16 instead of f32 on the bf16
 # train step: every LayerNorm backward then reads and writes 0.5 KB instead of 1 KB per element for it.  autograd sees
-# stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  Measured:
-# 1.547 vs 1.559 ms per c2 step (the LayerNorm backward is not purely bandwidth-bound at 3 KB per element) for eight more
-# bf16 roundings on the way down -- OFF by default ("1" = on)
+# stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  ON by
+# default since round 4 (-25 us per c2 step; gradient cosine against the f64 oracle 0.99972 vs 0.99975 with the f32
+# stream, tests/test_gpu_model.py); "0" = f32 stream
 RES_GRAD_BF16 = os.environ.get("MFP_RES_GRAD_BF16", "1") == "1"
 
 
@@ -59,16 +61,12 @@ HEADS_FUSED = os.environ.get("MFP_HEADS_FUSED", "1") == "1"
 # unset: when the documents fill the chip (one workgroup = one document per CU); with fewer documents than CUs (c4: 128 per
 # GPU) the three launches, which split a document over more workgroups, are faster (1.187 vs 1.210 ms per step)
 ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "")
-_CU_COUNT = {}
 
 
 def _attn_block_bwd_on(ctx) -> bool:
     if ATTN_BLOCK_BWD != "":
         return ATTN_BLOCK_BWD == "1"
-    dev = ctx.store.w.device
-    if dev not in _CU_COUNT:
-        _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
-    return ctx.B >= _CU_COUNT[dev]
+    return ctx.B >= ops.cu_count(ctx.store.w.device)
 FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
 
 
@@ -388,6 +386,17 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x = x.contiguous()
+        if (BLOCK_FWD and ATTN_BLOCK and BLOCK_INFER and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S
+                and not ctx.training and not fctx.needs_input_grad[0]):
+            # inference callers (MFP.__call__(training=False), iterative_decode, eval.py): nothing is saved for a
+            # backward pass, so only x1 (re-read as the MLP half's residual) and x2 reach HBM
+            fctx.ctx, fctx.i, fctx.saved = ctx, i, None
+            return ops.block_infer(
+                x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), st.cw(p + "attn/dense_query/kernel", rows=3 * D),
+                st.span(st.w, p + "attn/dense_query/bias", 3 * D), st.cw(p + "attn/combine_heads/kernel"),
+                st.weight(p + "attn/combine_heads/bias"), ctx.nvalid, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
+                st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"),
+                st.weight(p + "mlp/dense_1/bias"), B, S, NUM_HEADS)
         if BLOCK_FWD and ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S:
             # the whole block in one launch (csrc/block_attn.hip); the last block also leaves the heads' bf16 operand
             x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)

@@ -194,7 +194,26 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kmajor: 
     return out
 
 
-_WG_TARGET = int(os.environ.get("MFP_WG_TARGET", "256"))   # workgroups a wgrad launch aims for
+_cu_count: Dict = {}
+
+
+_reserved_cus = 0
+
+
+def set_reserved_cus(n: int) -> None:
+    """Leave ``n`` CUs free in every persistent launch (see mfp_set_reserved_cus): room for RCCL's workgroups when the
+    all-reduce of a gradient bucket overlaps the backward pass (``MFP_DP_RESERVE_CUS``, mfp/dp.py)."""
+    global _reserved_cus
+    check(load().mfp_set_reserved_cus(int(n)), "mfp_set_reserved_cus")
+    _reserved_cus = int(n)
+
+
+def cu_count(device=None) -> int:
+    """Compute units of ``device`` (the current HIP device by default): what a persistent launch aims its grid at."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev not in _cu_count:
+        _cu_count[dev] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    return _cu_count[dev]
 
 
 def wgrad_splitk(T: int, M: int, N: int) -> int:
@@ -202,7 +221,7 @@ def wgrad_splitk(T: int, M: int, N: int) -> int:
     persistent workgroup per CU (the streaming wgrad kernel keeps 8 waves and ~80 KB of LDS per
     workgroup: one per CU), in multiples of 8 (a k-chunk's tiles then share an XCD)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    sk = max(1, _WG_TARGET // max(tiles, 1))
+    sk = max(1, (cu_count() - _reserved_cus) // max(tiles, 1))
     if sk >= 8:
         sk = sk // 8 * 8
     while sk > 1 and T // sk < 256:
@@ -314,7 +333,9 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defe
         with _timed("gemm_wgg_kernel", flops, nbytes):
             check(lib.mfp_wgrad_group_partial(arr, n, K, splitk, ws.data_ptr(), ws.numel(), _stream()), "mfp_wgrad_group_partial")
         defer.append(dict(arr=arr, n=n, splitk=splitk, ws=ws, scope=_scope[-1],
-                          keep=[(j["A"], j["B"], j["out"], j.get("colsum"), j.get("rowskip")) for j in jobs],
+                          # (the partial kernel has consumed A / B / rowskip in stream order: only what the reduction
+                          #  launch writes is kept alive -- views of the persistent gradient buffer)
+                          keep=[(j["out"], j.get("colsum")) for j in jobs],
                           nbytes=need + sum(j["M"] * j["N"] * 4 for j in jobs)))
         return
     ws = workspace(need, dev)
@@ -421,6 +442,22 @@ def block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1,
                                 B, S, D, H, LN_EPS, float(p), int(seed), int(off_attn), int(off_mlp),
                                 _ptr(step_ptr) if step_ptr is not None else None, _stream()), "mfp_block_fwd")
     return x2, (y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
+
+
+def block_infer(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1, W2, b2, B: int, S: int, H: int):
+    """A whole DeepSVG block forward in ONE launch with nothing saved for a backward pass (see mfp_block_infer): the
+    inference callers' form (``MFP.__call__(training=False)``, ``iterative_decode``, eval.py).  Returns x2."""
+    lib = load()
+    T, D = x.shape
+    dev = x.device
+    x1, x2 = (torch.empty((T, D), dtype=torch.float32, device=dev) for _ in range(2))
+    stats = torch.empty((4 * T,), dtype=torch.float32, device=dev)
+    flops = 2 * T * D * 3 * D + 4 * B * S * S * D + 2 * T * D * D + 2 * 2 * T * D * 2 * D
+    with _timed("block_fwd_kernel", flops, T * D * 4 * 5 + 8 * D * D * 2):
+        check(lib.mfp_block_infer(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(Wqkv), _ptr(bqkv), _ptr(Wo), _ptr(bo), _ptr(nvalid),
+                                  _ptr(gamma2), _ptr(beta2), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(x1), _ptr(stats),
+                                  _ptr(x2), B, S, D, H, LN_EPS, _stream()), "mfp_block_infer")
+    return x2
 
 
 def qkv_fused_fwd(x, gamma, beta, W, bias):

@@ -269,8 +269,9 @@ class MFP:
             if length.dtype == torch.int32 and length.is_contiguous():
                 # the head of the step in ONE launch on its counter-based stream: task ids (torch.multinomial is ~8
                 # tiny kernels), nvalid = length + 1, and the loss accumulators zeroed
-                sums_flat = torch.empty(3 * len(loss_key_names(self._all_input_columns)) + 1, dtype=torch.float32,
-                                        device=length.device)
+                # (a captured step writes into a buffer that lives OUTSIDE the graphs' shared pool: capture_train_step)
+                sums_flat = self._sums_buf if getattr(self, "_sums_buf", None) is not None else torch.empty(
+                    3 * len(loss_key_names(self._all_input_columns)) + 1, dtype=torch.float32, device=length.device)
                 tasks, nvalid = ops_hip().step_prologue(self.task_probs, length, self._masker.seed, 1,
                                                         self.model.step_ptr, sums_flat)
             else:
@@ -349,6 +350,8 @@ class MFP:
         through all of them in order (bench.py rotates them so that a step's 4 KB per element of
         inputs come from HBM, not from the infinity cache a single re-masked batch would sit in)."""
         assert self.optimizer is not None, "call compile() first"
+        self.train_steps_resident = None      # (state of an earlier capture)
+        self.static_batches = None
         if resident > 1 and dp.world_size() == 1:
             return self._capture_resident(example_batch, warmup, resident)
         static = {k: v.clone() for k, v in example_batch.items()}
@@ -447,21 +450,41 @@ class MFP:
                 self._apply()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # The graphs share one activation pool and are replayed in ANY order, so nothing a caller reads later may live in
+        # that pool (a later capture's output could sit in a block an earlier graph uses for transients): every capture
+        # writes its per-key sums into its own buffer allocated here, outside the pool.
+        nflat = 3 * len(loss_key_names(self._all_input_columns)) + 1
+        dev = self.model.store.device
+        outs = [torch.zeros(nflat, dtype=torch.float32, device=dev) for _ in range(resident + 1)]
+
+        def pinned(s_, buf):
+            if s_.data_ptr() == buf.data_ptr():      # the fused train path: the step wrote into `buf` itself
+                return s_
+            view = buf[:s_.numel()].view(s_.shape)   # other paths: one small copy node at the end of the step
+            view.copy_(s_)
+            return view
         graphs, sums = [], []
-        for i, static in enumerate(statics):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, pool=graphs[0].pool() if graphs else None):
-                s_ = self._forward_backward(static)
-                self._apply()
-            graphs.append(g)
-            sums.append(s_)
-        # ... and ONE graph that steps through all the buffer sets in order: a training loop that has `resident` batches
-        # staged pays the graph-launch gap (~8-13 us of idle queue between two replays) once per `resident` steps
-        gall = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gall, stream=side, pool=graphs[0].pool()):
-            for static in statics:
-                all_sums = self._forward_backward(static)
-                self._apply()
+        try:
+            for i, static in enumerate(statics):
+                g = torch.cuda.CUDAGraph()
+                self._sums_buf = outs[i]
+                with torch.cuda.graph(g, stream=side, pool=graphs[0].pool() if graphs else None):
+                    s_ = self._forward_backward(static)
+                    self._apply()
+                    s_ = pinned(s_, outs[i])
+                graphs.append(g)
+                sums.append(s_)
+            # ... and ONE graph that steps through all the buffer sets in order: a training loop that has `resident` batches
+            # staged pays the graph-launch gap (~8-13 us of idle queue between two replays) once per `resident` steps
+            gall = torch.cuda.CUDAGraph()
+            self._sums_buf = outs[resident]
+            with torch.cuda.graph(gall, stream=side, pool=graphs[0].pool()):
+                for static in statics:
+                    all_sums = self._forward_backward(static)
+                    self._apply()
+                all_sums = pinned(all_sums, outs[resident])
+        finally:
+            self._sums_buf = None
 
         def replay_all():
             gall.replay()
@@ -472,17 +495,15 @@ class MFP:
         by_ptr = {st["left"].data_ptr(): i for i, st in enumerate(statics)}
 
         def replay(batch):
-            i = by_ptr.get(batch["left"].data_ptr())
-            if i is None:
-                if any(k in statics[0] and tuple(v.shape) != tuple(statics[0][k].shape) for k, v in batch.items()):
-                    s_ = self._forward_backward(batch)
-                    self._apply()
-                    self.last_sums = s_
-                    return s_
-                i = 0
-                for k, v in batch.items():
-                    if k in statics[0]:
-                        statics[0][k].copy_(v, non_blocking=True)
+            if any(k in statics[0] and tuple(v.shape) != tuple(statics[0][k].shape) for k, v in batch.items()):
+                s_ = self._forward_backward(batch)
+                self._apply()
+                self.last_sums = s_
+                return s_
+            i = by_ptr.get(batch["left"].data_ptr(), 0)
+            for k, v in batch.items():      # (a dict that reuses some static buffers with other fresh tensors: copy those)
+                if k in statics[i] and v.data_ptr() != statics[i][k].data_ptr():
+                    statics[i][k].copy_(v, non_blocking=True)
             graphs[i].replay()
             self.last_sums = sums[i]
             return sums[i]

@@ -188,6 +188,8 @@ class ParamStore:
         # fp8 mode (BASELINE config c5): e4m3 copies of the fused Q|K|V and FFN1 kernels ([out][in], as stored)
         # with one scale per copy, refreshed after every optimizer step; everything else stays bf16
         self.fp8 = bool(fp8) and compute_dtype == torch.bfloat16 and torch.device(device).type == "cuda"
+        if self.fp8 and layout.D % 128 != 0:      # (one MX MFMA contracts 128 input features: csrc/gemm_fp8.hip)
+            raise ValueError("dtype='fp8' needs latent_dim %% 128 == 0 (got %d)" % layout.D)
         self.shadow8, self.scale8, self._fp8_tensors = None, None, []
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype

@@ -38,6 +38,14 @@ enum {
 const char* mfp_last_error(void);
 int mfp_version(void);
 
+/* Compute units of the current device, and how many of them persistent launches (one workgroup per CU: grouped weight
+ * gradients, weight-stationary products, single-pass attention backward) leave FREE: with N > 1 ranks RCCL's
+ * workgroups cannot share a CU with a 160 KB / 8-wave workgroup, so a data-parallel run may reserve n CUs for the
+ * all-reduce that overlaps the backward pass (new; the reference's train.py:25 strategy line is commented out).
+ * 0 <= n <= #CUs - 8; process-wide; returns MFP_EINVAL otherwise. */
+int mfp_cu_count(void);
+int mfp_set_reserved_cus(int n);
+
 /* ---------------------------------------------------------------------------------- GEMM
  * One MFMA tile kernel with epilogue flags.
  * C[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] ).  Operand storage:
@@ -189,6 +197,15 @@ int mfp_block_fwd(const float* x, const float* gamma, const float* beta, const v
                   float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
                   float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
                   const int32_t* step_ptr, mfp_stream_t stream);
+
+/* Inference form of mfp_block_fwd (what MFP.__call__(training=False), iterative_decode and eval.py run: reference
+ * models/mfp.py:141-207, eval.py:35-118): the same single launch with nothing saved for a backward pass -- y1, qkv, a, lse,
+ * y2 and h never reach memory (2 KB instead of 7.2 KB written per element); dropout off.  x1 f32 [T,256] is scratch (the
+ * MLP half re-reads it as its residual), stats f32 [4 T] scratch for the LayerNorm statistics.  S = 128, d_model 256. */
+int mfp_block_infer(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                    const void* Wo, const float* bo, const int32_t* nvalid, const float* gamma2, const float* beta2,
+                    const void* W1, const float* b1, const void* W2, const float* b2, float* x1, float* stats,
+                    float* x2, int32_t B, int32_t S, int32_t D, int32_t H, float eps, mfp_stream_t stream);
 
 /* LayerNormalization + the fused Q | K | V Dense of a block in one launch (transformer.py:216-217,85-90):
  * qkv bf16 [T,768] = LN(x) W^T + bias, with y1 = LN(x) (bf16 [T,256]), mean, rstd (f32 [T]) saved for the

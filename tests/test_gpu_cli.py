@@ -133,5 +133,5 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["params_in_sync"] is True and line["value"] > 0
-    assert line["dp"]["rccl_ranks"] == 2 and sum(b["params"] for b in line["dp"]["plan"]) == line["config"]["params"]
+    assert line["dp"]["collective_ranks"] == 2 and sum(b["params"] for b in line["dp"]["plan"]) == line["config"]["params"]
     assert "roofline" in line and "cpu_baseline" not in line

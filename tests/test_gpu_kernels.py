@@ -1301,3 +1301,6 @@ def test_block_fwd(B, p):
         assert_close(h, hd, 2e-2, 1e-2, "h vs double")
         want = x1.cpu().double() + h.float().cpu().double() @ W2.double().t() + c2.double()
         assert_close(x2, want, 5e-3, 2e-3, "x2 vs double")
+        # mfp_block_infer: the same launch with nothing saved (inference callers) -- x2 bit for bit
+        x2i = ops.block_infer(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H)
+        assert torch.equal(x2i, x2)

@@ -717,6 +717,86 @@ def test_train_step_timed_route_vs_oracle():
     assert bare(eager_names) == bare(got_names), (bare(eager_names), bare(got_names))
 
 
+# total-loss deviation of the bf16 replay from the f64 oracle's trajectory, at EVERY step (north_star's 1e-3)
+TRAJ_LOSS_BUDGET = 1e-3
+TRAJ_DELTA_COS = 0.99        # cosine of the accumulated parameter change after the last step, all parameters
+TRAJ_DELTA_COS_VAR = 0.95    # ... and per significant variable (worst)
+
+
+@pytest.mark.parametrize("res16", [True, False])
+def test_train_trajectory_timed_route_vs_oracle(res16):
+    """Ten consecutive steps of the timed bf16 route (the hipGraph replay of ``test_train_step_timed_route_vs_oracle``)
+    against ten steps of the f64 oracle (oracle/torch_ref.py: loss_and_grads + apply_gradients; reference train.py:71-77):
+    each engine steps its OWN parameters from the same start, on the masks the replay draws at that step (inferred from
+    the masking kernel's output and replayed through the oracle's masking, bit for bit), dropout 0, the reference's
+    learning rate.  Asserts the total loss stays within 1e-3 of the oracle's curve at every step and that the accumulated
+    parameter change points the same way -- once with the bf16 residual-gradient stream (the default since round 4) and
+    once with the f32 stream."""
+    from oracle import np_ref, torch_ref
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.hip import functions
+    from mfp.models.mfp import MFP
+    S, D, L, B, lr, l2, steps = 128, 256, 4, 32, 1e-4, 1e-2, 10
+    ic = make_input_columns("crello")
+    params = np_ref.init_params(ic, D, L, seed=-11)
+    batch = synthetic_batch(ic, B, S, seed=31, ragged=True)
+    dbatch = {k: v.to(DEV) for k, v in batch.items()}
+    state = torch_ref.TrainState(params, lr=lr, l2=l2, clipnorm=1.0, dtype=torch.float64)
+    w0 = {k: v.detach().clone() for k, v in state.p.items()}
+    cast = lambda d: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+    old = functions.RES_GRAD_BF16
+    functions.RES_GRAD_BF16 = res16
+    curve = []
+    try:
+        with _route("timed"):
+            model = MFP(ic, num_blocks=L, latent_dim=D, dropout=0.0, l2=l2, masking_method="random", dtype="bf16",
+                        device=DEV, seed=5)
+            model.compile(learning_rate=lr)
+            model.train_step(dbatch)
+            model.capture_train_step(dbatch, warmup=1)
+            store, opt = model.model.store, model.optimizer
+            store.load_state_dict(params)
+            opt.m.zero_(), opt.v.zero_(), opt.step_t.zero_()
+            before = store.state_dict()
+            gmax = None
+            for t in range(steps):
+                modified, masks = _masker_output_as_oracle_inputs(model, ic, batch, dbatch, B, S)
+                sums = model.train_step(dbatch)          # one replay: masks of step counter t, then Adam step t + 1
+                torch.cuda.synchronize()
+                assert int(opt.step_t.item()) == t + 1
+                got = float(sums[:, 0].double().sum())
+                info, grads = torch_ref.loss_and_grads(state, ic, cast(batch), cast(modified), masks, L, maxlen=S)
+                if gmax is None:
+                    gmax = {k: float(g.abs().max()) for k, g in grads.items()}
+                torch_ref.apply_gradients(state, grads)
+                want = float(info["data_loss"])
+                curve.append((got, want, abs(got - want) / want))
+            after = store.state_dict()
+    finally:
+        functions.RES_GRAD_BF16 = old
+    top = max(gmax.values())
+    dots = nw = ng = 0.0
+    var_cos = {}
+    for name in w0:
+        d_want = (state.p[name].detach() - w0[name]).reshape(-1)
+        d_got = (after[name].double() - before[name].double()).reshape(-1)
+        dots, nw, ng = dots + float(torch.dot(d_want, d_got)), nw + float(d_want.norm() ** 2), ng + float(d_got.norm() ** 2)
+        if gmax[name] >= 1e-3 * top:
+            var_cos[name] = float(torch.dot(d_want, d_got) / (d_want.norm() * d_got.norm() + 1e-300))
+    cos_all = dots / ((nw * ng) ** 0.5 + 1e-300)
+    worst = max(c[2] for c in curve)
+    _record("c2_bf16_trajectory_%s" % ("res16" if res16 else "res32"),
+            dict(B=B, S=S, D=D, L=L, lr=lr, steps=steps, loss_rel_dev_per_step=[c[2] for c in curve],
+                 oracle_loss_per_step=[c[1] for c in curve], worst_loss_rel_dev=worst, param_delta_cosine=cos_all,
+                 worst_variable_delta_cosine=min(var_cos.values())))
+    print("trajectory (res16=%s): worst loss rel dev %.2e over %d steps (%.1f -> %.1f), delta cosine %.5f, worst variable %.4f"
+          % (res16, worst, steps, curve[0][1], curve[-1][1], cos_all, min(var_cos.values())))
+    assert curve[-1][1] < curve[0][1]                      # the oracle's loss falls over the ten steps
+    assert worst <= TRAJ_LOSS_BUDGET, [c[2] for c in curve]
+    assert cos_all >= TRAJ_DELTA_COS, cos_all
+    assert min(var_cos.values()) >= TRAJ_DELTA_COS_VAR, var_cos
+
+
 def test_grouped_wgrad_equals_per_product_path():
     """bf16 step at the timed widths: every parameter gradient from the grouped weight-gradient launches
     (csrc/gemm_wgg.h: split-K reduction inside the launch) against the per-product mfp_gemm + reduce
@@ -912,9 +992,10 @@ def test_context_id_trains_through_the_api():
 
 
 def test_c5_fp8_deviation_and_training():
-    """BASELINE config c5 precision mode: e4m3 QKV / FFN1 forward products (per-tensor scales), everything
-    else bf16.  Loss deviation from the f64 oracle at the c5 shape is MEASURED and recorded (the north_star
-    bound of 1e-3 is stated for bf16; fp8 is reported), and the mode trains through eager steps + hipGraph."""
+    """BASELINE config c5 precision mode: the QKV / FFN1 forward products as OCP-MX block-scaled products (e4m3
+    elements, one e8m0 scale per 32 input features, v_mfma_scale_f32_16x16x128_f8f6f4), everything else bf16.  Loss
+    deviation from the f64 oracle at the c5 shape is MEASURED and recorded (the north_star bound of 1e-3 is stated
+    for bf16; fp8 is reported), and the mode trains through eager steps + hipGraph."""
     from mfp.data.spec import make_input_columns, synthetic_batch
     from mfp.models.mfp import MFP
     S, D, L, B = 256, 512, 8, 2

@@ -64,6 +64,9 @@ if "block" in which:
     step = torch.zeros(1, dtype=torch.int32, device=dev)
     timeit("block_fwd (1 launch)", lambda: ops.block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8, 0.1, 5, 3, 4, step),
            T * (256 * 4 * 5 + 256 * 2 * 3 + 768 * 2 + 512 * 2))
+    # the inference form (nothing saved): what the in-CU pipeline does when only x1 / x2 cross HBM
+    timeit("block_infer (1 launch)", lambda: ops.block_infer(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8),
+           T * 256 * 4 * 5)
     def two():
         x1 = ops.attn_block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, B, 128, 8, (0.1, 5, 3), step)[0]
         return ops.mlp_fused_fwd(x1, g2, be2, W1, b1, W2, b2, (0.1, 5, 4), step)

@@ -5,7 +5,9 @@
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-template <int MODE>      // 0: as the kernels (wf double-buffered by hand), 1: MFMAs only, 2: LDS reads only
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int MODE>      // 0: as the kernels (wf double-buffered by hand), 1: MFMAs only, 2: LDS reads only,
+                         // 3: the same product as v_mfma_f32_32x32x16_bf16 (wave = one 32 x 32 tile, 16 MFMAs + 16 ds_read_b128), 4: those MFMAs only
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
@@ -18,6 +20,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
   for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
   const unsigned char* wa = smem + ((nh * 2) * 16 + li) * 512;
   f32x4 acc[2][2] = {};
+  f32x16 acc32 = {};
   f32x4 junk = {0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) {
@@ -35,6 +38,18 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
       for (int ks = 0; ks < 8; ++ks)
         for (int nt = 0; nt < 2; ++nt)
           for (int rt = 0; rt < 2; ++rt) acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[nt][ks], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+    } else if (MODE == 3 || MODE == 4) {
+      // wave (rp, nh): rows 32 rp .. + 31 (B operand: lane l = row l & 31, k = 16 ks + 8 (l >> 5) .. + 7, from xf) x chunk columns
+      // 32 nh .. + 31 (A operand: lane l = weight row 32 nh + (l & 31), 16-byte slot 2 ks + (l >> 5) of its 512-byte image row)
+      const unsigned char* wr = smem + (nh * 32 + (lane & 31)) * 512;
+      const int sw = lane & 15, hi = lane >> 5;
+      bf16x8 wf2[2];
+      if (MODE == 3) wf2[0] = *reinterpret_cast<const bf16x8*>(wr + (((0 + hi) ^ sw) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (MODE == 3 && ks + 1 < 16) wf2[(ks + 1) & 1] = *reinterpret_cast<const bf16x8*>(wr + ((((ks + 1) * 2 + hi) ^ sw) << 4));
+        acc32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MODE == 3 ? wf2[ks & 1] : xf[1][ks & 7], xf[ks >> 3][ks & 7], acc32, 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
@@ -46,6 +61,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     asm volatile("" ::: "memory");
   }
   float s = junk[0] + junk[1];
+  for (int r = 0; r < 16; ++r) s += acc32[r];
   for (int nt = 0; nt < 2; ++nt) for (int rt = 0; rt < 2; ++rt) for (int r = 0; r < 4; ++r) s += acc[nt][rt][r];
   if (s == 1234.5f) out[0] = s;
 }
@@ -64,5 +80,6 @@ void run(float* out, const char* what) {
 int main() {
   float* out; hipMalloc(&out, 4);
   run<0>(out, "LDS reads + MFMAs (kernel)"); run<1>(out, "MFMAs only"); run<2>(out, "LDS reads only");
+  run<3>(out, "32x32x16: LDS reads + MFMAs"); run<4>(out, "32x32x16: MFMAs only");
   return 0;
 }
