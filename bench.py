@@ -431,7 +431,7 @@ def main():
         "input_residency": ("%d batches resident in HBM, rotated (%.0f MB of inputs per batch: beyond the 256 MB infinity cache)"
                             % (len(batches), sum(v.numel() * v.element_size() for v in batch.values()) / 1e6)
                             if len(batches) > 1 else "one batch, re-masked every step (its inputs can sit in the infinity cache)"),
-        "fused_path": bool(dtype in ("bf16", "fp8") and D == 256 and S == 128),
+        "fused_path": bool((dtype in ("bf16", "fp8") and D == 256 and S == 128) or (dtype == "bf16" and D == 512)),
     }
     if dp_info is not None:
         out["dp"] = dp_info

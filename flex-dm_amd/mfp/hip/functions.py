@@ -76,6 +76,16 @@ def _fused_ok(ctx, D) -> bool:
     return MLP_FUSE and ctx.cdt == torch.bfloat16 and D == 256 and ctx.T <= FUSE_MAX_T
 
 
+# bf16 path, d_model 512 (BASELINE config c5): LN1 + Q|K|V and LN2 + FFN1 as one launch each, the products with a d_model-wide
+# output (attention output projection, FFN2, the three input gradients) on the row-owning kernel (csrc/block_d512.hip);
+# 0 = ln_fwd + the generic weight-stationary / LDS-tiled products
+D512_FUSE = os.environ.get("MFP_D512_FUSE", "1") == "1"
+
+
+def _fused512_ok(ctx, D) -> bool:
+    return D512_FUSE and ctx.cdt == torch.bfloat16 and D == 512 and ctx.T <= (1 << 19) and not ctx.store.fp8
+
+
 def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False, w8=None):
     """``Dense(LayerNormalization(x))`` of a DeepSVG block (transformer.py:216-217 / 222-223): returns
     (out, y = LN(x) in the compute dtype, mean, rstd).  ``w8`` = (fp8 kernel, its e8m0 block scales): fp8 mode."""
@@ -412,6 +422,25 @@ class BlockFn(torch.autograd.Function):
             fctx.ctx, fctx.i = ctx, i
             fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
             return x2
+        if _fused512_ok(ctx, D):
+            # d_model 512: LN1 + Q|K|V | attention | output projection + dropout + residual | LN2 + FFN1 + ReLU | FFN2 + dropout +
+            # residual = five launches (csrc/block_d512.hip); the last block also leaves the heads' bf16 operand
+            qkv, y1, mean1, rstd1 = ops.ln_dense_d512(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
+                                                      st.cw(p + "attn/dense_query/kernel", rows=3 * D),
+                                                      st.span(st.w, p + "attn/dense_query/bias", 3 * D), 3 * D)
+            a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
+            x1 = ops.dense_n512_res(a, st.cw(p + "attn/combine_heads/kernel"), st.weight(p + "attn/combine_heads/bias"), x,
+                                    (ctx.p, ctx.seed, 2 * i + 1), ctx.step_ptr)
+            h, y2, mean2, rstd2 = ops.ln_dense_d512(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
+                                                    st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), 2 * D, relu=True)
+            x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)
+                    if ctx.tail["fuse"] and i == st.layout.L - 1 else None)
+            x2 = ops.dense_n512_res(h, st.cw(p + "mlp/dense_1/kernel"), st.weight(p + "mlp/dense_1/bias"), x1,
+                                    (ctx.p, ctx.seed, 2 * i + 2), ctx.step_ptr, out_bf16=x2_c)
+            ctx.tail["x_c"] = (x2, x2_c) if x2_c is not None else None
+            fctx.ctx, fctx.i = ctx, i
+            fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
+            return x2
         if ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S:
             # the whole attention half in one launch
             x1, y1, mean1, rstd1, qkv, a, lse = ops.attn_block_fwd(
@@ -475,8 +504,11 @@ class BlockFn(torch.autograd.Function):
         wt = st.cwt(p + "mlp/dense_1/kernel")     # [2D][D]: dgrad as a k-major product when kept
         wt0 = st.cwt(p + "mlp/dense_0/kernel")    # [D][2D]
         fused_bwd = _fused_ok(ctx, D) and wt is not None and wt0 is not None
+        f512 = _fused512_ok(ctx, D) and wt is not None and wt0 is not None
         if fused_bwd:      # both input-gradient products of the half in one launch (csrc/block_fused.hip)
             dh, dy2 = ops.mlp_fused_bwd(d_o2, h, wt, wt0)
+        elif f512:         # d_model 512 (csrc/block_d512.hip): the ReLU mask in the first product's epilogue, row-owning second
+            dh = ops.dense_relumask_d512(d_o2, wt, h)
         else:
             dh = ops.gemm(d_o2, wt if wt is not None else st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True,
                           b_kmajor=wt is not None, out_dtype=cdt, relu_bwd_aux=h)
@@ -490,7 +522,9 @@ class BlockFn(torch.autograd.Function):
                      colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
         if not grouped:
             ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
-        if not fused_bwd:
+        if f512:
+            dy2 = ops.dense_n512(dh, wt0)
+        elif not fused_bwd:
             dy2 = ops.gemm(dh, wt0 if wt0 is not None else st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True,
                            b_kmajor=wt0 is not None, out_dtype=cdt)
         # LN2 backward also emits the masked/cast gradient of the attention Dropout + its bias grad
@@ -509,6 +543,8 @@ class BlockFn(torch.autograd.Function):
         else:
             if _fused_ok(ctx, D) and wt is not None:
                 da = ops.dgrad_d256(d_o1, wt)      # activation-stationary (csrc/block_fused.hip)
+            elif _fused512_ok(ctx, D) and wt is not None:
+                da = ops.dense_n512(d_o1, wt)      # row-owning (csrc/block_d512.hip)
             else:
                 da = ops.gemm(d_o1, wt if wt is not None else st.cw(p + "attn/combine_heads/kernel"), T, D, D,
                               a_kmajor=True, b_kmajor=wt is not None, out_dtype=cdt)
@@ -539,6 +575,8 @@ class BlockFn(torch.autograd.Function):
             pass
         elif _fused_ok(ctx, D) and wtq is not None:
             dy1 = ops.dgrad_qkv(dqkv, wtq)       # activation-stationary (csrc/block_fused.hip)
+        elif _fused512_ok(ctx, D) and wtq is not None:
+            dy1 = ops.dense_n512(dqkv, wtq)      # row-owning (csrc/block_d512.hip)
         else:
             dy1 = ops.gemm(dqkv, wtq if wtq is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
                            3 * D, a_kmajor=True, b_kmajor=wtq is not None, out_dtype=cdt)

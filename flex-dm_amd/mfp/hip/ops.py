@@ -444,6 +444,59 @@ def block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1,
     return x2, (y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
 
 
+# ---------------------------------------------------------------- d_model 512 (csrc/block_d512.hip)
+def ln_dense_d512(x, gamma, beta, W, bias, N: int, relu: bool = False):
+    """out = (relu?)(LN(x) W^T + bias) in one launch, d_model 512 (see mfp_ln_dense_d512).  Returns (out, y, mean, rstd)."""
+    lib = load()
+    T, D = x.shape
+    assert D == 512 and x.dtype == torch.float32 and W.dtype == torch.bfloat16
+    dev = x.device
+    y = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    out = torch.empty((T, N), dtype=torch.bfloat16, device=dev)
+    mean = torch.empty((T,), dtype=torch.float32, device=dev)
+    rstd = torch.empty((T,), dtype=torch.float32, device=dev)
+    with _timed("as512_kernel", 2 * T * D * N, T * (D * 4 + D * 2 + N * 2) + N * D * 2):
+        check(lib.mfp_ln_dense_d512(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(W), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd),
+                                    _ptr(out), T, N, int(relu), LN_EPS, _stream()), "mfp_ln_dense_d512")
+    return out, y, mean, rstd
+
+
+def dense_relumask_d512(A, W, aux):
+    """out bf16 [T, N] = (A W^T) * [aux > 0] (see mfp_dense_relumask_d512): A [T, 512], W [N, 512], aux [T, N]."""
+    lib = load()
+    T, K = A.shape
+    N = aux.shape[1]
+    assert K == 512 and A.dtype == torch.bfloat16 and aux.dtype == torch.bfloat16 and A.is_contiguous() and aux.is_contiguous()
+    out = torch.empty((T, N), dtype=torch.bfloat16, device=A.device)
+    with _timed("as512_kernel", 2 * T * K * N, T * (K * 2 + 2 * N * 2) + N * K * 2):
+        check(lib.mfp_dense_relumask_d512(_ptr(A), _ptr(W), _ptr(aux), _ptr(out), T, N, _stream()), "mfp_dense_relumask_d512")
+    return out
+
+
+def dense_n512_res(A, W, bias, residual, dropout: Tuple[float, int, int] = (0.0, 0, 0), step_ptr=None, out_bf16=None):
+    """out f32 [T, 512] = residual + Dropout(A W^T + bias) (see mfp_dense_n512_res): A bf16 [T, K], W bf16 [512, K]."""
+    lib = load()
+    T, K = A.shape
+    assert A.dtype == torch.bfloat16 and A.is_contiguous() and residual.dtype == torch.float32 and residual.shape == (T, 512)
+    out = torch.empty((T, 512), dtype=torch.float32, device=A.device)
+    with _timed("os512_kernel", 2 * T * K * 512, T * (K * 2 + 512 * 8 + (512 * 2 if out_bf16 is not None else 0)) + 512 * K * 2):
+        check(lib.mfp_dense_n512_res(_ptr(A), _ptr(W), _ptr(bias), _ptr(residual), _ptr(out), _ptr(out_bf16), T, K,
+                                     float(dropout[0]), int(dropout[1]), int(dropout[2]),
+                                     _ptr(step_ptr) if step_ptr is not None else None, _stream()), "mfp_dense_n512_res")
+    return out
+
+
+def dense_n512(A, W):
+    """out bf16 [T, 512] = A W^T (see mfp_dense_n512): A bf16 [T, K], W bf16 [512, K]."""
+    lib = load()
+    T, K = A.shape
+    assert A.dtype == torch.bfloat16 and A.is_contiguous()
+    out = torch.empty((T, 512), dtype=torch.bfloat16, device=A.device)
+    with _timed("os512_kernel", 2 * T * K * 512, T * (K * 2 + 512 * 2) + 512 * K * 2):
+        check(lib.mfp_dense_n512(_ptr(A), _ptr(W), _ptr(out), T, K, _stream()), "mfp_dense_n512")
+    return out
+
+
 def block_infer(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1, W2, b2, B: int, S: int, H: int):
     """A whole DeepSVG block forward in ONE launch with nothing saved for a backward pass (see mfp_block_infer): the
     inference callers' form (``MFP.__call__(training=False)``, ``iterative_decode``, eval.py).  Returns x2."""

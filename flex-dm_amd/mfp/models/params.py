@@ -205,9 +205,10 @@ class ParamStore:
         if self.shadow is not None and torch.device(device).type == "cuda":
             segs = [(s.offset, s.shape[0], s.shape[1]) for s in layout.segments.values()
                     if s.transposed and ("/mlp/" in s.name or "/combine_heads/" in s.name)
-                    and s.shape[0] in WS_K]
-            # fused Q|K|V ([3D][D], three adjacent variables) -> one [D][3D] block at the query offset
-            if 3 * layout.D == 768:
+                    and (s.shape[0] in WS_K or layout.D == 512)]
+            # fused Q|K|V ([3D][D], three adjacent variables) -> one [D][3D] block at the query offset (d_model 256: the
+            # activation-stationary kernels of csrc/block_fused.hip; d_model 512: csrc/block_d512.hip)
+            if layout.D in (256, 512):
                 for i in range(layout.L):
                     q = layout.segments["blocks/seq2seq_%d/attn/dense_query/kernel" % i]
                     for j, nm in enumerate(("dense_query", "dense_key", "dense_value")):
@@ -291,10 +292,10 @@ class ParamStore:
             return None
         s = self.layout.segments[name]
         if name.endswith("attn/dense_query/kernel"):     # the fused Q|K|V block, [D][3D]
-            if 3 * self.layout.D != 768:
+            if self.layout.D not in (256, 512):
                 return None
             return self.shadow_t[s.offset:s.offset + 3 * s.size].view(s.shape[1], 3 * s.shape[0])
-        if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and s.shape[0] in WS_K):
+        if not (s.transposed and ("/mlp/" in name or "/combine_heads/" in name) and (s.shape[0] in WS_K or self.layout.D == 512)):
             return None
         return self.shadow_t[s.offset:s.offset + s.size].view(s.shape[1], s.shape[0])
 

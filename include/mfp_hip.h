@@ -198,6 +198,28 @@ int mfp_block_fwd(const float* x, const float* gamma, const float* beta, const v
                   float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
                   const int32_t* step_ptr, mfp_stream_t stream);
 
+/* --------------------------------------------------------------------------- Dense layers of a block at d_model 512
+ * (csrc/block_d512.hip; BASELINE config 5 = Crello Ours-EXP-FT: reference args.py:29-38 --latent_dim 512 --num_blocks 8;
+ * the layers are transformer.py:85-90,161-171,216-225 and their autodiff).  All weights bf16 [out][in] (k-major).
+ *
+ * mfp_ln_dense_d512:       out bf16 [T,N] = (relu?)(LayerNorm(x) W^T + bias), x f32 [T,512], W [N][512]; saves y = LN(x) bf16
+ *                          [T,512], mean / rstd f32 [T] (what mfp_layernorm_fwd + mfp_gemm leave): LN1 + Q|K|V, LN2 + FFN1.
+ * mfp_dense_relumask_d512: out bf16 [T,N] = (A W^T) * [aux > 0], A bf16 [T,512], W [N][512], aux bf16 [T,N] (the saved ReLU
+ *                          output): dh = (d_o2 W2) * [h > 0].
+ * mfp_dense_n512_res:      out f32 [T,512] = residual + Dropout(A W^T + bias), A bf16 [T,K], W [512][K], K % 128 == 0;
+ *                          out_bf16 (may be NULL): a bf16 copy; dropout stream = MFP_GEMM_DROPOUT's (seed, offset, step_ptr):
+ *                          attention output projection (K = 512), FFN2 (K = 1024).
+ * mfp_dense_n512:          out bf16 [T,512] = A W^T, A bf16 [T,K], W [512][K]: the input gradients da = d_o1 Wo (K = 512),
+ *                          dy2 = dh W1 (K = 1024), dy1 = dqkv Wqkv (K = 1536) on the transposed shadows.
+ * N % 128 == 0.  Never allocate, never synchronise. */
+int mfp_ln_dense_d512(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
+                      float* mean, float* rstd, void* out, int32_t T, int32_t N, int32_t relu, float eps, mfp_stream_t stream);
+int mfp_dense_relumask_d512(const void* A, const void* W, const void* aux, void* out, int32_t T, int32_t N, mfp_stream_t stream);
+int mfp_dense_n512_res(const void* A, const void* W, const float* bias, const float* residual, float* out, void* out_bf16,
+                       int32_t T, int32_t K, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
+                       mfp_stream_t stream);
+int mfp_dense_n512(const void* A, const void* W, void* out, int32_t T, int32_t K, mfp_stream_t stream);
+
 /* Inference form of mfp_block_fwd (what MFP.__call__(training=False), iterative_decode and eval.py run: reference
  * models/mfp.py:141-207, eval.py:35-118): the same single launch with nothing saved for a backward pass -- y1, qkv, a, lse,
  * y2 and h never reach memory (2 KB instead of 7.2 KB written per element); dropout off.  x1 f32 [T,256] is scratch (the

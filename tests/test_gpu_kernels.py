@@ -1304,3 +1304,85 @@ def test_block_fwd(B, p):
         # mfp_block_infer: the same launch with nothing saved (inference callers) -- x2 bit for bit
         x2i = ops.block_infer(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H)
         assert torch.equal(x2i, x2)
+
+
+# ------------------------------------------------------------------------------------ d_model 512 (csrc/block_d512.hip)
+@pytest.mark.parametrize("T,N,relu", [(256, 1536, False), (1000, 1024, True), (16384, 1536, False), (384, 128, True)])
+def test_ln_dense_d512(T, N, relu):
+    """mfp_ln_dense_d512 (LN1 + Q|K|V, LN2 + FFN1 + ReLU of a d_model-512 block: transformer.py:216-217,222-223,161-166) against
+    a double reference: LN statistics and y, then the product FROM THE KERNEL'S OWN bf16 y (so the bound is the product's)."""
+    ops = _ops()
+    D = 512
+    g = torch.Generator().manual_seed(500 + N + T)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(T, D) * (0.5 + torch.rand(T, 1, generator=g)) + 0.3 * rn(T, 1)
+    gam, bet = 1.0 + 0.2 * rn(D), 0.1 * rn(D)
+    W, b = bf16_round(rn(N, D) * 0.05), rn(N) * 0.1
+    out, y, mean, rstd = ops.ln_dense_d512(x.to(DEV), gam.to(DEV), bet.to(DEV), W.to(DEV, torch.bfloat16), b.to(DEV), N, relu=relu)
+    xd = x.double()
+    mu = xd.mean(1)
+    var = ((xd - mu[:, None]) ** 2).mean(1)
+    rs = 1.0 / torch.sqrt(var + 1e-3)
+    assert_close(mean, mu, 1e-5, 1e-5, "mean")
+    assert_close(rstd, rs, 1e-5, 1e-4, "rstd")
+    yw = (xd - mu[:, None]) * rs[:, None] * gam.double() + bet.double()
+    assert_close(y, yw, 2e-2, 8e-3, "y = LN(x)")
+    want = y.float().cpu().double() @ W.double().t() + b.double()
+    if relu:
+        want = torch.relu(want)
+    assert_close(out, want, 2e-2, 8e-3, "out vs double (from the kernel's own y)")
+
+
+@pytest.mark.parametrize("T,N", [(256, 1024), (1000, 1024), (16384, 1024), (128, 256)])
+def test_dense_relumask_d512(T, N):
+    """mfp_dense_relumask_d512: dh = (d_o2 W2) * [h > 0] (autodiff of transformer.py:161-171) against a double reference."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(600 + T)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    A, W = bf16_round(rn(T, 512)), bf16_round(rn(N, 512) * 0.05)
+    h = bf16_round(torch.relu(rn(T, N)))
+    out = ops.dense_relumask_d512(A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16), h.to(DEV, torch.bfloat16))
+    want = (A.double() @ W.double().t()) * (h > 0).double()
+    assert_close(out, want, 2e-2, 8e-3, "dh vs double")
+    assert torch.equal(out.cpu() == 0, (h == 0) | (out.cpu() == 0)) and bool((out.cpu()[h == 0] == 0).all())
+
+
+@pytest.mark.parametrize("T,K,p", [(256, 512, 0.0), (1000, 1024, 0.1), (16384, 1024, 0.1), (64, 1536, 0.0)])
+def test_dense_n512_res(T, K, p):
+    """mfp_dense_n512_res (attention output projection / FFN2 of a d_model-512 block with dropout and residual:
+    transformer.py:218-221,224-225) against a double reference; the dropout mask is mfp_gemm's for the same stream (the
+    backward kernels regenerate it from (seed, offset, step, row, column))."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(700 + T + K)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    A, W, b, res = bf16_round(rn(T, K)), bf16_round(rn(512, K) * 0.04), rn(512) * 0.1, rn(T, 512)
+    step = torch.full((1,), 3, dtype=torch.int32, device=DEV)
+    oc = torch.empty(T, 512, dtype=torch.bfloat16, device=DEV)
+    Ad, Wd, bd, rd = A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16), b.to(DEV), res.to(DEV)
+    out = ops.dense_n512_res(Ad, Wd, bd, rd, (p, 11, 5), step, out_bf16=oc)
+    lin = A.double() @ W.double().t() + b.double()
+    if p == 0.0:
+        assert_close(out, res.double() + lin, 2e-2, 3e-3, "out vs double")
+    else:
+        ref = ops.gemm(Ad, Wd, T, 512, K, a_kmajor=True, b_kmajor=True, bias=bd, residual=rd, dropout=(p, 11, 5), step_ptr=step,
+                       out_dtype=torch.float32)
+        keep = ((ref.cpu().double() - res.double()).abs() > 1e-12)      # mfp_gemm's mask for the same stream
+        frac = keep.double().mean().item()
+        assert abs(frac - (1 - p)) < 0.01, frac
+        assert_close(out, res.double() + keep.double() * lin / (1 - p), 3e-2, 3e-3, "out vs double under mfp_gemm's mask")
+    assert torch.equal(oc.view(torch.int16), out.to(torch.bfloat16).view(torch.int16))
+    # the copy is optional
+    out2 = ops.dense_n512_res(Ad, Wd, bd, rd, (p, 11, 5), step)
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("T,K", [(256, 512), (1000, 1024), (16384, 1536), (64, 1024)])
+def test_dense_n512(T, K):
+    """mfp_dense_n512: the input gradients da = d_o1 Wo, dy2 = dh W1, dy1 = dqkv Wqkv of a d_model-512 block (autodiff of
+    transformer.py:85-99,161-171) on the transposed weight shadows, against a double reference."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(800 + T + K)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    A, W = bf16_round(rn(T, K)), bf16_round(rn(512, K) * 0.04)
+    out = ops.dense_n512(A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16))
+    assert_close(out, A.double() @ W.double().t(), 2e-2, 8e-3, "out vs double")

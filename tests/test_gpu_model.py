@@ -535,6 +535,11 @@ class _route:
             os.environ["MFP_FUSED_HALF"] = self.old[1]
 
 
+def re_sub_template(name):
+    import re
+    return re.sub(r"<.*$", "", name)
+
+
 def _kernel_names(fn):
     """Names (template arguments kept, parameter lists cut) of the device kernels ``fn`` launches, through the
     HIP activity tracer behind torch.profiler."""
@@ -884,23 +889,40 @@ def test_bf16_residual_gradient_stream_vs_f32():
 
 
 # ------------------------------------------------------------------ BASELINE config c5 shape (D=512, 8 blocks, S=256)
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_c5_shape_parity_vs_oracle(dtype):
+@pytest.mark.parametrize("dtype,route", [("fp32", "default"), ("bf16", "d512"), ("bf16", "generic")])
+def test_c5_shape_parity_vs_oracle(dtype, route):
     """Crello Ours-EXP-FT shape of BASELINE config 5 (d_model 512, 8 blocks, seq_len 256; head dim 64,
-    K = 512 / 1024 / 1536 products) with the EXP task mix, against the f64 oracle at B = 2."""
+    K = 512 / 1024 / 1536 products) with the EXP task mix, against the f64 oracle at B = 2.  bf16: once on the d_model-512
+    kernels of csrc/block_d512.hip (the default: LN + Dense in one launch, row-owning products) -- the kernel names of the
+    pass are checked -- and once on the generic kernels (MFP_D512_FUSE=0)."""
+    from mfp.hip import functions
     S, D, L, B = 256, 512, 8, 2
     ic, params, batch, modified, masks, torch_ref, keys = _timed_shape_case("c3", B, S, D, L)
     state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S)
+    old_fuse = functions.D512_FUSE
+    functions.D512_FUSE = route != "generic"
+    try:
+        _c5_parity_body(dtype, route, ic, params, batch, modified, masks, info, grads, keys, S, D, L, B)
+    finally:
+        functions.D512_FUSE = old_fuse
+
+
+def _c5_parity_body(dtype, route, ic, params, batch, modified, masks, info, grads, keys, S, D, L, B):
+    if dtype == "bf16":
+        probe = _model(ic, params, D, L, dtype)
+        names = set(re_sub_template(n) for n in _kernel_names(lambda: _run(probe, ic, batch, modified, masks)))
+        assert ({"as512_kernel", "os512_kernel"} <= names) == (route == "d512"), sorted(names)
+        assert ("ln_fwd_kernel" in names) == (route == "generic"), sorted(names)
     model = _model(ic, params, D, L, dtype)
     loss, sums, outputs = _run(model, ic, batch, modified, masks)
     want = float(info["data_loss"])
     rel = abs(float(loss) - want) / want
     logit_err = max((outputs[k].cpu().double() - info["outputs"][k].detach()).abs().max().item() for k in keys)
     worst_cos, excess = _bf16_grad_report(model.store.grads_state_dict(), grads)
-    _record("c5_%s" % dtype, dict(B=B, S=S, D=D, L=L, loss=float(loss), oracle_loss=want, loss_rel_dev=rel,
+    _record("c5_%s%s" % (dtype, "" if route != "generic" else "_generic"), dict(B=B, S=S, D=D, L=L, loss=float(loss), oracle_loss=want, loss_rel_dev=rel,
                                   max_logit_abs_err=logit_err, worst_grad_cosine=worst_cos,
                                   worst_grad_rms_err_over_budget=excess))
-    print("c5 shape %s: loss rel dev %.2e, logits %.2e, worst grad cos %.6f" % (dtype, rel, logit_err, worst_cos))
+    print("c5 shape %s (%s): loss rel dev %.2e, logits %.2e, worst grad cos %.6f" % (dtype, route, rel, logit_err, worst_cos))
     if dtype == "fp32":
         assert rel <= 1e-5 and logit_err < 5e-4 and worst_cos > 0.99999
     else:
