@@ -82,8 +82,12 @@ def _fused_ok(ctx, D) -> bool:
 D512_FUSE = os.environ.get("MFP_D512_FUSE", "1") == "1"
 
 
-def _fused512_ok(ctx, D) -> bool:
-    return D512_FUSE and ctx.cdt == torch.bfloat16 and D == 512 and ctx.T <= (1 << 19) and not ctx.store.fp8
+def _fused512_ok(ctx, D, mx_forward: bool = False) -> bool:
+    """d_model 512 kernels of csrc/block_d512.hip.  ``mx_forward``: the LN + Dense forward launches, which the fp8 mode replaces
+    by ln_fwd + its MX block-scaled product; the other products (output projection, FFN2, the input gradients) are bf16 in
+    both modes."""
+    return (D512_FUSE and ctx.cdt == torch.bfloat16 and D == 512 and ctx.T <= (1 << 19)
+            and not (mx_forward and ctx.store.fp8))
 
 
 def _ln_dense(ctx, x, gamma, beta, W, T, N, D, bias, relu=False, w8=None):
@@ -424,15 +428,27 @@ class BlockFn(torch.autograd.Function):
             return x2
         if _fused512_ok(ctx, D):
             # d_model 512: LN1 + Q|K|V | attention | output projection + dropout + residual | LN2 + FFN1 + ReLU | FFN2 + dropout +
-            # residual = five launches (csrc/block_d512.hip); the last block also leaves the heads' bf16 operand
-            qkv, y1, mean1, rstd1 = ops.ln_dense_d512(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
-                                                      st.cw(p + "attn/dense_query/kernel", rows=3 * D),
-                                                      st.span(st.w, p + "attn/dense_query/bias", 3 * D), 3 * D)
+            # residual = five launches (csrc/block_d512.hip); the last block also leaves the heads' bf16 operand.  fp8 mode: the
+            # two LN + Dense launches are ln_fwd + the MX block-scaled product instead (csrc/gemm_fp8.hip)
+            if _fused512_ok(ctx, D, mx_forward=True):
+                qkv, y1, mean1, rstd1 = ops.ln_dense_d512(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
+                                                          st.cw(p + "attn/dense_query/kernel", rows=3 * D),
+                                                          st.span(st.w, p + "attn/dense_query/bias", 3 * D), 3 * D)
+            else:
+                qkv, y1, mean1, rstd1 = _ln_dense(ctx, x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
+                                                  st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
+                                                  st.span(st.w, p + "attn/dense_query/bias", 3 * D),
+                                                  w8=st.w8(p + "attn/dense_query/kernel", 3 * D))
             a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
             x1 = ops.dense_n512_res(a, st.cw(p + "attn/combine_heads/kernel"), st.weight(p + "attn/combine_heads/bias"), x,
                                     (ctx.p, ctx.seed, 2 * i + 1), ctx.step_ptr)
-            h, y2, mean2, rstd2 = ops.ln_dense_d512(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
-                                                    st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), 2 * D, relu=True)
+            if _fused512_ok(ctx, D, mx_forward=True):
+                h, y2, mean2, rstd2 = ops.ln_dense_d512(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
+                                                        st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), 2 * D, relu=True)
+            else:
+                h, y2, mean2, rstd2 = _ln_dense(ctx, x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
+                                                st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, st.weight(p + "mlp/dense_0/bias"),
+                                                relu=True, w8=st.w8(p + "mlp/dense_0/kernel", 2 * D))
             x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)
                     if ctx.tail["fuse"] and i == st.layout.L - 1 else None)
             x2 = ops.dense_n512_res(h, st.cw(p + "mlp/dense_1/kernel"), st.weight(p + "mlp/dense_1/bias"), x1,
