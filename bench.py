@@ -106,6 +106,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--masking_method", default=None, help="override the configuration's task mix")
     ap.add_argument("--batch", type=int, default=None, help="documents per GPU (override)")
+    ap.add_argument("--seq", type=int, default=None, help="positions per document (override; 64 = two documents per 128-row "
+                    "tile, the shape of real Crello / RICO batches whose sequences are at most 51 positions long)")
     ap.add_argument("--resident", type=int, default=4, help="input batches resident in HBM that the timed loop rotates")
     return ap.parse_args()
 
@@ -124,9 +126,9 @@ _KERNEL_FAMILY = (("attn_bwd", "attn_bwd"), ("attn_fwd", "attn_fwd"), ("ce_tile_
 
 
 def kernel_family(device_name):
-    if "attn_block_fwd_kernel" in device_name:    # <DROPOUT, MLP>: the whole-block variant is booked as block_fwd_kernel
+    if "attn_block_fwd_kernel" in device_name:    # <DROPOUT, MLP, STASH, SDOC>: the whole-block variant (MLP) is booked as block_fwd_kernel
         args_ = device_name.split("attn_block_fwd_kernel<")[-1].split(">")[0].replace(" ", "").split(",")
-        return "block_fwd_kernel" if args_[-1] in ("true", "1") else "attn_block_fwd_kernel"
+        return "block_fwd_kernel" if len(args_) > 1 and args_[1] in ("true", "1") else "attn_block_fwd_kernel"
     for key, fam in _KERNEL_FAMILY:
         if key in device_name:
             return fam
@@ -303,6 +305,8 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
+    if args.seq:
+        cfg["S"] = args.seq
     dtype = args.dtype or cfg["dtype"]
     masking_method = args.masking_method or cfg["masking_method"]
     D, NB, S, B = cfg["D"], cfg["L"], cfg["S"], cfg["B"]
@@ -431,7 +435,7 @@ def main():
         "input_residency": ("%d batches resident in HBM, rotated (%.0f MB of inputs per batch: beyond the 256 MB infinity cache)"
                             % (len(batches), sum(v.numel() * v.element_size() for v in batch.values()) / 1e6)
                             if len(batches) > 1 else "one batch, re-masked every step (its inputs can sit in the infinity cache)"),
-        "fused_path": bool((dtype in ("bf16", "fp8") and D == 256 and S == 128) or (dtype == "bf16" and D == 512)),
+        "fused_path": bool((dtype in ("bf16", "fp8") and D == 256 and (S == 128 or (S == 64 and B % 2 == 0))) or (dtype == "bf16" and D == 512)),
     }
     if dp_info is not None:
         out["dp"] = dp_info

@@ -83,8 +83,13 @@ __device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <bool DROPOUT, bool MLP, bool STASH = true>
+// SDOC = positions per document: 128 (a tile is a document) or 64 (a tile is TWO documents: the datasets' sequences are at most
+// 51 positions long -- data/crello-spec.yml:6-13, rico-spec.yml:3-10 -- so --seq_len 64 is the shape real runs have).  Everything
+// but the attention is row-wise; in the attention a wave's 16 queries belong to one document (queries 16 w .. + 15: document
+// w >> 2) and it visits only that document's 64 keys (rows kb .. kb + 63 of the k / v images): half the score work per head.
+template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128>
 __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) {
+  static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
   constexpr int NCH = MLP ? 2 * AB_CHUNKS : AB_CHUNKS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Im = smem;                      // Im + t * AB_IMG, t = 0 (q, then a), 1 (k), 2 (v)
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   // (the step counter and the document's length are read first: their loads must not sit between the counted waits)
   const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
-  const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[doc]);
+  const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[SDOC == 128 ? doc : 2 * doc]);
+  const int nv1 = SDOC == 128 ? 0 : __builtin_amdgcn_readfirstlane(p.nvalid[2 * doc + 1]);
 
   const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(doc * 8 + wave) * 64;
   AB_TR(0);
@@ -172,7 +178,9 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
                      : tid < 256 ? p.gamma2 + (tid - 192) * 4 : p.beta2 + (tid - 256) * 4;
     *reinterpret_cast<f32x4*>(smem + AB_VEC2_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(src);
   }
-  if (tid < 128) Mb[tid] = tid < nv ? 0.f : -1e9f * LOG2E;      // additive key term (exp2 domain); S = 128: no row past S
+  // additive key term (exp2 domain); no row past S.  SDOC = 64: key's validity inside ITS document (a wave only visits the
+  // 64 keys of its queries' document)
+  if (tid < 128) Mb[tid] = (SDOC == 128 ? tid < nv : (tid & 63) < (tid >> 6 ? nv1 : nv)) ? 0.f : -1e9f * LOG2E;
 
   // ---- LN1 (as qkv_fused_kernel): wave w normalises rows 16 w .. + 15 in the MFMA operand layout
   bf16x8 xf[2][8];
@@ -331,6 +339,11 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       const unsigned char* ki = Im + AB_IMG;
       const unsigned char* vi = Im + 2 * AB_IMG;
       const int qrow = 16 * wave + li;
+      constexpr int NKT = SDOC / 16;                                    // key tiles a query sees
+      const int kb = SDOC == 128 ? 0 : (wave >> 2) * 64;                // first key row of this wave's queries' document
+      const unsigned char* const kid = ki + kb * 128;                   // ((row >> 1) & 7, the slot swizzle, is the same for row + 64)
+      const unsigned char* const vid = vi + kb * 128;
+      const float* const Mbq = Mb + kb;
       // (the output tile of a head overwrites this wave's own rows of the q image: nobody else reads these rows -- their q
       //  columns left for HBM at the head of the k chunk)
       unsigned char* ai = Im;
@@ -343,12 +356,12 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         // maximum, pass 2 recomputes the scores tile by tile, exponentiates and feeds P V.
         float m = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
           const int krow = kt * 16 + li;
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ki + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
           const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
-          const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mb + kt * 16 + 4 * g);
+          const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mbq + kt * 16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fmaf(sa[r], c2, mb4[r]));
         }
@@ -357,15 +370,15 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         float l = 0.f;
         f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NKT / 2; ++u) {
           f32x4 pe[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
             const int kt = 2 * u + hf, krow = kt * 16 + li;
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ki + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
-            const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mb + kt * 16 + 4 * g);
+            const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mbq + kt * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               pe[hf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, mb4[r]) - m);
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
             // V^T fragment: for column hh * 32 + 16 dt + li the key rows {32 u + 4 g + j} and {32 u + 16 + 4 g + j}
             const int vrow = 32 * u + 4 * g + (li >> 2);
             const int P = hh * 8 + dt * 4 + (li & 3);                 // 8-byte piece of the 128-byte row
-            const unsigned char* ptr = vi + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
+            const unsigned char* ptr = vid + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
             const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
             // (row + 16: bits 1..3 of the row, hence the swizzle, are unchanged)
             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
@@ -396,7 +409,9 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         }
         const float lv = (m + __builtin_amdgcn_logf(l)) * LN2;      // natural-log lse
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, lv), rs_l,
-                                              g == 0 ? (unsigned int)(((doc * p.H + 2 * pr + hh) * AB_ROWS + qrow) * 4) : 0xFFFFFFF0u, 0, 0);
+                                              g != 0 ? 0xFFFFFFF0u
+                                              : SDOC == 128 ? (unsigned int)(((doc * p.H + 2 * pr + hh) * AB_ROWS + qrow) * 4)
+                                                            : (unsigned int)((((2 * doc + (wave >> 2)) * p.H + 2 * pr + hh) * 64 + (qrow & 63)) * 4), 0, 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();      // the pair's a image is complete
@@ -662,15 +677,22 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
 
 }  // namespace
 
-static int launch_block(AttnBlockParams& p, bool mlp, int B, hipStream_t st) {
+template <typename K>
+static hipError_t ab_set_lds(K k, int bytes) { return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+
+// `tiles` = 128-row tiles (= documents at S = 128, document pairs at S = 64)
+static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStream_t st) {
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_fwd_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_MLP);
+    hipError_t e = ab_set_lds(attn_block_fwd_kernel<true, false>, AB_LDS);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, false>, AB_LDS);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, false>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 64>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 64>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, false, 64>, AB_LDS_MLP);
     if (e != hipSuccess) {
       mfp_set_error("mfp_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS_MLP, hipGetErrorString(e));
       return MFP_ELAUNCH;
@@ -678,14 +700,20 @@ static int launch_block(AttnBlockParams& p, bool mlp, int B, hipStream_t st) {
     attr_set = true;
   }
   const bool drop = p.dropout_p > 0.f;
-  if (mlp && !p.stash) {
-    hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, false>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
+  const dim3 grid(tiles), blk(512);
+  if (S == 64) {      // (two documents per tile: the whole-block forms only)
+    if (!mlp) { mfp_set_error("mfp_attn_block_fwd: S = 64 is provided by mfp_block_fwd / mfp_block_infer only"); return MFP_EINVAL; }
+    if (!p.stash) hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, false, 64>), grid, blk, AB_LDS_MLP, st, p);
+    else if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 64>), grid, blk, AB_LDS_MLP, st, p);
+    else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 64>), grid, blk, AB_LDS_MLP, st, p);
+  } else if (mlp && !p.stash) {
+    hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, false>), grid, blk, AB_LDS_MLP, st, p);
   } else if (mlp) {
-    if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
-    else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true>), dim3(B), dim3(512), AB_LDS_MLP, st, p);
+    if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true>), grid, blk, AB_LDS_MLP, st, p);
+    else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true>), grid, blk, AB_LDS_MLP, st, p);
   } else {
-    if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, false>), dim3(B), dim3(512), AB_LDS, st, p);
-    else hipLaunchKernelGGL((attn_block_fwd_kernel<false, false>), dim3(B), dim3(512), AB_LDS, st, p);
+    if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, false>), grid, blk, AB_LDS, st, p);
+    else hipLaunchKernelGGL((attn_block_fwd_kernel<false, false>), grid, blk, AB_LDS, st, p);
   }
   return MFP_OK;
 }
@@ -695,7 +723,8 @@ static int fill_attn(AttnBlockParams& p, const float* x, const float* gamma, con
                      float* lse, float* x1, int32_t B, int32_t S, int32_t D, int32_t H, float eps, float dropout_p, uint64_t seed,
                      uint64_t offset, const int32_t* step_ptr) {
   MFP_CHECK_ARG(x && gamma && beta && Wqkv && bqkv && Wo && bo && nvalid && y1 && mean && rstd && qkv && a && lse && x1);
-  MFP_CHECK_ARG(B > 0 && B <= 8192 && S == AB_ROWS && D == AB_D && H == 8 && eps > 0.f && dropout_p >= 0.f && dropout_p < 1.f);
+  MFP_CHECK_ARG(B > 0 && B <= 16384 && (S == AB_ROWS || (S == 64 && B % 2 == 0)) && D == AB_D && H == 8 && eps > 0.f && dropout_p >= 0.f &&
+                dropout_p < 1.f);
   MFP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)Wqkv % 16) == 0 && ((uintptr_t)Wo % 16) == 0 && ((uintptr_t)y1 % 16) == 0 &&
                 ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)bqkv % 16) == 0 &&
                 ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)bo % 16) == 0);
@@ -720,7 +749,7 @@ extern "C" int mfp_attn_block_fwd(const float* x, const float* gamma, const floa
   AttnBlockParams p;
   if (int rc = fill_attn(p, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, y1, mean, rstd, qkv, a, lse, x1, B, S, D, H, eps, dropout_p,
                          seed, offset, step_ptr)) return rc;
-  if (int rc = launch_block(p, false, B, reinterpret_cast<hipStream_t>(stream))) return rc;
+  if (int rc = launch_block(p, false, B * S / AB_ROWS, S, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
@@ -745,7 +774,7 @@ extern "C" int mfp_block_fwd(const float* x, const float* gamma, const float* be
   p.y2 = reinterpret_cast<unsigned short*>(y2); p.mean2 = mean2; p.rstd2 = rstd2;
   p.h = reinterpret_cast<unsigned short*>(h); p.x2 = x2; p.x2c = reinterpret_cast<unsigned short*>(x2_bf16);
   p.offset2 = offset_mlp;
-  if (int rc = launch_block(p, true, B, reinterpret_cast<hipStream_t>(stream))) return rc;
+  if (int rc = launch_block(p, true, B * S / AB_ROWS, S, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
@@ -772,7 +801,7 @@ extern "C" int mfp_block_infer(const float* x, const float* gamma, const float* 
   p.y2 = reinterpret_cast<unsigned short*>(dummy); p.mean2 = stats + 2 * T; p.rstd2 = stats + 3 * T;
   p.h = reinterpret_cast<unsigned short*>(dummy); p.x2 = x2; p.x2c = nullptr;
   p.stash = 0;
-  if (int rc = launch_block(p, true, B, reinterpret_cast<hipStream_t>(stream))) return rc;
+  if (int rc = launch_block(p, true, B * S / AB_ROWS, S, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -136,7 +136,12 @@ __device__ __forceinline__ float dot8(const u32x4& x, const u32x4& y) {
 //   N_0 .. N_3 = 4   N_4 = 2 + P = 11   N_5 = P + S + 2 = 13   (last pair: no P, no next chunks: N_4 = N_5 = 2)
 // P goes behind the pair's last weight chunk: loads return in order, a weight chunk (an L2 hit) issued behind the HBM loads
 // of P would not count as landed before they are.
+// SDOC = positions per document: 128 (a tile is a document) or 64 (two documents per tile, see csrc/block_attn.hip): a wave owns
+// 32 keys of ONE document (key block w4: document w4 >> 1) and walks all four 32-query blocks -- the blocks of the other
+// document get the padding term (P = dS = 0 exactly), so the barrier structure is the same for both forms.
+template <int SDOC>
 __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams p) {
+  static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Ws = smem + BB_WS;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -146,7 +151,8 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
   const int k0 = 32 * w4, dt_w = w4 & 1, qt_w = w4 >> 1;
   const int doc = blockIdx.x, row0 = doc * BB_ROWS;
   constexpr float LOG2E = 1.4426950408889634f;
-  const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[doc]);
+  const int kd = SDOC == 128 ? 0 : (w4 >> 1);          // this wave's keys' document inside the tile
+  const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[SDOC == 128 ? doc : 2 * doc + kd]);
   const float c2 = p.scale * LOG2E;
   const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.dy1) + (size_t)(doc * 8 + wave) * 64;
   BB_TR(0);
@@ -215,7 +221,9 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
     a0 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff, 0, 0);
     a1 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff + 16, 0, 0);
     lse_r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-        rs_l, tid < 256 ? (unsigned int)(((doc * p.H + 2 * pr + (tid >> 7)) * BB_ROWS + (tid & 127)) * 4) : 0xFFFFFFF0u, 0, 0));
+        rs_l, tid >= 256 ? 0xFFFFFFF0u
+              : SDOC == 128 ? (unsigned int)(((doc * p.H + 2 * pr + (tid >> 7)) * BB_ROWS + (tid & 127)) * 4)
+                            : (unsigned int)((((2 * doc + ((tid >> 6) & 1)) * p.H + 2 * pr + (tid >> 7)) * 64 + (tid & 63)) * 4), 0, 0));
   };
   // ---- prologue: the d_o1 fragments and chunks 0, 1 first (the da product starts when they are in); behind them pair 0's
   // q | k | v and a / lse (nine loads: they land under the da product)
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
       const int j = k0 + 16 * t + li_p;
       bk[t] = pfragk(smem + BB_K, hh, j, g_p);
       bv[t] = pfragk(smem + BB_V, hh, j, g_p);
-      madd[t] = j < nv ? 0.f : -1e9f * LOG2E;
+      madd[t] = (SDOC == 128 ? j : (j & 63)) < nv ? 0.f : -1e9f * LOG2E;
     }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) kT[kb] = pfragtr(smem + BB_K, hh, 32 * kb, 16 * dt_w, li_p, g_p);
@@ -345,6 +353,8 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
 #pragma unroll
       for (int qb = 0; qb < (BB_ABL == 1 ? 0 : 4); ++qb) {
         u32x2 ppk[2][2], dsk[2][2];     // P and dS as bf16 pairs, [query tile][key tile]
+        // SDOC = 64: queries 32 qb .. + 31 belong to document qb >> 1; the other document's keys weigh nothing
+        const float mq[2] = {(SDOC == 64 && (qb >> 1) != kd) ? -1e9f * LOG2E : madd[0], (SDOC == 64 && (qb >> 1) != kd) ? -1e9f * LOG2E : madd[1]};
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           const int q = qb * 32 + qt * 16;
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
             float pe[4], de[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, madd[t]) - Lr[r]);
+              pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, mq[t]) - Lr[r]);
               de[r] = pe[r] * (dpacc[r] - Dr[r]);
             }
             ppk[qt][t] = (u32x2){pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3])};
@@ -463,7 +473,7 @@ extern "C" int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void*
                                   const int32_t* nvalid, const void* Wqkvt, void* dqkv, void* dy1, int32_t B, int32_t S,
                                   int32_t D, int32_t H, mfp_stream_t stream) {
   MFP_CHECK_ARG(d_o1 && Wot && qkv && a && lse && nvalid && Wqkvt && dqkv && dy1);
-  MFP_CHECK_ARG(B > 0 && B <= 8192 && S == BB_ROWS && D == BB_D && H == 8);
+  MFP_CHECK_ARG(B > 0 && B <= 16384 && (S == BB_ROWS || (S == 64 && B % 2 == 0)) && D == BB_D && H == 8);
   MFP_CHECK_ARG(((uintptr_t)d_o1 % 16) == 0 && ((uintptr_t)Wot % 16) == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 &&
                 ((uintptr_t)Wqkvt % 16) == 0 && ((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)dy1 % 16) == 0);
   AttnBwdBlockParams p;
@@ -475,14 +485,16 @@ extern "C" int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void*
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
     if (e != hipSuccess) {
       mfp_set_error("mfp_attn_block_bwd: cannot raise dynamic LDS to %d: %s", BB_LDS, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_block_bwd_kernel, dim3(B), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  if (S == 64) hipLaunchKernelGGL(attn_block_bwd_kernel<64>, dim3(B / 2), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(attn_block_bwd_kernel<128>, dim3(B), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

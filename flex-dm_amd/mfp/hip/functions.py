@@ -66,8 +66,14 @@ ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "")
 def _attn_block_bwd_on(ctx) -> bool:
     if ATTN_BLOCK_BWD != "":
         return ATTN_BLOCK_BWD == "1"
-    return ctx.B >= ops.cu_count(ctx.store.w.device)
+    return ctx.T // 128 >= ops.cu_count(ctx.store.w.device)      # (128-row tiles: documents at S = 128, document pairs at S = 64)
 FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
+
+
+def _doc_tile_ok(B: int, S: int, T: int) -> bool:
+    """Shapes the document-tile kernels take (csrc/block_attn.hip, block_attn_bwd.hip): a 128-row tile is one document of 128
+    positions or two documents of 64 (the datasets' sequences are at most 51 positions long: --seq_len 64)."""
+    return T == B * S and (S == 128 or (S == 64 and B % 2 == 0))
 
 
 def _fused_ok(ctx, D) -> bool:
@@ -400,7 +406,7 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x = x.contiguous()
-        if (BLOCK_FWD and ATTN_BLOCK and BLOCK_INFER and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S
+        if (BLOCK_FWD and ATTN_BLOCK and BLOCK_INFER and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T)
                 and not ctx.training and not fctx.needs_input_grad[0]):
             # inference callers (MFP.__call__(training=False), iterative_decode, eval.py): nothing is saved for a
             # backward pass, so only x1 (re-read as the MLP half's residual) and x2 reach HBM
@@ -411,7 +417,7 @@ class BlockFn(torch.autograd.Function):
                 st.weight(p + "attn/combine_heads/bias"), ctx.nvalid, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
                 st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"),
                 st.weight(p + "mlp/dense_1/bias"), B, S, NUM_HEADS)
-        if BLOCK_FWD and ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S:
+        if BLOCK_FWD and ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T):
             # the whole block in one launch (csrc/block_attn.hip); the last block also leaves the heads' bf16 operand
             x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)
                     if ctx.tail["fuse"] and i == st.layout.L - 1 else None)
@@ -457,7 +463,7 @@ class BlockFn(torch.autograd.Function):
             fctx.ctx, fctx.i = ctx, i
             fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
             return x2
-        if ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S:
+        if ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T):
             # the whole attention half in one launch
             x1, y1, mean1, rstd1, qkv, a, lse = ops.attn_block_fwd(
                 x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), st.cw(p + "attn/dense_query/kernel", rows=3 * D),
@@ -472,7 +478,7 @@ class BlockFn(torch.autograd.Function):
                                           st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
                                           st.span(st.w, p + "attn/dense_query/bias", 3 * D),
                                           w8=st.w8(p + "attn/dense_query/kernel", 3 * D) if st.fp8 else None)
-        if not (ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and S == 128 and T == B * S):
+        if not (ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T)):
             a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
             x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
                           bias=st.weight(p + "attn/combine_heads/bias"), residual=x,
@@ -553,7 +559,7 @@ class BlockFn(torch.autograd.Function):
         wtq = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
         dy1 = None
         if (_attn_block_bwd_on(ctx) and _fused_ok(ctx, D) and wt is not None and wtq is not None and cdt == torch.bfloat16
-                and S == 128 and T == B * S):
+                and _doc_tile_ok(B, S, T)):
             # da = d_o1 Wo, attention backward and dy1 = dqkv Wqkv in one launch (csrc/block_attn_bwd.hip)
             dqkv, dy1 = ops.attn_block_bwd(d_o1, wt, qkv, a, lse, ctx.nvalid, wtq, B, S, NUM_HEADS)
         else:

@@ -1216,13 +1216,14 @@ def test_heads_loss_fused(dataset, B, S, want_logits, p):
         assert torch.equal((dxd != 0) & both, (dxd_u != 0) & both)
 
 
-@pytest.mark.parametrize("B", [1, 5])
-def test_attn_block_bwd(B):
+@pytest.mark.parametrize("B,S", [(1, 128), (5, 128), (2, 64), (6, 64)])
+def test_attn_block_bwd(B, S):
     """mfp_attn_block_bwd: da = d_o1 Wo, dqkv = MHSA'(...; da), dy1 = dqkv Wqkv in ONE launch (autodiff of
-    transformer.py:216-221,60-99; documents of 128 positions) against the three launches it replaces (mfp_dgrad_d256,
-    mfp_attention_bwd, mfp_dgrad_qkv) and a double reference built from the same bf16 inputs; ragged key masks."""
+    transformer.py:216-221,60-99; documents of 128 positions, or two documents of 64 per tile) against the three launches it
+    replaces (mfp_dgrad_d256, mfp_attention_bwd, mfp_dgrad_qkv) and a double reference built from the same bf16 inputs;
+    ragged key masks."""
     ops = _ops()
-    S, D, H = 128, 256, 8
+    D, H = 256, 8
     T = B * S
     g = torch.Generator().manual_seed(700 + B)
     rn = lambda *s: torch.randn(*s, generator=g)
@@ -1386,3 +1387,50 @@ def test_dense_n512(T, K):
     A, W = bf16_round(rn(T, K)), bf16_round(rn(512, K) * 0.04)
     out = ops.dense_n512(A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16))
     assert_close(out, A.double() @ W.double().t(), 2e-2, 8e-3, "out vs double")
+
+
+@pytest.mark.parametrize("B,p", [(2, 0.0), (6, 0.1)])
+def test_block_fwd_two_documents_per_tile(B, p):
+    """mfp_block_fwd / mfp_block_infer at S = 64 (two documents per 128-row tile: the shape of real Crello / RICO batches,
+    whose sequences are at most 51 positions long -- data/crello-spec.yml:6-13) against the separate launches on the same
+    dropout streams: LN1 + Q|K|V (mfp_qkv_fused_fwd), attention per document (mfp_attention_fwd), output projection
+    (mfp_gemm), MLP half (mfp_mlp_fused_fwd); ragged lengths, so both documents of a tile carry their own key mask."""
+    ops = _ops()
+    S, D, H = 64, 256, 8
+    T = B * S
+    g = torch.Generator().manual_seed(900 + B)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(T, D) * (1.0 + torch.rand(T, 1, generator=g))
+    g1, b1_, g2, b2_ = 1.0 + 0.2 * rn(D), 0.1 * rn(D), 1.0 + 0.2 * rn(D), 0.1 * rn(D)
+    Wqkv, bqkv, Wo, bo = bf16_round(rn(3 * D, D) * 0.08), rn(3 * D) * 0.1, bf16_round(rn(D, D) * 0.06), rn(D) * 0.1
+    W1, c1, W2, c2 = bf16_round(rn(2 * D, D) * 0.06), rn(2 * D) * 0.1, bf16_round(rn(D, 2 * D) * 0.05), rn(D) * 0.1
+    nvalid = torch.randint(1, 52, (B,), generator=g).to(torch.int32)
+    nvalid[0] = S
+    step = torch.full((1,), 1, dtype=torch.int32, device=DEV)
+    d = lambda t, dt=None: t.to(DEV, dt) if dt else t.to(DEV)
+    bf = torch.bfloat16
+    args = (d(x), d(g1), d(b1_), d(Wqkv, bf), d(bqkv), d(Wo, bf), d(bo), d(nvalid))
+    x2, (y1, m1, r1, qkv, a, lse, x1, y2, m2, r2, h) = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H,
+                                                                       p, 7, 3, 4, step)
+    qkvu, y1u, m1u, r1u = ops.qkv_fused_fwd(d(x), d(g1), d(b1_), d(Wqkv, bf), d(bqkv))
+    for got, want in ((y1, y1u), (qkv, qkvu)):
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(m1, m1u) and torch.equal(r1, r1u)
+    au, lseu = ops.attention_fwd(qkvu, d(nvalid), B, S, H)
+    assert_close(a, au.float().cpu().double(), 1e-2, 1e-2, "attention output vs mfp_attention_fwd")
+    assert_close(lse, lseu.cpu().double(), 2e-3, 1e-3, "lse vs mfp_attention_fwd")
+    x1u = ops.gemm(a, d(Wo, bf), T, D, D, a_kmajor=True, b_kmajor=True, bias=d(bo), residual=d(x), dropout=(p, 7, 3), step_ptr=step,
+                   out_dtype=torch.float32)
+    assert_close(x1, x1u.cpu().double(), 2e-3, 1e-3, "x1 vs mfp_gemm on the kernel's own a")
+    x2u, y2u, m2u, r2u, hu = ops.mlp_fused_fwd(x1, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), (p, 7, 4), step)
+    assert_close(h, hu.float().cpu().double(), 3e-2, 2e-2, "h vs mlp_fused")
+    assert_close(x2, x2u.cpu().double(), 3e-2, 2e-2, "x2 vs mlp_fused")
+    # a double reference of the attention from the kernel's own qkv: every query sees only ITS document's valid keys
+    q64 = qkv.float().cpu().double().view(B, S, 3, H, 32)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q64[:, :, 0], q64[:, :, 1]) / 32 ** 0.5
+    sc = sc + ((torch.arange(S)[None, :] >= nvalid[:, None]).double() * -1e9)[:, None, None, :]
+    want_a = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), q64[:, :, 2]).reshape(T, D)
+    assert_close(a, want_a, 1e-2, 1e-2, "attention output vs double")
+    if p == 0.0:
+        x2i = ops.block_infer(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H)
+        assert torch.equal(x2i, x2)

@@ -590,6 +590,40 @@ def test_timed_shape_parity_vs_oracle(dtype, route, mix, B):
         assert worst_cos > 0.98 and excess <= 1.0, (worst_cos, excess)
 
 
+@pytest.mark.parametrize("route", ["timed", "default"])
+def test_seq64_two_documents_per_tile_parity_vs_oracle(route):
+    """--seq_len 64, the shape real Crello / RICO batches have (sequences of at most 51 positions: data/crello-spec.yml:6-13,
+    rico-spec.yml:3-10): the document-tile kernels run two documents per 128-row tile (csrc/block_attn.hip,
+    block_attn_bwd.hip, template argument 64).  Loss, per-key losses, counts and every gradient against the f64 oracle on
+    ragged lengths (1 .. 64 positions, so both documents of a tile carry their own key mask), with the budgets of the S = 128 test; the kernel names of the pass are checked."""
+    S, D, L, B = 64, 256, 4, 4
+    ic, params, batch, modified, masks, torch_ref, keys = _timed_shape_case("c2", B, S, D, L)
+    state, info, grads = _oracle(ic, params, batch, modified, masks, torch_ref, L, S)
+    with _route(route):
+        probe = _model(ic, params, D, L, "bf16")
+        names = set(_kernel_names(lambda: _run(probe, ic, batch, modified, masks)))
+        assert any(n.startswith("attn_block_fwd_kernel<") and n.endswith(", 64>") for n in names), sorted(names)
+        assert ("attn_block_bwd_kernel<64>" in names) == (route == "timed"), sorted(names)
+        model = _model(ic, params, D, L, "bf16")
+        loss, sums, outputs = _run(model, ic, batch, modified, masks)
+    want = float(info["data_loss"])
+    rel = abs(float(loss) - want) / want
+    sums = sums.cpu().double()
+    key_rel = {}
+    for i, k in enumerate(keys):
+        w = float(info["losses"][k])
+        key_rel[k] = abs(sums[i, 0].item() - w) / max(abs(w), 1e-3 * want)
+        assert abs(sums[i, 2].item() - float(info["scores"][k + "_score_den"])) < 1e-6, k      # counts: exact
+    worst_cos, excess = _bf16_grad_report(model.store.grads_state_dict(), grads)
+    _record("c2_seq64_bf16_%s" % route, dict(B=B, S=S, D=D, L=L, loss=float(loss), oracle_loss=want, loss_rel_dev=rel,
+                                            worst_key_loss_rel_dev=max(key_rel.values()), worst_grad_cosine=worst_cos,
+                                            worst_grad_rms_err_over_budget=excess))
+    print("S = 64 (%s): loss rel dev %.2e, worst key %.2e, worst grad cos %.6f" % (route, rel, max(key_rel.values()), worst_cos))
+    assert rel <= BF16_LOSS_BUDGET, rel
+    assert max(key_rel.values()) <= BF16_KEY_BUDGET, key_rel
+    assert worst_cos > 0.98 and excess <= 1.0, (worst_cos, excess)
+
+
 def _masker_output_as_oracle_inputs(model, ic, batch, dbatch, B, S):
     """What the fused masking kernel draws at the model's CURRENT step counter, in the reference's
     (modified_inputs, masks) form: the draws are inferred from the kernel's output and replayed through the oracle's
