@@ -88,6 +88,20 @@ def _fused_ok(ctx, D) -> bool:
 D512_FUSE = os.environ.get("MFP_D512_FUSE", "1") == "1"
 
 
+# fp8 mode, d_model 512, MEASUREMENT switches (tests/test_gpu_model.py::test_c5_fp8_deviation_and_training):
+# which forward products run as MX fp8 products ("qkv,ffn1" = the mode; "ffn1": Q|K|V, whose result feeds a softmax, stays
+# bf16), and "weights only" = bf16 products on the MX-quantised weights (e4m3 weights x bf16 activations)
+FP8_PRODUCTS = set(os.environ.get("MFP_FP8_PRODUCTS", "qkv,ffn1").split(","))
+FP8_WEIGHTS_ONLY = os.environ.get("MFP_FP8_WEIGHTS_ONLY", "0") == "1"
+
+
+def _w8_as_bf16(st, name: str, rows: int) -> torch.Tensor:
+    """The MX-quantised copy of a kernel, dequantised to bf16 [rows][in] (exact: e4m3 x 2^e fits bf16)."""
+    q, sc = st.w8(name, rows)
+    v = q.view(torch.float8_e4m3fn).to(torch.float32).view(rows, -1, 32)
+    return (v * torch.exp2(sc.to(torch.float32) - 127.0)[..., None]).view(rows, -1).to(torch.bfloat16).contiguous()
+
+
 def _fused512_ok(ctx, D, mx_forward: bool = False) -> bool:
     """d_model 512 kernels of csrc/block_d512.hip.  ``mx_forward``: the LN + Dense forward launches, which the fp8 mode replaces
     by ln_fwd + its MX block-scaled product; the other products (output projection, FFN2, the input gradients) are bf16 in
@@ -436,9 +450,10 @@ class BlockFn(torch.autograd.Function):
             # d_model 512: LN1 + Q|K|V | attention | output projection + dropout + residual | LN2 + FFN1 + ReLU | FFN2 + dropout +
             # residual = five launches (csrc/block_d512.hip); the last block also leaves the heads' bf16 operand.  fp8 mode: the
             # two LN + Dense launches are ln_fwd + the MX block-scaled product instead (csrc/gemm_fp8.hip)
-            if _fused512_ok(ctx, D, mx_forward=True):
-                qkv, y1, mean1, rstd1 = ops.ln_dense_d512(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
-                                                          st.cw(p + "attn/dense_query/kernel", rows=3 * D),
+            if _fused512_ok(ctx, D, mx_forward=True) or "qkv" not in FP8_PRODUCTS or FP8_WEIGHTS_ONLY:
+                wq = (_w8_as_bf16(st, p + "attn/dense_query/kernel", 3 * D) if st.fp8 and FP8_WEIGHTS_ONLY and "qkv" in FP8_PRODUCTS
+                      else st.cw(p + "attn/dense_query/kernel", rows=3 * D))
+                qkv, y1, mean1, rstd1 = ops.ln_dense_d512(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), wq,
                                                           st.span(st.w, p + "attn/dense_query/bias", 3 * D), 3 * D)
             else:
                 qkv, y1, mean1, rstd1 = _ln_dense(ctx, x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
@@ -448,9 +463,11 @@ class BlockFn(torch.autograd.Function):
             a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
             x1 = ops.dense_n512_res(a, st.cw(p + "attn/combine_heads/kernel"), st.weight(p + "attn/combine_heads/bias"), x,
                                     (ctx.p, ctx.seed, 2 * i + 1), ctx.step_ptr)
-            if _fused512_ok(ctx, D, mx_forward=True):
-                h, y2, mean2, rstd2 = ops.ln_dense_d512(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
-                                                        st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), 2 * D, relu=True)
+            if _fused512_ok(ctx, D, mx_forward=True) or "ffn1" not in FP8_PRODUCTS or FP8_WEIGHTS_ONLY:
+                w1 = (_w8_as_bf16(st, p + "mlp/dense_0/kernel", 2 * D) if st.fp8 and FP8_WEIGHTS_ONLY and "ffn1" in FP8_PRODUCTS
+                      else st.cw(p + "mlp/dense_0/kernel"))
+                h, y2, mean2, rstd2 = ops.ln_dense_d512(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"), w1,
+                                                        st.weight(p + "mlp/dense_0/bias"), 2 * D, relu=True)
             else:
                 h, y2, mean2, rstd2 = _ln_dense(ctx, x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
                                                 st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, st.weight(p + "mlp/dense_0/bias"),

@@ -18,6 +18,25 @@ from mfp.models.mfp import MFP
 logger = logging.getLogger(__name__)
 
 
+def fused_path_hint(dtype, latent_dim, seq_len, docs_per_rank):
+    """One line when the run will NOT take the document-tile / activation-stationary kernels (mfp/hip/functions.py), with
+    the flag that puts it there; None when it will.  The datasets' sequences are at most 51 positions long (data/*-spec.yml:
+    length <= 50), so ``--seq_len 64`` (two documents per 128-row tile) costs 1.25x the padding of the longest batch and runs
+    the fused kernels; without ``--seq_len`` every batch has its own length and is stepped on the generic kernels."""
+    if dtype not in ("bf16", "fp8"):
+        return None      # (the f32 parity path has no fused kernels)
+    if latent_dim == 512:
+        return None      # csrc/block_d512.hip takes any sequence length
+    if latent_dim != 256:
+        return ("latent_dim %d runs on the generic tile kernels (the fused kernels are built for --latent_dim 256 and 512)" % latent_dim)
+    if seq_len == 128 or (seq_len == 64 and docs_per_rank % 2 == 0):
+        return None
+    if seq_len == 64:
+        return "--seq_len 64 needs an even number of documents per GPU for the document-tile kernels (got %d)" % docs_per_rank
+    return ("--seq_len %s falls off the document-tile kernels (generic attention / projection launches, ~1.3x slower per element); "
+            "use --seq_len 64 (two documents per tile; sequences are at most 51 positions long) or --seq_len 128" % seq_len)
+
+
 def train(args):
     logger.info(f"torch version {torch.__version__}")
     world = dp.init_from_env()
@@ -40,6 +59,9 @@ def train(args):
     checkpoint_dir = os.path.join(args.job_dir, "checkpoints")
     checkpoint_path = os.path.join(checkpoint_dir, "best.ckpt")
 
+    hint = fused_path_hint(args.dtype, args.latent_dim, args.seq_len, args.batch_size // max(world, 1))
+    if hint and dp.rank() == 0:
+        print("mfp.train: " + hint, flush=True)
     dataspec = DataSpec(args.dataset_name, args.data_dir, batch_size=args.batch_size,
                         seq_len=args.seq_len, device=device)
     train_dataset = dataspec.make_dataset("train", shuffle=True, repeat=True, cache=True)

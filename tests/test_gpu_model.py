@@ -1074,6 +1074,23 @@ def test_c5_fp8_deviation_and_training():
                            worst_grad_cosine=worst_cos, worst_grad_rms_err_over_budget=excess))
     print("c5 shape fp8: loss rel dev %.2e, worst grad cos %.4f, rms err / budget %.2f" % (rel, worst_cos, excess))
     assert rel < 2e-2 and worst_cos > 0.9
+    # ---- measured alternatives (recorded): which rounding carries the deviation
+    from mfp.hip import functions
+    old_sw = (functions.FP8_PRODUCTS, functions.FP8_WEIGHTS_ONLY)
+    table = {"qkv,ffn1 (the mode)": rel}
+    try:
+        for label, prods, wonly in (("ffn1 only", {"ffn1"}, False), ("qkv only", {"qkv"}, False),
+                                    ("e4m3 weights x bf16 activations", {"qkv", "ffn1"}, True)):
+            functions.FP8_PRODUCTS, functions.FP8_WEIGHTS_ONLY = prods, wonly
+            m2 = _model(ic, params, D, L, "fp8")
+            loss2, _, _ = _run(m2, ic, batch, modified, masks)
+            cos2, _ = _bf16_grad_report(m2.store.grads_state_dict(), grads)
+            table[label] = abs(float(loss2) - want) / want
+            table[label + " / worst grad cos"] = cos2
+    finally:
+        functions.FP8_PRODUCTS, functions.FP8_WEIGHTS_ONLY = old_sw
+    _record("c5_fp8_variants", table)
+    print("c5 fp8 variants (loss rel dev vs the f64 oracle):", {k: "%.2e" % v for k, v in table.items() if "cos" not in k})
     ic = make_input_columns("crello")
     dbatch = synthetic_batch(ic, 8, 64, seed=0, ragged=True, device=DEV)
     mfp = MFP(ic, num_blocks=2, latent_dim=256, dropout=0.1, l2=1e-2, masking_method="elem_pos_attr_img_txt",

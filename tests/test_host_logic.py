@@ -159,3 +159,15 @@ def test_task_probabilities():
     assert get_task_probs(names, "random") == [1, 0, 0, 0, 0, 0, 0]
     p = get_task_probs(names, "elem_pos_attr_img_txt")
     assert p[0] == 0 and p[2] == 0 and abs(sum(p) - 1) < 1e-12 and p[1] == pytest.approx(0.2)
+
+
+def test_fused_path_hint():
+    """mfp.train prints one line when a run falls off the fused kernels, and names the flag that puts it back."""
+    from mfp.train import fused_path_hint
+    assert fused_path_hint("bf16", 256, 128, 256) is None
+    assert fused_path_hint("bf16", 256, 64, 256) is None
+    assert fused_path_hint("bf16", 512, None, 64) is None
+    assert fused_path_hint("fp32", 256, None, 8) is None
+    assert "--seq_len 64" in fused_path_hint("bf16", 256, None, 256)
+    assert "even" in fused_path_hint("bf16", 256, 64, 3)
+    assert "latent_dim 128" in fused_path_hint("bf16", 128, 32, 8)
