@@ -779,6 +779,230 @@ __global__ __launch_bounds__(256, 2) void attn_bwd1_hd32(const bf16_t* __restric
 
 }  // namespace sp
 
+// ---------------------------------------------------------------------------------------------------------
+// Attention backward, single pass, head width 64, S <= 256 (round 5: BASELINE config 5 = d_model 512, 8 heads, seq_len 256).
+// The two-pass kernel above evaluates every score in both orientations and needs all four matrices of an item in LDS
+// (147 KB at S = 256: one workgroup per CU, load -> loop A -> loop B -> store in sequence; 72 us per block at c5).  Here,
+// attn_bwd1_hd32's scheme at twice the width: eight waves, wave w owns keys 32 w .. + 31 (K / V fragments and the dK / dV
+// accumulators in registers, V straight from global memory: it is never needed transposed), walks the eight 32-query blocks
+// evaluating every score ONCE (lane = key), drops its dS tile into a shared [256 keys][32 queries] image (two in rotation:
+// one barrier per query block) and computes ONE 16 x 16 tile of the block's dQ^T (d tile w & 3, query tile w >> 2) over all
+// 256 keys from transposing reads; dQ goes over the Q rows of the block (dead by then), dK over the K image, dV over the dO
+// image, and the three images leave in 128-byte row pieces.  Images have 128-byte rows, 16-byte slot ^ ((row >> 1) & 7)
+// (csrc/block_attn.hip's: fragment reads, transposing reads and the 8-byte tile writes are bank-conflict-free); the dS image
+// is attn_bwd1_hd32's (64-byte rows, 8-byte piece swizzle).  LDS: Q 32 + dO 32 + K 32 + dS 2 x 16 + Ls / Dl 2 = 130 KB.
+namespace sp64 {
+
+constexpr int IMG = 256 * 128;                 // one matrix: [256][128 B]
+constexpr int Q_OFF = 0, DO_OFF = IMG, K_OFF = 2 * IMG;
+constexpr int DS_OFF = 3 * IMG;                // [2] x dS image [256 keys][64 B]
+constexpr int DS_IMG = 256 * 64;
+constexpr int LSD_OFF = DS_OFF + 2 * DS_IMG;   // Ls[256] f32, Dl[256] f32
+constexpr int LDS_BYTES = LSD_OFF + 2048;      // 133 120 B
+
+__device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ bf16x8 fragk(const unsigned char* img, int row, int slot) {      // 16-byte slot `slot` of row `row`
+  return *reinterpret_cast<const bf16x8*>(img + row * 128 + ((slot ^ isw(row)) << 4));
+}
+// for column c0 + li (c0 a multiple of 16): the rows {kb + 4 lg + j} and {kb + 16 + 4 lg + j}, j = 0..3 (kb a multiple of 32)
+__device__ __forceinline__ bf16x8 fragtr(const unsigned char* img, int kb, int c0, int li, int lg) {
+  const int row = kb + 4 * lg + (li >> 2);
+  const int P = (c0 >> 2) + (li & 3);
+  const unsigned char* ptr = img + row * 128 + ((((P >> 1) ^ isw(row)) << 4) | ((P & 1) << 3));
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+__global__ __launch_bounds__(512) void attn_bwd1_hd64(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
+                                                      const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                      const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                                                      int B, int S, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * 64, D3 = 3 * D;
+  const float c2 = scale * LOG2E;
+  const unsigned int qkv_bytes = (unsigned int)B * (unsigned int)S * (unsigned int)D3 * 2u;
+  const unsigned int o_bytes = (unsigned int)B * (unsigned int)S * (unsigned int)D * 2u;
+  const __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qkv), 0, qkv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_do = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dout), 0, o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(out), 0, o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dq = __builtin_amdgcn_make_buffer_rsrc(dqkv, 0, qkv_bytes, 0x00020000);
+  constexpr unsigned int OOB = 0xFFFFFFF0u;
+  const int item = xcd_remap(blockIdx.x, gridDim.x);      // heads of one document -> one XCD (shared 128-byte lines)
+  const int b = item / H, h = item - b * H;
+  unsigned char* const Qs = smem + Q_OFF;
+  unsigned char* const dOs = smem + DO_OFF;
+  unsigned char* const Ks = smem + K_OFF;
+  float* const Ls = reinterpret_cast<float*>(smem + LSD_OFF);
+  float* const Dl = Ls + 256;
+
+  // ---- Q, dO, K -> LDS by LDS-DMA: wave w stages rows 32 w .. + 31 of each (4 pieces of 8 rows x 128 B per matrix); the source
+  // slot of a lane is its destination slot ^ swizzle(row), swizzle = 4 (i & 1) + (lane >> 4) for row 32 w + 8 i + (lane >> 3)
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    unsigned char* dst = smem + m * IMG + wave * 4096;
+    const unsigned int stride = m == 1 ? D * 2 : D3 * 2;
+    const unsigned int colb = m == 0 ? h * 128 : m == 1 ? h * 128 : (D + h * 64) * 2;      // Q | dO | K
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + 8 * i + (lane >> 3);
+      const unsigned int voff = row < S ? (unsigned int)(b * S + row) * stride + colb + (((lane & 7) ^ ((i & 1) * 4 + (lane >> 4))) << 4) : OOB;
+      if (m == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_do, (lds_u8*)(dst + i * 1024), 16, voff, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_qkv, (lds_u8*)(dst + i * 1024), 16, voff, 0, 0, 0);
+    }
+  }
+  // this wave's V fragments (keys 32 w .. + 31 as B operands), straight from global memory
+  const int k0 = 32 * wave;
+  bf16x8 bv[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int j = k0 + 16 * t + li;
+      bv[t][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+          rs_qkv, j < S ? (unsigned int)(b * S + j) * (D3 * 2) + (2 * D + h * 64) * 2 + (ks * 4 + lg) * 16 : OOB, 0, 0));
+    }
+  // the O row half (64 B) of thread (row = tid >> 1, half = tid & 1) and the lse of row tid (< 256) for the delta / Ls prologue
+  u32x4 o4[4];
+  {
+    const int row = tid >> 1;
+    const unsigned int voff = row < S ? (unsigned int)(b * S + row) * (D * 2) + h * 128 + (tid & 1) * 64 : OOB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, voff + e * 16, 0, 0);
+  }
+  const float lse_r = (tid < S && tid < 256) ? lse[((long long)b * H + h) * S + tid] : 0.f;
+  const int nv = nvalid[b];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const int row = tid >> 1, hf = tid & 1;
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x4 d = __builtin_bit_cast(u32x4, fragk(dOs, row, 4 * hf + e));
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        part += bf16_to_f32((bf16_t)(d[w] & 0xffff)) * bf16_to_f32((bf16_t)(o4[e][w] & 0xffff));
+        part += bf16_to_f32((bf16_t)(d[w] >> 16)) * bf16_to_f32((bf16_t)(o4[e][w] >> 16));
+      }
+    }
+    part += __shfl_xor(part, 1, 64);
+    if (hf == 0) Dl[row] = part;
+    if (tid < 256) Ls[tid] = lse_r * LOG2E;
+  }
+  // this wave's K fragments (B operands) and K^T (d tile dt_w) of EVERY key block for dQ
+  const int dt_w = wave & 3, qt_w = wave >> 2;       // this wave's tile of every query block's dQ^T
+  bf16x8 bk[2][2], kT[8];
+  float madd[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int j = k0 + 16 * t + li;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) bk[t][ks] = fragk(Ks, j, ks * 4 + lg);
+    madd[t] = j < S ? (j < nv ? 0.f : -1e9f * LOG2E) : -INFINITY;
+  }
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) kT[kb] = fragtr(Ks, 32 * kb, 16 * dt_w, li, lg);
+  f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();      // Ls / Dl are in place
+
+  const int nqb = (S + 31) >> 5;
+  for (int qb = 0; qb < nqb; ++qb) {
+    unsigned char* const dsi = smem + DS_OFF + (qb & 1) * DS_IMG;
+    u32x2 ppk[2][2], dsk[2][2];     // P and dS as bf16 pairs, [query tile][key tile]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = qb * 32 + qt * 16;
+      const bf16x8 aq0 = fragk(Qs, q + li, lg), aq1 = fragk(Qs, q + li, 4 + lg);
+      const bf16x8 ad0 = fragk(dOs, q + li, lg), ad1 = fragk(dOs, q + li, 4 + lg);
+      const f32x4 Lr = *reinterpret_cast<const f32x4*>(Ls + q + 4 * lg);
+      const f32x4 Dr = *reinterpret_cast<const f32x4*>(Dl + q + 4 * lg);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq0, bk[t][0], z, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq1, bk[t][1], sacc, 0, 0, 0);
+        f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad0, bv[t][0], z, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad1, bv[t][1], dpacc, 0, 0, 0);
+        float pe[4], de[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, madd[t]) - Lr[r]);
+          de[r] = pe[r] * (dpacc[r] - Dr[r]);
+        }
+        ppk[qt][t] = (u32x2){pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3])};
+        dsk[qt][t] = (u32x2){pack_bf16x2(de[0], de[1]), pack_bf16x2(de[2], de[3])};
+        // dS tile -> image [key k0 + 16 t + li][query 16 qt + 4 lg .. + 3]
+        const int row = k0 + 16 * t + li;
+        *reinterpret_cast<u32x2*>(dsi + row * 64 + (((4 * qt + lg) ^ sp::hsw(row)) << 3)) = dsk[qt][t];
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8 doT = fragtr(dOs, qb * 32, 16 * dt, li, lg), qT = fragtr(Qs, qb * 32, 16 * dt, li, lg);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 bp = __builtin_bit_cast(bf16x8, (u32x4){ppk[0][t][0], ppk[0][t][1], ppk[1][t][0], ppk[1][t][1]});
+        const bf16x8 bds = __builtin_bit_cast(bf16x8, (u32x4){dsk[0][t][0], dsk[0][t][1], dsk[1][t][0], dsk[1][t][1]});
+        dv[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doT, bp, dv[t][dt], 0, 0, 0);
+        dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, bds, dk[t][dt], 0, 0, 0);
+      }
+    }
+    // every wave's dS tile of this query block is in the image (the image of block qb - 2 was last read before the barrier
+    // of block qb - 1), and the block's Q rows have been read for the last time: dQ^T tile (dt_w, qt_w) over all 256 keys,
+    // written (bf16, scaled) over those rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[kb], sp::scrtr(dsi + kb * 2048, 16 * qt_w, li, lg), acc, 0, 0, 0);
+    {
+      const int row = 32 * qb + 16 * qt_w + li;
+      const f32x4 v = acc * scale;
+      *reinterpret_cast<u32x2*>(Qs + row * 128 + (((2 * dt_w + (lg >> 1)) ^ isw(row)) << 4) + (lg & 1) * 8) =
+          (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+  }
+  // ---- dK (scaled) over this wave's rows of the K image, dV over the same rows of the dO image (every wave is past its reads
+  // of both after the barrier); then the three images leave in 128-byte row pieces
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int row = k0 + 16 * t + li;
+      const int so = (((2 * dt + (lg >> 1)) ^ isw(row)) << 4) + (lg & 1) * 8;
+      const f32x4 kv = dk[t][dt] * scale;
+      *reinterpret_cast<u32x2*>(Ks + row * 128 + so) = (u32x2){pack_bf16x2(kv[0], kv[1]), pack_bf16x2(kv[2], kv[3])};
+      *reinterpret_cast<u32x2*>(dOs + row * 128 + so) = (u32x2){pack_bf16x2(dv[t][dt][0], dv[t][dt][1]), pack_bf16x2(dv[t][dt][2], dv[t][dt][3])};
+    }
+  __syncthreads();
+  const unsigned int rowbase = (unsigned int)(b * S) * (D3 * 2) + h * 128;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {        // 0: dQ (Q image), 1: dK (K image), 2: dV (dO image)
+    const unsigned char* img = m == 0 ? Qs : m == 1 ? Ks : dOs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i, r = idx >> 3, c16 = idx & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * 128 + ((c16 ^ isw(r)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs_dq, r < S ? rowbase + (unsigned int)r * (D3 * 2) + m * D * 2 + c16 * 16 : OOB, 0, 0);
+    }
+  }
+}
+
+}  // namespace sp64
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return MFP_OK;
@@ -851,6 +1075,15 @@ int bwd_hd(const void* qkv, const int* nvalid, const void* out, const void* dout
       if (int rc = set_lds(sp::attn_bwd1_hd32, sp::LDS_BYTES)) return rc;
       hipLaunchKernelGGL(sp::attn_bwd1_hd32, dim3(nwg), dim3(256), sp::LDS_BYTES, st, (const bf16_t*)qkv, nvalid, (const bf16_t*)out,
                          (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, S, H, scale, items, ipw);
+      MFP_CHECK_LAUNCH();
+      return MFP_OK;
+    }
+    static const bool single64 = !(getenv("MFP_ATTN_BWD_SINGLE64") && atoi(getenv("MFP_ATTN_BWD_SINGLE64")) == 0);   // A/B switch
+    if (HD == 64 && S > 128 && S <= 256 && single64 && (long long)B * S * H * 64 * 3 * 2 < 0xFFFFFF00LL) {
+      // single pass, one workgroup of eight waves per (document, head)
+      if (int rc = set_lds(sp64::attn_bwd1_hd64, sp64::LDS_BYTES)) return rc;
+      hipLaunchKernelGGL(sp64::attn_bwd1_hd64, dim3(B * H), dim3(512), sp64::LDS_BYTES, st, (const bf16_t*)qkv, nvalid, (const bf16_t*)out,
+                         (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, S, H, scale);
       MFP_CHECK_LAUNCH();
       return MFP_OK;
     }

@@ -258,7 +258,7 @@ def _attn_ref(qkv, nvalid, B, S, H):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,H,hd", [(2, 32, 8, 16), (3, 128, 8, 32), (2, 50, 8, 32), (1, 7, 4, 32),
-                                       (2, 256, 2, 64), (2, 100, 2, 16)])
+                                       (2, 256, 2, 64), (2, 100, 2, 16), (3, 200, 8, 64), (2, 256, 8, 64), (1, 129, 8, 64)])
 def test_attention(dtype, B, S, H, hd):
     ops = _ops()
     g = torch.Generator().manual_seed(B * 1000 + S)
