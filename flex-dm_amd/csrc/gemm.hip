@@ -494,14 +494,12 @@ int launch_ws_any(const mfp_gemm_args* a, const GemmParams& p, hipStream_t st) {
   const int ncu = mfp_ncu_launch();
   // narrow column slices (half the weight prologue per CU, twice the row tiles per workgroup) pay
   // off when a full-width slice would leave a workgroup only a handful of 32-row tiles
-  static const char* nv = getenv("MFP_WS_NARROW");   // experiment switch: 0 never, 1 N <= 256, 2 always
-  const int narrow_mode = nv ? nv[0] - '0' : 1;
-  const bool narrow = narrow_mode == 2 || (narrow_mode == 1 && a->N <= 256);
+  // (narrow for N <= 256 is the measured best; the MFP_WS_NARROW experiment switch of rounds 2-4 is gone)
+  const bool narrow = a->N <= 256;
   if (a->K == 256) {
     if (narrow) return launch_ws_epi<8, 2, true>(a, p, ncu, st);
     return launch_ws_epi<8, 2>(a, p, ncu, st);
   }
-  if (a->K == 512 && narrow_mode == 2) return launch_ws_epi<16, 2, true>(a, p, ncu, st);
   if (a->K == 768)   // plain epilogue only (ws_eligible): the fused-QKV input gradient
     return a->out_dtype == MFP_BF16 ? launch_ws<24, 2, WS_EPI_PLAIN, false, true>(p, ncu, st)
                                     : launch_ws<24, 2, WS_EPI_PLAIN, false, false>(p, ncu, st);
@@ -577,14 +575,12 @@ extern "C" size_t mfp_gemm_workspace_bytes(const mfp_gemm_args* a) {
   return ((size_t)sk * a->M * a->N + (size_t)sk * a->M) * sizeof(float);
 }
 
-static bool env_ws_off() { static const bool v = getenv("MFP_GEMM_NO_WS") != nullptr; return v; }   // benchmarking only
-static bool env_wg_off() { static const bool v = getenv("MFP_GEMM_NO_WG") != nullptr; return v; }   // benchmarking only
 
 extern "C" const char* mfp_gemm_kernel_family(const mfp_gemm_args* a) {
   if (a == nullptr) return "";
   const int splitk = a->splitk < 1 ? 1 : a->splitk;
-  if (!env_ws_off() && ws_eligible(a, splitk)) return "gemm_ws_kernel";
-  if (!env_wg_off() && uses_workspace(a) && wg_eligible(a, splitk)) return "gemm_wg_kernel";
+  if (ws_eligible(a, splitk)) return "gemm_ws_kernel";
+  if (uses_workspace(a) && wg_eligible(a, splitk)) return "gemm_wg_kernel";
   return "gemm_kernel";
 }
 
@@ -644,14 +640,14 @@ extern "C" int mfp_gemm(const mfp_gemm_args* a, mfp_stream_t stream) {
   kchunk = ((kchunk + bk - 1) / bk) * bk;
   p.kchunk = kchunk;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!env_ws_off() && ws_eligible(a, splitk)) {
+  if (ws_eligible(a, splitk)) {
     int rcw = launch_ws_any(a, p, st);
     if (rcw != MFP_OK) return rcw;
     MFP_CHECK_LAUNCH();
     return MFP_OK;
   }
   int rc;
-  if (!env_wg_off() && ws_path && wg_eligible(a, splitk)) rc = launch_wg(p, a->M, a->N, splitk, st);
+  if (ws_path && wg_eligible(a, splitk)) rc = launch_wg(p, a->M, a->N, splitk, st);
   else rc = a->in_dtype == MFP_BF16 ? launch_gemm<unsigned short>(a, p, splitk, st)
                                     : launch_gemm<float>(a, p, splitk, st);
   if (rc != MFP_OK) return rc;

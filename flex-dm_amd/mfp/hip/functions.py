@@ -138,7 +138,7 @@ class StepCtx:
         self.cuts = {}      # block index -> the activation entering that block (every block > 0; the data-parallel
                             # step cuts its backward pass at some of them, MFP.capture_train_step)
         # pending LayerNorm parameter-gradient reductions (flush_ln_jobs); None = reduce in line
-        self.ln_jobs = [] if os.environ.get("MFP_LN_BATCH_REDUCE", "1") == "1" else None
+        self.ln_jobs = []
         # grouped weight-gradient launches whose split-K reduction is still pending (flush_ln_jobs); None = reduce in place
         # (side streams: the groups' slab buffers are per stream, and a deferred reduction would have to join them first)
         self.wgrad_pending = [] if (WGRAD_DEFER and not self.sides) else None
@@ -171,7 +171,7 @@ class StepCtx:
     # MFP_SIDE_STREAMS=2: only a block's grouped weight-gradient launch leaves the main stream, and only for as long as
     # that block's LN1 backward (an HBM-bound streaming kernel whose workgroups fit beside the weight-gradient ones) runs:
     # BlockFn joins before it returns.  Every other on_side call joins at once (= in line).
-    OVERLAP = os.environ.get("MFP_SIDE_STREAMS", "0") == "2"
+    OVERLAP = False      # (MFP_SIDE_STREAMS was measured slower in rounds 1-4 in every form and is gone: one stream)
 
     def on_side(self, fn, *tensors, which: int = 0, hold: bool = False):
         """Run ``fn`` (weight-gradient GEMMs: off the critical path, only Adam needs them) on the

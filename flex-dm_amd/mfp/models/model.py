@@ -48,10 +48,10 @@ class Model:
         self.decoder = Decoder(input_columns, self.store, context=context, latent_dim=latent_dim,
                                dropout=dropout, l2=l2)
         self.step_ptr = None  # device int32 step counter (set by the optimizer) for dropout offsets
-        import os
-        cuda = self.store.device.type == "cuda" and os.environ.get("MFP_SIDE_STREAMS", "0") in ("1", "2")   # 1: weight gradients on side streams (measured 85 us/step SLOWER with the grouped launches)
-        self.side_stream = torch.cuda.Stream(device=self.store.device) if cuda else None
-        self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=self.store.device) for _ in range(2)] if cuda else []
+        # everything runs on ONE stream (weight gradients on side streams were measured 85 us per step slower with the grouped
+        # launches, rounds 1-4; the switch is gone)
+        self.side_stream = None
+        self.side_streams = []
         self._first = _first_seq_key(input_columns)
 
     def make_ctx(self, inputs: Dict, training: bool, nvalid: Optional[torch.Tensor] = None) -> StepCtx:
