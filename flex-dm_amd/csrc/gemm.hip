@@ -695,9 +695,10 @@ extern "C" int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs, int32_t njob
 // Split of the token dimension: a multiple of 8 (a k-slice's tiles share an XCD) that minimises
 // waves-of-workgroups x k-tiles-per-workgroup on this device, smallest split on ties (fewer partial
 // slabs); slices of at least 256 tokens, at most WG_MAX_KCHUNK when a job masks rows (codes in LDS).
-extern "C" int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K) {
+extern "C" int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int32_t deferred) {
   if (jobs == nullptr || njobs < 1 || K < 1) return 8;
-  const int tiles = wgg_macro_ok(jobs, njobs) ? wgg_tiles(jobs, njobs) / 2 : wgg_tiles(jobs, njobs), ncu = wgg_ncu();
+  // (the 256 x 128 macro-tile kernel only exists in the deferred form: the in-place form launches one workgroup per 128 x 128 tile)
+  const int tiles = (deferred && wgg_macro_ok(jobs, njobs)) ? wgg_tiles(jobs, njobs) / 2 : wgg_tiles(jobs, njobs), ncu = wgg_ncu();
   bool rowskip = false;
   for (int i = 0; i < njobs; ++i) rowskip |= jobs[i].rowcode != nullptr;
   int best = 8;

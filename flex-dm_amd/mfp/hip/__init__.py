@@ -88,7 +88,7 @@ SIGNATURES = {
     "mfp_gemm_workspace_bytes": (c_size_t, [POINTER(GemmArgs)]),
     "mfp_gemm_kernel_family": (c_char_p, [POINTER(GemmArgs)]),
     "mfp_wgrad_group_tiles": (c_int32, [POINTER(WgradJob), c_int32]),
-    "mfp_wgrad_group_splitk": (c_int32, [POINTER(WgradJob), c_int32, c_int32]),
+    "mfp_wgrad_group_splitk": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32]),
     "mfp_wgrad_group_workspace_bytes": (c_size_t, [POINTER(WgradJob), c_int32, c_int32]),
     "mfp_wgrad_group": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mfp_wgrad_group_partial": (c_int32, [POINTER(WgradJob), c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),

@@ -294,9 +294,10 @@ def _wgrad_jobs_array(jobs: Sequence[dict]):
     return arr
 
 
-def wgrad_group_splitk(jobs: Sequence[dict], K: int) -> int:
-    """The token split ``mfp_wgrad_group_splitk`` picks for this group on this device."""
-    return int(load().mfp_wgrad_group_splitk(_wgrad_jobs_array(jobs), len(jobs), K))
+def wgrad_group_splitk(jobs: Sequence[dict], K: int, deferred: bool = True) -> int:
+    """The token split ``mfp_wgrad_group_splitk`` picks for this group on this device (``deferred``: for the partial-tile
+    launch of the train step, else for the launch that reduces in place)."""
+    return int(load().mfp_wgrad_group_splitk(_wgrad_jobs_array(jobs), len(jobs), K, int(deferred)))
 
 
 def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defer: Optional[list] = None) -> None:
@@ -324,7 +325,7 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defe
         nbytes += K * (a.M + a.N) * 2 + a.M * a.N * 4
     dev = jobs[0]["A"].device
     if splitk is None:
-        splitk = lib.mfp_wgrad_group_splitk(arr, n, K)
+        splitk = lib.mfp_wgrad_group_splitk(arr, n, K, int(defer is not None))
     assert lib.mfp_wgrad_group_tiles(arr, n) <= WGRAD_MAX_TILES
     need = lib.mfp_wgrad_group_workspace_bytes(arr, n, splitk)
     if defer is not None:

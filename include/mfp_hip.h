@@ -128,7 +128,8 @@ typedef struct mfp_wgrad_job {
   int32_t M, N, lda, ldb, ldc;
 } mfp_wgrad_job;
 int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs /*host*/, int32_t njobs);
-int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K);
+int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t deferred /* the split for
+                               mfp_wgrad_group_partial (1) or mfp_wgrad_group (0): they launch different tile units */);
 size_t mfp_wgrad_group_workspace_bytes(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t splitk);
 int mfp_wgrad_group(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t splitk,
                     void* workspace, size_t workspace_bytes, uint32_t* tickets, mfp_stream_t stream);

@@ -41,7 +41,7 @@ x = torch.randn(T, D, device=dev)
 gam, bet = torch.rand(D, device=dev) + 0.5, torch.randn(D, device=dev)
 W, b = rnd(1536, D), torch.randn(1536, device=dev)
 report("as512 LN1 + QKV (stamps: 0 start, 1 image read, 2+2cg kh0 done, 3+2cg kh1 done, 40 end)",
-       lambda: ops.ln_dense_d512(x, gam, bet, W, b, 1536), 256, [1] + list(range(2, 26)) + [40])
+       lambda: ops.ln_dense_d512(x, gam, bet, W, b, 1536), 256, [42, 43, 44, 45, 1] + list(range(2, 26)) + [40])
 A5, W2t, h = rnd(T, D), rnd(1024, D), torch.relu(torch.randn(T, 1024, device=dev)).to(bf)
 report("as512 dh (mask)", lambda: ops.dense_relumask_d512(A5, W2t, h), 256, [1] + list(range(2, 18)) + [40])
 res, bo = torch.randn(T, D, device=dev), torch.randn(D, device=dev)
