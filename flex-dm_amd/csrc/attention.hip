@@ -217,8 +217,12 @@ __device__ __forceinline__ void stage_head(bf16_t* dst, const bf16_t* src, long 
   }
 }
 
-// MAX_KT = key tiles held in registers: 8 (S <= 128) or 16 (S <= 256)
-template <int HD, int MAX_KT>
+// MAX_KT = key tiles held in registers: 8 (S <= 128) or 16 (S <= 256).
+// QSPLIT (round 5, S > 128 / head width 64: BASELINE config 5): two workgroups per (document, head), each takes half of the
+// query tiles (one per wave) and stages only K and V -- the query fragments come straight from global memory -- so an item's
+// LDS drops from 111 KB to 75 KB and TWO workgroups share a CU: one's staging and stores run under the other's products
+// (the one-workgroup form ran load -> compute -> store in sequence, 29.5 us per launch against a 13 us byte floor).
+template <int HD, int MAX_KT, bool QSPLIT = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, const int* __restrict__ nvalid,
                                                      bf16_t* __restrict__ out, float* __restrict__ lse, int S,
                                                      int H, float scale) {
@@ -226,14 +230,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16(const bf16_t* __restrict
   extern __shared__ __attribute__((aligned(16))) bf16_t smb[];
   const int SP = (S + 31) & ~31;
   bf16_t* Qs = smb;
-  bf16_t* Ks = Qs + SP * LDH;
+  bf16_t* Ks = QSPLIT ? smb : Qs + SP * LDH;
   bf16_t* Vs = Ks + SP * LDH;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);   // heads of one document -> one XCD (shared 128-B lines)
+  const int bid0 = xcd_remap(blockIdx.x, gridDim.x);   // heads of one document (and both halves of a head) -> one XCD
+  const int bid = QSPLIT ? bid0 >> 1 : bid0, qhalf = QSPLIT ? bid0 & 1 : 0;
   const int b = bid / H, h = bid % H;
   const int D = H * HD, D3 = 3 * D;
   const int nv = nvalid[b];
   const bf16_t* base = qkv + (long long)b * S * D3 + h * HD;
-  stage_head<HD, HDP, LDH>(Qs, base, D3, S, SP);
+  if (!QSPLIT) stage_head<HD, HDP, LDH>(Qs, base, D3, S, SP);
   stage_head<HD, HDP, LDH>(Ks, base + D, D3, S, SP);
   stage_head<HD, HDP, LDH>(Vs, base + 2 * D, D3, S, SP);
   // The score math is VALU-issue-bound (64 % of SIMD cycles issuing, 14 VALU per score): work in
@@ -246,10 +251,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16(const bf16_t* __restrict
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int nkt = SP / 16;
-  for (int qt = wave; qt < nkt; qt += (int)(blockDim.x >> 6)) {
+  const int nqh = QSPLIT ? (nkt + 1) >> 1 : nkt;                    // query tiles of this workgroup: [qhalf * nqh, + nqh)
+  for (int qt = qhalf * nqh + wave; qt < min(nkt, (qhalf + 1) * nqh); qt += (int)(blockDim.x >> 6)) {
     bf16x8 bq[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bq[ks] = frag_k(Qs, LDH, qt * 16 + li, ks * 32, lg);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (QSPLIT) {      // query row qt * 16 + li, k = 32 ks + 8 lg .. + 7, straight from global memory (zero past S)
+        const int q = qt * 16 + li;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q < S) v = *reinterpret_cast<const u32x4*>(base + (long long)q * D3 + ks * 32 + lg * 8);
+        bq[ks] = __builtin_bit_cast(bf16x8, v);
+      } else {
+        bq[ks] = frag_k(Qs, LDH, qt * 16 + li, ks * 32, lg);
+      }
+    }
     f32x4 s[MAX_KT];
     float m = -INFINITY;
 #pragma unroll
@@ -1036,9 +1051,14 @@ int fwd_hd(const void* qkv, const int* nvalid, void* out, float* lse, int B, int
     const int SP = (S + 31) & ~31;
     size_t lds = (size_t)3 * SP * LDH * sizeof(bf16_t) + (size_t)SP * sizeof(float);
     block = dim3(512);   // 8 waves: one 16-query tile each at S = 128 (measured 20.0 vs 21.0 us with 4)
+    static const bool qsplit = !(getenv("MFP_ATTN_FWD_QSPLIT") && atoi(getenv("MFP_ATTN_FWD_QSPLIT")) == 0);   // A/B switch
     if (SP <= 128) {
       if (int rc = set_lds(attn_fwd_bf16<HD, 8>, lds)) return rc;
       hipLaunchKernelGGL((attn_fwd_bf16<HD, 8>), grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);
+    } else if (HD == 64 && qsplit) {
+      const size_t lds2 = (size_t)2 * SP * LDH * sizeof(bf16_t) + (size_t)SP * sizeof(float);
+      if (int rc = set_lds(attn_fwd_bf16<HD, 16, true>, lds2)) return rc;
+      hipLaunchKernelGGL((attn_fwd_bf16<HD, 16, true>), dim3(2 * B * H), block, lds2, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);
     } else {
       if (int rc = set_lds(attn_fwd_bf16<HD, 16>, lds)) return rc;
       hipLaunchKernelGGL((attn_fwd_bf16<HD, 16>), grid, block, lds, st, (const bf16_t*)qkv, nvalid, (bf16_t*)out, lse, S, H, scale);

@@ -62,7 +62,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #ifndef LN_BWD_DEPTH
 #define LN_BWD_DEPTH 2
 #endif
-constexpr int LN_BWD_ROWS = 32;  // rows per workgroup (4 waves x 8 rows); 64 and 16 measured 6-15 % slower
+// rows per workgroup: 32 (4 waves x 8 rows; 64 and 16 measured 6-15 % slower at 32 768 rows), 16 when 32 would leave the
+// chip under-occupied (round 5, BASELINE config 5: 16 384 rows = 512 workgroups = two waves per SIMD, each walking a chain
+// load -> reduce -> store per row -- latency-bound at 3.4 us per row)
+static int ln_bwd_rows(int T) {
+  static const int force = getenv("MFP_LN_BWD_ROWS") ? atoi(getenv("MFP_LN_BWD_ROWS")) : 0;      // A/B switch: 16 | 32
+  if (force == 16 || force == 32) return force;
+  return (T + 31) / 32 < 3 * mfp_ncu_physical() ? 16 : 32;
+}
 
 // Optional fused consumer: the LN-backward output dx is, in the DeepSVG block, immediately fed to
 // the backward of a Dropout + Dense pair (x1 = x + Dropout(Dense(.))): when `ddrop` is given the
@@ -71,7 +78,7 @@ constexpr int LN_BWD_ROWS = 32;  // rows per workgroup (4 waves x 8 rows); 64 an
 // bias gradient) as a third partial vector -- saving a full re-read of dx and two launches.
 // TRES = type of the residual gradient stream (dres in, dx out): float, or bf16 (unsigned short) when the step carries
 // the residual gradient in the compute dtype (mfp_layernorm_bwd_res16: 1 KB per element and layer less).
-template <typename TDY, int NVEC, typename TRES = float>
+template <typename TDY, int NVEC, typename TRES = float, int LN_BWD_ROWS = 32>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ x,
                                                      const float* __restrict__ gamma,
@@ -256,7 +263,8 @@ extern "C" int mfp_layernorm_fwd(const float* x, const float* gamma, const float
 }
 
 extern "C" size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D) {
-  size_t nblk = (size_t)(T + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+  const int rows = ln_bwd_rows(T);
+  size_t nblk = (size_t)(T + rows - 1) / rows;
   return nblk * 3 * D * sizeof(float);
 }
 
@@ -273,17 +281,20 @@ static int ln_bwd_impl(const char* who, const void* dy, const float* x, const fl
     return MFP_EWORKSPACE;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int nblk = (T + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+  const int rows = ln_bwd_rows(T);
+  int nblk = (T + rows - 1) / rows;
   float* part = reinterpret_cast<float*>(workspace);
   MFP_CHECK_ARG(dy_dtype == MFP_F32 || dy_dtype == MFP_BF16);
   const int nvec = (D + 255) / 256;
-#define LN_BWD(TT, NV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV, TRES>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D, (TT*)ddrop, drop_p, seed, offset, step_ptr)
+#define LN_BWD_(TT, NV, R) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV, TRES, R>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D, (TT*)ddrop, drop_p, seed, offset, step_ptr)
+#define LN_BWD(TT, NV) do { if (rows == 16) LN_BWD_(TT, NV, 16); else LN_BWD_(TT, NV, 32); } while (0)
   if (dy_dtype == MFP_F32) {
     if (nvec == 1) LN_BWD(float, 1); else if (nvec == 2) LN_BWD(float, 2); else LN_BWD(float, 4);
   } else {
     if (nvec == 1) LN_BWD(unsigned short, 1); else if (nvec == 2) LN_BWD(unsigned short, 2); else LN_BWD(unsigned short, 4);
   }
 #undef LN_BWD
+#undef LN_BWD_
   MFP_CHECK_LAUNCH();
   if (dgamma == nullptr) return MFP_OK;   // partials only: the caller reduces them (mfp_reduce_partials)
   // one launch: columns [0,D) -> dgamma, [D,2D) -> dbeta, [2D,3D) -> dropout bias gradient
@@ -311,7 +322,7 @@ extern "C" int mfp_layernorm_bwd_res16(const void* dy, const float* x, const flo
                                      ddrop, drop_colsum, drop_p, seed, offset, step_ptr, stream);
 }
 
-extern "C" int32_t mfp_layernorm_bwd_partial_rows(int32_t T) { return (T + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
+extern "C" int32_t mfp_layernorm_bwd_partial_rows(int32_t T) { const int rows = ln_bwd_rows(T); return (T + rows - 1) / rows; }
 
 extern "C" int mfp_reduce_partials(const float* part, float* out0, float* out1, float* out2, int64_t split1,
                                    int64_t split2, int32_t P, int64_t N, int64_t pstride, mfp_stream_t stream) {

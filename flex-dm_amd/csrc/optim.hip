@@ -103,8 +103,9 @@ __global__ void cast_kernel(const float* __restrict__ src, unsigned short* __res
 }
 
 // thread = (row, 4 consecutive columns): the dropout keying of the GEMM epilogue (common.h).  Block = 256 threads = (N/4 column quads) x (1024/N rows per pass).
-template <typename TOUT>
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dx, TOUT* __restrict__ dy,
+// TIN = float, or bf16 (unsigned short) when the step carries the residual gradient in the compute dtype (mfp_dropout_bwd_res16)
+template <typename TOUT, typename TIN = float>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const TIN* __restrict__ dx, TOUT* __restrict__ dy,
                                                           float* __restrict__ colsum_part, int M, int N,
                                                           float p, unsigned long long seed,
                                                           unsigned long long offset0, const int* step_ptr,
@@ -124,7 +125,14 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
     if (rsub < rows_at_once) {
       for (int r = r0 + rsub; r < r1; r += rows_at_once) {
         const long long o = (long long)r * N + q * 4;
-        float4 v = *reinterpret_cast<const float4*>(dx + o);
+        float4 v;
+        if constexpr (sizeof(TIN) == 4) {
+          v = *reinterpret_cast<const float4*>(dx + o);
+        } else {
+          const u32x2 h = *reinterpret_cast<const u32x2*>(dx + o);
+          v = make_float4(__uint_as_float(h[0] << 16), __uint_as_float(h[0] & 0xFFFF0000u), __uint_as_float(h[1] << 16),
+                          __uint_as_float(h[1] & 0xFFFF0000u));
+        }
         if (p > 0.f) {
           bool keep[4];
           drop_keep4(drop_row(dkey, (unsigned int)r), (unsigned int)(q * 4), dthr, keep);
@@ -291,6 +299,25 @@ extern "C" int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* w
     hipLaunchKernelGGL(dropout_bwd_kernel<float>, grid, dim3(256), 0, st, dx, (float*)dy, part, M, N, p, seed, offset, step_ptr, rpb);
   else
     hipLaunchKernelGGL(dropout_bwd_kernel<unsigned short>, grid, dim3(256), 0, st, dx, (unsigned short*)dy, part, M, N, p, seed, offset, step_ptr, rpb);
+  MFP_CHECK_LAUNCH();
+  launch_reduce_rows(part, colsum, colsum, N, nrb, N, N, st);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_dropout_bwd_res16(const void* dx, void* dy, float* colsum, void* workspace, size_t workspace_bytes, int32_t M,
+                                     int32_t N, float p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
+                                     mfp_stream_t stream) {
+  MFP_CHECK_ARG(dx && dy && colsum && M > 0 && N > 0 && N % 4 == 0 && p >= 0.f && p < 1.f);
+  if (!workspace || workspace_bytes < mfp_colsum_workspace_bytes(M, N)) {
+    mfp_set_error("mfp_dropout_bwd_res16: workspace too small");
+    return MFP_EWORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpb = rows_per_block_for(M), nrb = (M + rpb - 1) / rpb;
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL((dropout_bwd_kernel<unsigned short, unsigned short>), dim3(1, nrb), dim3(256), 0, st, (const unsigned short*)dx,
+                     (unsigned short*)dy, part, M, N, p, seed, offset, step_ptr, rpb);
   MFP_CHECK_LAUNCH();
   launch_reduce_rows(part, colsum, colsum, N, nrb, N, N, st);
   MFP_CHECK_LAUNCH();

@@ -144,6 +144,8 @@ SIGNATURES = {
     "mfp_colsum_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mfp_dropout_bwd": (c_int32, [c_void_p] * 4 + [c_size_t, c_int32, c_int32, c_float, c_uint64,
                                                    c_uint64, c_void_p, c_int32, c_void_p]),
+    "mfp_dropout_bwd_res16": (c_int32, [c_void_p] * 4 + [c_size_t, c_int32, c_int32, c_float, c_uint64,
+                                                         c_uint64, c_void_p, c_void_p]),
     "mfp_colsum": (c_int32, [c_void_p] * 3 + [c_size_t] + [c_int32] * 4 + [c_void_p]),
     "mfp_step_prologue": (c_int32, [POINTER(c_float), c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_uint64, c_uint64,
                                     c_void_p, c_void_p, c_int32, c_void_p]),

@@ -43,7 +43,8 @@ BLOCK_INFER = os.environ.get("MFP_BLOCK_INFER", "1") == "1"
 # train step: every LayerNorm backward then reads and writes 0.5 KB instead of 1 KB per element for it.  autograd sees
 # stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  ON by
 # default since round 4 (-25 us per c2 step; gradient cosine against the f64 oracle 0.99972 vs 0.99975 with the f32
-# stream, tests/test_gpu_model.py); "0" = f32 stream
+# stream, tests/test_gpu_model.py), at d_model 512 since round 5 (the heads' input-gradient product writes bf16,
+# mfp_dropout_bwd_res16 masks it for the last block); "0" = f32 stream
 RES_GRAD_BF16 = os.environ.get("MFP_RES_GRAD_BF16", "1") == "1"
 
 
@@ -52,7 +53,7 @@ def _res16_ok(ctx) -> bool:
     encoder's grouped weight-gradient launch (which reads its bf16 copy anyway)."""
     L = ctx.store.layout
     return (RES_GRAD_BF16 and ctx.cdt == torch.bfloat16 and ctx.training and ctx.tail["fuse"] and WGRAD_GROUP and MLP_FUSE
-            and L.table_rows_pad <= 1024 and L.D == 256 and L.L > 0)
+            and L.table_rows_pad <= 1024 and L.D in (256, 512) and L.L > 0)
 
 
 # heads forward + LossLayer + heads input gradient in one launch (csrc/heads_loss.hip); "0" = four launches
@@ -684,7 +685,7 @@ def _heads_drop(ctx: StepCtx):
     return None
 
 
-def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Tensor:
+def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     st, L = ctx.store, ctx.store.layout
     first = L.head_order[0]
     T, D, U = ctx.T, L.D, L.Upad
@@ -702,7 +703,7 @@ def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> torch.Ten
             return dh
         return ops.dgrad_rows(dl_c, wt, U)        # activation-stationary (csrc/block_fused.hip)
     dh = ops.gemm(dl_c, st.cw("decoder/decoder_%s/kernel" % first, rows=U), T, D, U, a_kmajor=True,
-                  b_kmajor=False, out_dtype=torch.float32)
+                  b_kmajor=False, out_dtype=out_dtype)
     return dh
 
 
@@ -825,6 +826,10 @@ class DecoderLossFn(torch.autograd.Function):
                 return ctx.store.scratch("grad_placeholder", (1,), fctx.hshape[1]).expand(fctx.hshape[0]), None, None
             return dh, None, None
         h_c, dl = fctx.saved
-        dh = _heads_bwd(ctx, dl, h_c)
+        r16 = fctx.needs_input_grad[0] and _res16_ok(ctx) and ctx.store.layout.D != 256
+        dh = _heads_bwd(ctx, dl, h_c, out_dtype=torch.bfloat16 if r16 else torch.float32)
         fctx.saved = None
+        if r16:      # RES_GRAD_BF16 at d_model 512: the plain product writes the compute dtype, the gradient goes down in StepCtx
+            ctx.res_grad = dh
+            return ctx.store.scratch("grad_placeholder", (1,), torch.float32).expand(h_c.shape), None, None
         return dh, None, None

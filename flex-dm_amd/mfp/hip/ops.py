@@ -940,6 +940,12 @@ def dropout_bwd(dx: torch.Tensor, out_dtype: torch.dtype, colsum: torch.Tensor, 
     M, N = dx.shape
     dy = torch.empty((M, N), dtype=out_dtype, device=dx.device)
     ws = workspace(lib.mfp_colsum_workspace_bytes(M, N), dx.device)
+    if dx.dtype == torch.bfloat16:      # the residual gradient travels in bf16 (functions.RES_GRAD_BF16)
+        assert out_dtype == torch.bfloat16
+        with _timed("dropout_bwd_kernel", 0, M * N * 4):
+            check(lib.mfp_dropout_bwd_res16(_ptr(dx), _ptr(dy), _ptr(colsum), ws.data_ptr(), ws.numel(), M, N, float(p),
+                                            int(seed), int(offset), _ptr(step_ptr), _stream()), "mfp_dropout_bwd_res16")
+        return dy
     with _timed("dropout_bwd_kernel", 0, M * N * (4 + _esz(dy))):
         check(lib.mfp_dropout_bwd(_ptr(dx), _ptr(dy), _ptr(colsum), ws.data_ptr(), ws.numel(), M, N, float(p),
                                   int(seed), int(offset), _ptr(step_ptr), dt_code(out_dtype), _stream()),

@@ -475,6 +475,11 @@ size_t mfp_colsum_workspace_bytes(int32_t M, int32_t N);
 int mfp_dropout_bwd(const float* dx, void* dy, float* colsum, void* workspace, size_t workspace_bytes,
                     int32_t M, int32_t N, float p, uint64_t seed, uint64_t offset,
                     const int32_t* step_ptr, int32_t out_dtype, mfp_stream_t stream);
+/* The same with dx and dy both bf16: the train step that carries the gradient of the residual stream in the compute dtype
+ * (mfp_layernorm_bwd_res16) -- d_model 512, where the gradient of the last block's output comes from a plain product. */
+int mfp_dropout_bwd_res16(const void* dx, void* dy, float* colsum, void* workspace, size_t workspace_bytes,
+                          int32_t M, int32_t N, float p, uint64_t seed, uint64_t offset,
+                          const int32_t* step_ptr, mfp_stream_t stream);
 /* colsum[n] = sum_m X[m][n] for a cdt matrix (bias gradients). */
 int mfp_colsum(const void* X, float* colsum, void* workspace, size_t workspace_bytes, int32_t M,
                int32_t N, int32_t ld, int32_t dtype, mfp_stream_t stream);
