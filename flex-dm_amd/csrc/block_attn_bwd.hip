@@ -28,6 +28,7 @@
 // -- conflict-free for the row-wise fragment reads and the transposing reads; dS image: 8-byte piece swizzle of
 // attn_bwd1_hd32.  256 VGPRs, no spill (a spill reload is a scratch access: it would drain the weight ring).
 #include "common.h"
+#include "ln_bwd_tile.h"
 #include <type_traits>
 #ifndef BB_ABL
 #define BB_ABL 0
@@ -50,6 +51,7 @@ struct AttnBwdBlockParams {
   unsigned short* dqkv;            // [T][768] bf16
   unsigned short* dy1;             // [T][256] bf16
   int T, H; float scale;
+  LnTileArgs ln;                   // LNB form (mfp_attn_block_bwd_ln): the backward of LN1 in the epilogue -- dy1 never leaves the CU
 };
 
 constexpr int BB_ROWS = 128, BB_D = 256;
@@ -139,7 +141,7 @@ __device__ __forceinline__ float dot8(const u32x4& x, const u32x4& y) {
 // SDOC = positions per document: 128 (a tile is a document) or 64 (two documents per tile, see csrc/block_attn.hip): a wave owns
 // 32 keys of ONE document (key block w4: document w4 >> 1) and walks all four 32-query blocks -- the blocks of the other
 // document get the padding term (P = dS = 0 exactly), so the barrier structure is the same for both forms.
-template <int SDOC>
+template <int SDOC, bool LNB = false>
 __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams p) {
   static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -459,6 +461,17 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
   __syncthreads();
   BB_TR(53);
   if (BB_ABL == 9) { asm volatile("s_dcache_wb" ::: "memory"); return; }
+  if constexpr (LNB) {
+    // ---- backward of LN1 on the tile (ln_bwd_tile.h): dy1 is read from its image, the partial sums go through the q image
+    // (dead: the barrier behind the last product)
+    f32x4 xv[16];
+    ln_tile_load_x(ln_tile_x_rsrc(p.ln, p.T), row0, wave, lane, xv);
+    const int c16 = lane >> 1, sub = (lane & 1) * 8;
+    ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wave, lane, tid, xv,
+                [&](int r) { return *reinterpret_cast<const u32x2*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4) + sub); },
+                reinterpret_cast<float*>(smem + BB_Q));
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = tid + 512 * i, r = idx >> 5, c16 = idx & 31;
@@ -476,7 +489,7 @@ extern "C" int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void*
   MFP_CHECK_ARG(B > 0 && B <= 16384 && (S == BB_ROWS || (S == 64 && B % 2 == 0)) && D == BB_D && H == 8);
   MFP_CHECK_ARG(((uintptr_t)d_o1 % 16) == 0 && ((uintptr_t)Wot % 16) == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 &&
                 ((uintptr_t)Wqkvt % 16) == 0 && ((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)dy1 % 16) == 0);
-  AttnBwdBlockParams p;
+  AttnBwdBlockParams p = {};
   p.d_o1 = reinterpret_cast<const unsigned short*>(d_o1); p.Wot = reinterpret_cast<const unsigned short*>(Wot);
   p.qkv = reinterpret_cast<const unsigned short*>(qkv); p.a = reinterpret_cast<const unsigned short*>(a);
   p.lse = lse; p.nvalid = nvalid; p.Wqkvt = reinterpret_cast<const unsigned short*>(Wqkvt);
@@ -495,6 +508,47 @@ extern "C" int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void*
   }
   if (S == 64) hipLaunchKernelGGL(attn_block_bwd_kernel<64>, dim3(B / 2), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(attn_block_bwd_kernel<128>, dim3(B), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_attn_block_bwd_ln(const void* d_o1, const void* Wot, const void* qkv, const void* a, const float* lse,
+                                     const int32_t* nvalid, const void* Wqkvt, void* dqkv, const float* x, const float* gamma,
+                                     const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop, float* part,
+                                     size_t part_bytes, int32_t B, int32_t S, int32_t D, int32_t H, float drop_p, uint64_t seed,
+                                     uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(d_o1 && Wot && qkv && a && lse && nvalid && Wqkvt && dqkv && x && gamma && mean && rstd && dres && dx && part);
+  MFP_CHECK_ARG(B > 0 && B <= 16384 && (S == BB_ROWS || (S == 64 && B % 2 == 0)) && D == BB_D && H == 8 && drop_p >= 0.f && drop_p < 1.f);
+  MFP_CHECK_ARG(((uintptr_t)d_o1 % 16) == 0 && ((uintptr_t)Wot % 16) == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 &&
+                ((uintptr_t)Wqkvt % 16) == 0 && ((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                ((uintptr_t)dres % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)ddrop % 16) == 0);
+  const int T = B * S;
+  if (part_bytes < (size_t)(T / BB_ROWS) * 3 * BB_D * sizeof(float)) {
+    mfp_set_error("mfp_attn_block_bwd_ln: partial-sum buffer too small");
+    return MFP_EWORKSPACE;
+  }
+  AttnBwdBlockParams p = {};
+  p.d_o1 = reinterpret_cast<const unsigned short*>(d_o1); p.Wot = reinterpret_cast<const unsigned short*>(Wot);
+  p.qkv = reinterpret_cast<const unsigned short*>(qkv); p.a = reinterpret_cast<const unsigned short*>(a);
+  p.lse = lse; p.nvalid = nvalid; p.Wqkvt = reinterpret_cast<const unsigned short*>(Wqkvt);
+  p.dqkv = reinterpret_cast<unsigned short*>(dqkv); p.dy1 = nullptr;
+  p.T = T; p.H = H; p.scale = 1.0f / sqrtf(32.0f);
+  p.ln.x = x; p.ln.gamma = gamma; p.ln.mean = mean; p.ln.rstd = rstd; p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
+  p.ln.dx = reinterpret_cast<unsigned short*>(dx); p.ln.ddrop = reinterpret_cast<unsigned short*>(ddrop); p.ln.part = part;
+  p.ln.drop_p = drop_p; p.ln.seed = seed; p.ln.offset = offset; p.ln.step_ptr = step_ptr;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_attn_block_bwd_ln: cannot raise dynamic LDS to %d: %s", BB_LDS, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  if (S == 64) hipLaunchKernelGGL((attn_block_bwd_kernel<64, true>), dim3(B / 2), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL((attn_block_bwd_kernel<128, true>), dim3(B), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "ln_bwd_tile.h"
 #include <type_traits>
 
 namespace {
@@ -544,8 +545,10 @@ struct MlpBwdParams {
 #ifdef MFP_GEMM_TRACE
   unsigned long long* trace;
 #endif
+  LnTileArgs ln;                   // LNB form (mfp_mlp_bwd_ln): the backward of LN2 in the epilogue -- dy2 never leaves the CU
 };
 
+template <bool LNB>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Hs = smem;
@@ -621,9 +624,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
 
+  // LNB: the x1 rows of the LN2-backward epilogue (wave w: rows 16 w .. + 15, a lane 4 columns) are requested at the head of
+  // chunk 14 -- the d_o2 fragments are dead by then, the 64 registers change hands -- and cross the last two chunks in flight
+  constexpr int LN_PF = LNB ? 16 : 0;
+  f32x4 xv[16];      // (dead registers in the plain form)
+  const __amdgpu_buffer_rsrc_t rs_x = ln_tile_x_rsrc(p.ln, LNB ? p.T : 0);
   auto chunk = [&](auto cc_) {
     constexpr int c = decltype(cc_)::value;
     constexpr int q = c >> 2, ffn2 = (c >> 1) & 1, j = c & 1;
+    if constexpr (LNB && c == MLP_CHUNKS - 2) ln_tile_load_x(rs_x, row0, wv, lane, xv);
     // the next quarter's h goes into its image while the two dy2 chunks of this quarter run (the masks of this
     // quarter were read before the barrier that ended the previous chunk); waited for at the end of the next chunk
     if (ffn2 && j == 0 && q < 3) hload(q + 1);
@@ -702,8 +711,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
     // issued behind the previous barrier (dh: 4, chunks 2, 6, 10, 14; dy2 of chunk 14: 4) are younger.  h waves: the
     // next h quarter must be there at the end of a quarter's last chunk; otherwise nothing to wait for
     {
-      constexpr int st_prev = ((c & 3) == 2 || c == MLP_CHUNKS - 1) ? 4 : 0;
-      constexpr int allowed_w = st_prev + (c + 2 < MLP_CHUNKS ? 8 : 0);
+      constexpr int st_prev = ((c & 3) == 2 || (c == MLP_CHUNKS - 1 && !LNB)) ? 4 : 0;
+      constexpr int allowed_w = st_prev + (c + 2 < MLP_CHUNKS ? 8 : 0) + (c >= MLP_CHUNKS - 2 ? LN_PF : 0);
       constexpr bool h_due = (c & 3) == 3 && q < 3;
       if (wv < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
       else if (h_due) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -725,7 +734,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
         for (int ks = 0; ks < 4; ++ks)
           hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
     }
-    if (c >= MLP_CHUNKS - 2) {
+    if (c >= MLP_CHUNKS - 2 && !LNB) {
       const unsigned char* img = Ws + (c % 3) * MLP_WS_B;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -744,6 +753,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   chunk(std::integral_constant<int, 12>{}); chunk(std::integral_constant<int, 13>{});
   chunk(std::integral_constant<int, 14>{}); chunk(std::integral_constant<int, 15>{});
   MLP_STAMP(19);
+  if constexpr (LNB) {
+    // ---- backward of LN2 on the tile (ln_bwd_tile.h).  dy2 sits in LDS as two bf16 images (columns 0..127 in ring buffer 2,
+    // 128..255 in ring buffer 0; every wave is past the barrier behind their last writes); the partial sums go through ring
+    // buffer 1 (free since that barrier)
+    const unsigned char* img = Ws + ((lane >> 5) ? 0 : 2) * MLP_WS_B;      // this lane's column half
+    const int c16 = (lane & 31) >> 1, sub = (lane & 1) * 8;
+    ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xv,
+                [&](int r) { return *reinterpret_cast<const u32x2*>(img + r * 256 + ((c16 ^ (r & 15)) << 4) + sub); },
+                reinterpret_cast<float*>(Ws + 1 * MLP_WS_B));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1333,7 +1352,7 @@ extern "C" int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2
   MFP_CHECK_ARG(T > 0 && T <= (1 << 21) && D == MLP_D);
   MFP_CHECK_ARG(((uintptr_t)d_o2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)W2t % 16) == 0 &&
                 ((uintptr_t)W1t % 16) == 0 && ((uintptr_t)dh % 16) == 0 && ((uintptr_t)dy2 % 16) == 0);
-  MlpBwdParams p;
+  MlpBwdParams p = {};
   p.d_o2 = reinterpret_cast<const unsigned short*>(d_o2); p.h = reinterpret_cast<const unsigned short*>(h);
   p.W2t = reinterpret_cast<const unsigned short*>(W2t); p.W1t = reinterpret_cast<const unsigned short*>(W1t);
   p.dh = reinterpret_cast<unsigned short*>(dh); p.dy2 = reinterpret_cast<unsigned short*>(dy2);
@@ -1345,14 +1364,54 @@ extern "C" int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2
   bool& attr_set = attr_done[mfp_device_slot()];
   constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;      // 160 KB: all of a CU's LDS
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_mlp_fused_bwd: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+extern "C" int mfp_mlp_bwd_ln(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, const float* x,
+                              const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop,
+                              float* part, size_t part_bytes, int32_t T, int32_t D, float drop_p, uint64_t seed, uint64_t offset,
+                              const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(d_o2 && h && W2t && W1t && dh && x && gamma && mean && rstd && dres && dx && ddrop && part);
+  MFP_CHECK_ARG(T > 0 && T % MLP_ROWS == 0 && T <= (1 << 21) && D == MLP_D && drop_p >= 0.f && drop_p < 1.f);
+  MFP_CHECK_ARG(((uintptr_t)d_o2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)W2t % 16) == 0 && ((uintptr_t)W1t % 16) == 0 &&
+                ((uintptr_t)dh % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)dres % 16) == 0 &&
+                ((uintptr_t)dx % 16) == 0 && ((uintptr_t)ddrop % 16) == 0);
+  if (part_bytes < (size_t)(T / MLP_ROWS) * 3 * MLP_D * sizeof(float)) {
+    mfp_set_error("mfp_mlp_bwd_ln: partial-sum buffer too small");
+    return MFP_EWORKSPACE;
+  }
+  MlpBwdParams p = {};
+  p.d_o2 = reinterpret_cast<const unsigned short*>(d_o2); p.h = reinterpret_cast<const unsigned short*>(h);
+  p.W2t = reinterpret_cast<const unsigned short*>(W2t); p.W1t = reinterpret_cast<const unsigned short*>(W1t);
+  p.dh = reinterpret_cast<unsigned short*>(dh); p.dy2 = nullptr;
+  p.T = T;
+#ifdef MFP_GEMM_TRACE
+  p.trace = g_mlp_trace;
+#endif
+  p.ln.x = x; p.ln.gamma = gamma; p.ln.mean = mean; p.ln.rstd = rstd; p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
+  p.ln.dx = reinterpret_cast<unsigned short*>(dx); p.ln.ddrop = reinterpret_cast<unsigned short*>(ddrop); p.ln.part = part;
+  p.ln.drop_p = drop_p; p.ln.seed = seed; p.ln.offset = offset; p.ln.step_ptr = step_ptr;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_mlp_bwd_ln: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(T / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

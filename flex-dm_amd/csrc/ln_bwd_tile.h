@@ -1,0 +1,108 @@
+// LayerNorm backward on a 128-row x 256-column tile whose dy rows sit in LDS: the epilogue of the launches that produce the
+// gradient of a LayerNorm output at d_model 256 (block_fused.hip mlp_bwd_kernel<true>: LN2; block_attn_bwd.hip
+// attn_block_bwd_kernel<.., true>: LN1), so that dy never crosses HBM.  The row arithmetic is ln_bwd_kernel's
+// (csrc/layernorm.hip; reference: Keras autodiff of LayerNormalization, transformer.py:216-217 / 222-223):
+//     xh = (x - mean) rstd,  gy = dy gamma,  dx = dres + rstd (gy - mean_c(gy) - xh mean_c(gy xh)),
+//     ddrop = Dropout-mask(dx) / keep  (the stream of mfp_dropout_bwd for (seed, offset, *step_ptr); ddrop == nullptr: none)
+//     part[tile][3][256] = sum over the tile's rows of  dy xh | dy | ddrop   (dgamma, dbeta, the consuming Dense's bias gradient)
+// bf16 residual-gradient stream (dres in, dx out: mfp_layernorm_bwd_res16's types).  Wave w owns rows 16 w .. + 15, a lane 4
+// consecutive columns: x in whole 1 KB rows, dres / dx / ddrop in 512-byte rows.  Every load is issued before the first store:
+// a load between two rows' stores would wait for them (vmcnt counts both).
+#pragma once
+#include "common.h"
+
+struct LnTileArgs {
+  const float* x; const float* gamma; const float* mean; const float* rstd;
+  const unsigned short* dres;      // bf16 [T][256]
+  unsigned short* dx;              // bf16 [T][256]
+  unsigned short* ddrop;           // bf16 [T][256] or nullptr
+  float* part;                     // [T / 128][3][256]
+  float drop_p; unsigned long long seed, offset; const int* step_ptr;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ln_tile_x_rsrc(const LnTileArgs& q, int T) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.x), 0, (unsigned int)T * 1024u, 0x00020000);
+}
+
+// the x rows of wave `wv` (may be issued early by the caller: 64 registers in flight)
+__device__ __forceinline__ void ln_tile_load_x(const __amdgpu_buffer_rsrc_t rs_x, int row0, int wv, int lane, f32x4 (&xv)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)(row0 + wv * 16 + i) * 1024u + lane * 16, 0, 0));
+}
+
+// dy_of(r) = the 4 bf16 values (u32x2) of tile row r at this lane's columns 4 lane .. + 3; red = 24 KB of free LDS; every wave
+// of the 512-thread workgroup calls it (one __syncthreads inside)
+template <typename DyOf>
+__device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0, int tile, int wv, int lane, int tid,
+                                            const f32x4 (&xv)[16], DyOf dy_of, float* red) {
+  constexpr int D = 256;
+  const unsigned int rbytes = (unsigned int)T * (D * 2);
+  const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(q.dres), 0, rbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc(q.dx, 0, rbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc(q.ddrop ? q.ddrop : q.dx, 0, q.ddrop ? rbytes : 0u, 0x00020000);
+  const int r0 = wv * 16;
+  u32x2 rv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    rv[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dr, (unsigned int)(row0 + r0 + i) * (D * 2) + lane * 8, 0, 0));
+  const f32x4 gam = *reinterpret_cast<const f32x4*>(q.gamma + lane * 4);
+  // the 16 rows' statistics in lanes 0..15, broadcast per row by v_readlane
+  float mu_l = 0.f, rs_l = 0.f;
+  if (lane < 16 && row0 + r0 + lane < T) { mu_l = q.mean[row0 + r0 + lane]; rs_l = q.rstd[row0 + r0 + lane]; }
+  const unsigned long long rng_off = q.offset + (q.step_ptr ? (unsigned long long)(*q.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  const float inv_keep = q.drop_p > 0.f ? 1.f / (1.f - q.drop_p) : 1.f;
+  const unsigned int dkey = drop_key(q.seed, rng_off), dthr = drop_thr16(q.drop_p);
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + i, row = row0 + r;
+    const bool live = row < T;
+    const float mu = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mu_l), i));
+    const float rs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rs_l), i));
+    const u32x2 dv = dy_of(r);
+    const float d[4] = {__uint_as_float(dv[0] << 16), __uint_as_float(dv[0] & 0xFFFF0000u), __uint_as_float(dv[1] << 16),
+                        __uint_as_float(dv[1] & 0xFFFF0000u)};
+    float xh[4], gy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[e] = (xv[i][e] - mu) * rs;
+      dg[e] += d[e] * xh[e];
+      db[e] += d[e];
+      gy[e] = d[e] * gam[e];
+    }
+    float s1 = gy[0] + gy[1] + gy[2] + gy[3];
+    float s2 = gy[0] * xh[0] + gy[1] * xh[1] + gy[2] * xh[2] + gy[3] * xh[3];
+    s1 = wave_sum(s1) * (1.0f / D);
+    s2 = wave_sum(s2) * (1.0f / D);
+    const float res[4] = {__uint_as_float(rv[i][0] << 16), __uint_as_float(rv[i][0] & 0xFFFF0000u), __uint_as_float(rv[i][1] << 16),
+                          __uint_as_float(rv[i][1] & 0xFFFF0000u)};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = rs * (gy[e] - s1 - xh[e] * s2) + res[e];
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_dx, (unsigned int)row * (D * 2) + lane * 8, 0, 0);
+    if (q.ddrop != nullptr) {
+      if (q.drop_p > 0.f) {
+        bool keep[4];
+        drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)(lane * 4), dthr, keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = keep[e] ? o[e] * inv_keep : 0.f;
+      }
+      __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_dd, (unsigned int)row * (D * 2) + lane * 8, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dc[e] += live ? o[e] : 0.f;
+    }
+  }
+  // the tile's partial sums: eight waves through LDS, one row of [3][256] per workgroup for the batched reduction at the end of
+  // the backward pass
+  *reinterpret_cast<f32x4*>(red + (wv * 3 + 0) * D + lane * 4) = (f32x4){dg[0], dg[1], dg[2], dg[3]};
+  *reinterpret_cast<f32x4*>(red + (wv * 3 + 1) * D + lane * 4) = (f32x4){db[0], db[1], db[2], db[3]};
+  *reinterpret_cast<f32x4*>(red + (wv * 3 + 2) * D + lane * 4) = (f32x4){dc[0], dc[1], dc[2], dc[3]};
+  __syncthreads();
+  for (int c = tid; c < 3 * D; c += 512) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a += red[w * 3 * D + c];
+    q.part[(size_t)tile * (3 * D) + c] = a;
+  }
+}

@@ -39,6 +39,11 @@ ATTN_BLOCK = os.environ.get("MFP_ATTN_BLOCK", "1") == "1"
 BLOCK_FWD = os.environ.get("MFP_BLOCK_FWD", "1") == "1"
 # ... and its inference form (nothing saved for a backward pass) for the callers that never differentiate; 0 = the training form
 BLOCK_INFER = os.environ.get("MFP_BLOCK_INFER", "1") == "1"
+# bf16 residual-gradient stream, d_model 256: the backward of LN2 in the epilogue of the MLP half's input-gradient launch
+# (mfp_mlp_bwd_ln: dy2 never leaves the CU); 0 = mlp_fused_bwd + layernorm_bwd (A/B switch)
+MLP_BWD_LN = os.environ.get("MFP_MLP_BWD_LN", "1") == "1"
+# ... and the backward of LN1 in the epilogue of the attention half's (mfp_attn_block_bwd_ln: dy1 never leaves the CU)
+ATTN_BWD_LN = os.environ.get("MFP_ATTN_BWD_LN", "1") == "1"
 # the gradient of the residual stream (what one block's backward hands to the next) in bf16 instead of f32 on the bf16
 # train step: every LayerNorm backward then reads and writes 0.5 KB instead of 1 KB per element for it.  autograd sees
 # stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  ON by
@@ -545,7 +550,15 @@ class BlockFn(torch.autograd.Function):
         wt0 = st.cwt(p + "mlp/dense_0/kernel")    # [D][2D]
         fused_bwd = _fused_ok(ctx, D) and wt is not None and wt0 is not None
         f512 = _fused512_ok(ctx, D) and wt is not None and wt0 is not None
-        if fused_bwd:      # both input-gradient products of the half in one launch (csrc/block_fused.hip)
+        ln_fused = False
+        if fused_bwd and MLP_BWD_LN and r16 and T % 128 == 0:
+            # ... and the backward of LN2 (+ the masked gradient of the attention dropout) in the same launch: dy2 stays on the CU
+            dh, dx1, d_o1 = ops.mlp_bwd_ln(d_o2, h, wt, wt0, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
+                                           st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
+                                           (st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1, ctx.step_ptr),
+                                           jobs=ctx.ln_jobs)
+            ln_fused = True
+        elif fused_bwd:      # both input-gradient products of the half in one launch (csrc/block_fused.hip)
             dh, dy2 = ops.mlp_fused_bwd(d_o2, h, wt, wt0)
         elif f512:         # d_model 512 (csrc/block_d512.hip): the ReLU mask in the first product's epilogue, row-owning second
             dh = ops.dense_relumask_d512(d_o2, wt, h)
@@ -568,18 +581,30 @@ class BlockFn(torch.autograd.Function):
             dy2 = ops.gemm(dh, wt0 if wt0 is not None else st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True,
                            b_kmajor=wt0 is not None, out_dtype=cdt)
         # LN2 backward also emits the masked/cast gradient of the attention Dropout + its bias grad
-        dx1, d_o1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
-                                      st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
-                                      drop=(st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
-                                            ctx.step_ptr), jobs=ctx.ln_jobs)
+        if not ln_fused:
+            dx1, d_o1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
+                                          st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
+                                          drop=(st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
+                                                ctx.step_ptr), jobs=ctx.ln_jobs)
         # ---- attention: x1 = x + drop(a Wo + bo)
         wt = st.cwt(p + "attn/combine_heads/kernel")
         wtq = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
         dy1 = None
+        ln1_fused = False
         if (_attn_block_bwd_on(ctx) and _fused_ok(ctx, D) and wt is not None and wtq is not None and cdt == torch.bfloat16
                 and _doc_tile_ok(B, S, T)):
-            # da = d_o1 Wo, attention backward and dy1 = dqkv Wqkv in one launch (csrc/block_attn_bwd.hip)
-            dqkv, dy1 = ops.attn_block_bwd(d_o1, wt, qkv, a, lse, ctx.nvalid, wtq, B, S, NUM_HEADS)
+            if ATTN_BWD_LN and r16:
+                # ... and the backward of LN1 (+ the masked gradient block i-1's MLP half starts from) in the same launch
+                drop1 = ((st.grad("blocks/seq2seq_%d/mlp/dense_1/bias" % (i - 1)), ctx.p, ctx.seed, 2 * (i - 1) + 2, ctx.step_ptr)
+                         if i > 0 else None)
+                dqkv, dx, nxt = ops.attn_block_bwd_ln(d_o1, wt, qkv, a, lse, ctx.nvalid, wtq, B, S, NUM_HEADS, x,
+                                                      st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
+                                                      st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), drop=drop1,
+                                                      jobs=ctx.ln_jobs)
+                ln1_fused = True
+            else:
+                # da = d_o1 Wo, attention backward and dy1 = dqkv Wqkv in one launch (csrc/block_attn_bwd.hip)
+                dqkv, dy1 = ops.attn_block_bwd(d_o1, wt, qkv, a, lse, ctx.nvalid, wtq, B, S, NUM_HEADS)
         else:
             if _fused_ok(ctx, D) and wt is not None:
                 da = ops.dgrad_d256(d_o1, wt)      # activation-stationary (csrc/block_fused.hip)
@@ -611,7 +636,7 @@ class BlockFn(torch.autograd.Function):
             ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1, hold=True)
         else:
             ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
-        if dy1 is not None:
+        if dy1 is not None or ln1_fused:
             pass
         elif _fused_ok(ctx, D) and wtq is not None:
             dy1 = ops.dgrad_qkv(dqkv, wtq)       # activation-stationary (csrc/block_fused.hip)
@@ -620,7 +645,12 @@ class BlockFn(torch.autograd.Function):
         else:
             dy1 = ops.gemm(dqkv, wtq if wtq is not None else st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, D,
                            3 * D, a_kmajor=True, b_kmajor=wtq is not None, out_dtype=cdt)
-        if i > 0:   # dx is the dx2 of block i-1: hand its masked/cast copy over (skips a dropout_bwd)
+        if ln1_fused:
+            if i > 0:
+                ctx.handoff[i - 1] = nxt
+            else:
+                ctx.dh_c = dx
+        elif i > 0:   # dx is the dx2 of block i-1: hand its masked/cast copy over (skips a dropout_bwd)
             pp = "blocks/seq2seq_%d/" % (i - 1)
             dx, nxt = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
                                         st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"),

@@ -553,6 +553,36 @@ def attn_block_bwd(d_o1, Wot, qkv, a, lse, nvalid, Wqkvt, B: int, S: int, H: int
     return dqkv, dy1
 
 
+def attn_block_bwd_ln(d_o1, Wot, qkv, a, lse, nvalid, Wqkvt, B: int, S: int, H: int, x, gamma, mean, rstd, dres, dgamma, dbeta,
+                      drop=None, jobs: Optional[list] = None):
+    """:func:`attn_block_bwd` with the backward of LN1 in its epilogue (``mfp_attn_block_bwd_ln``; bf16 residual-gradient
+    stream): returns (dqkv, dx, ddrop) -- dy1 never written.  ``drop`` = (colsum_out [D], p, seed, offset, step_ptr) or None
+    (block 0: no masked copy, ddrop = None); ``jobs`` as in :func:`mlp_bwd_ln`."""
+    lib = load()
+    T, D = d_o1.shape
+    dev = d_o1.device
+    dqkv = torch.empty((T, 3 * D), dtype=torch.bfloat16, device=dev)
+    dx = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    ddrop = torch.empty((T, D), dtype=torch.bfloat16, device=dev) if drop is not None else None
+    colsum, p_, seed_, off_, sp_ = drop if drop is not None else (None, 0.0, 0, 0, None)
+    P = T // 128
+    part = torch.empty((P, 3 * D), dtype=torch.float32, device=dev)
+    flops = 2 * T * D * D + 10 * B * S * S * D + 2 * T * 3 * D * D
+    nb = T * (D * 2 * 2 + 3 * D * 2 * 2 + D * (4 + 2 + 2 + (2 if drop is not None else 0))) + 4 * D * D * 2
+    with _timed("attn_block_bwd_kernel", flops, nb):
+        check(lib.mfp_attn_block_bwd_ln(_ptr(d_o1), _ptr(Wot), _ptr(qkv), _ptr(a), _ptr(lse), _ptr(nvalid), _ptr(Wqkvt), _ptr(dqkv),
+                                        _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part),
+                                        part.numel() * 4, B, S, D, H, float(p_), int(seed_), int(off_), _ptr(sp_), _stream()),
+              "mfp_attn_block_bwd_ln")
+    n = 3 * D if drop is not None else 2 * D
+    if jobs is not None:
+        jobs.append(dict(part=part, out0=dgamma, out1=dbeta, out2=colsum, split1=D, split2=2 * D, P=P, N=n, pstride=3 * D))
+    else:
+        check(lib.mfp_reduce_partials(part.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(colsum), D, 2 * D, P, n, 3 * D, _stream()),
+              "mfp_reduce_partials")
+    return dqkv, dx, ddrop
+
+
 def encoder_dense2(xs, Ws, biases, codes, h: torch.Tensor) -> torch.Tensor:
     """h += sum_j [codes[j] == 0] (xs[j] Ws[j]^T + biases[j]) for two 512-wide numerical attributes, in place."""
     lib = load()
@@ -600,6 +630,32 @@ def mlp_fused_bwd(d_o2, h, W2t, W1t):
         check(lib.mfp_mlp_fused_bwd(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(dy2), T, D, _stream()),
               "mfp_mlp_fused_bwd")
     return dh, dy2
+
+
+def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, drop, jobs: Optional[list] = None):
+    """:func:`mlp_fused_bwd` with the backward of LN2 in its epilogue (``mfp_mlp_bwd_ln``; bf16 residual-gradient stream):
+    returns (dh, dx, ddrop) -- what ``mlp_fused_bwd`` + ``layernorm_bwd(dy2, x, ..., dres, drop=drop)`` return, dy2 never
+    written.  ``drop`` = (colsum_out [D], p, seed, offset, step_ptr); ``jobs``: the parameter-gradient partials (one row per
+    128-row tile) join the batched reduction at the end of the backward pass, else they are reduced here."""
+    lib = load()
+    T, D = d_o2.shape
+    dev = d_o2.device
+    dh = torch.empty((T, 2 * D), dtype=torch.bfloat16, device=dev)
+    dx = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    ddrop = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    colsum, p_, seed_, off_, sp_ = drop
+    P = T // 128
+    part = torch.empty((P, 3 * D), dtype=torch.float32, device=dev)
+    with _timed("mlp_bwd_kernel", 2 * 2 * T * D * 2 * D, T * (D * 2 + 2 * D * 2 * 2 + D * (4 + 2 + 2 + 2)) + 2 * D * 2 * D * 2):
+        check(lib.mfp_mlp_bwd_ln(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(x), _ptr(gamma), _ptr(mean),
+                                 _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part), part.numel() * 4, T, D, float(p_),
+                                 int(seed_), int(off_), _ptr(sp_), _stream()), "mfp_mlp_bwd_ln")
+    if jobs is not None:
+        jobs.append(dict(part=part, out0=dgamma, out1=dbeta, out2=colsum, split1=D, split2=2 * D, P=P, N=3 * D, pstride=3 * D))
+    else:
+        check(lib.mfp_reduce_partials(part.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(colsum), D, 2 * D, P, 3 * D, 3 * D,
+                                      _stream()), "mfp_reduce_partials")
+    return dh, dx, ddrop
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,

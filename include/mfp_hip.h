@@ -243,6 +243,17 @@ int mfp_qkv_fused_fwd(const float* x, const float* gamma, const float* beta, con
 int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, void* dy2,
                       int32_t T, int32_t D, mfp_stream_t stream);
 
+/* The same launch with the backward of LN2 in its epilogue (round 5: dy2 never leaves the CU -- the tile's rows are complete
+ * in LDS when the second product ends): dx bf16 [T,256] = dres + d(LN2)(dy2; x, gamma, mean, rstd), ddrop bf16 = its
+ * dropout-masked copy (the stream of mfp_dropout_bwd for (seed, offset, *step_ptr); drop_p = 0: a plain copy), and one row of
+ * partial sums per 128-row tile, part[T / 128][3][256] = dgamma | dbeta | column sums of ddrop, for mfp_reduce_partials(_batch)
+ * (P = T / 128, pstride = 768).  The bf16 residual-gradient stream only (mfp_layernorm_bwd_res16's types); T % 128 == 0.
+ * Replaces mfp_mlp_fused_bwd + mfp_layernorm_bwd_res16 (reference: Keras autodiff of transformer.py:161-171, 222-225). */
+int mfp_mlp_bwd_ln(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, const float* x,
+                   const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop,
+                   float* part, size_t part_bytes, int32_t T, int32_t D, float drop_p, uint64_t seed, uint64_t offset,
+                   const int32_t* step_ptr, mfp_stream_t stream);
+
 /* Input gradient of the fused Q | K | V Dense in one activation-stationary launch: dy bf16 [T,256] = dqkv Wqkv,
  * dqkv bf16 [T,768], Wt bf16 [256][768] = the kernel transposed (k-major shadow).  d_model 256 only. */
 int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t T, int32_t D, mfp_stream_t stream);
@@ -258,6 +269,15 @@ int mfp_dgrad_d256(const void* dy, const void* Wt, void* dx, int32_t T, int32_t 
 int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void* qkv, const void* a, const float* lse,
                        const int32_t* nvalid, const void* Wqkvt, void* dqkv, void* dy1, int32_t B, int32_t S,
                        int32_t D, int32_t H, mfp_stream_t stream);
+
+/* The same launch with the backward of LN1 in its epilogue (round 5; the arguments of mfp_mlp_bwd_ln): dx = dres + d(LN1)(dy1),
+ * ddrop = its dropout-masked copy or nullptr (block 0: nothing consumes one), part[T / 128][3][256].  Replaces
+ * mfp_attn_block_bwd + mfp_layernorm_bwd_res16. */
+int mfp_attn_block_bwd_ln(const void* d_o1, const void* Wot, const void* qkv, const void* a, const float* lse,
+                          const int32_t* nvalid, const void* Wqkvt, void* dqkv, const float* x, const float* gamma,
+                          const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop, float* part,
+                          size_t part_bytes, int32_t B, int32_t S, int32_t D, int32_t H, float drop_p, uint64_t seed,
+                          uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
 /* Encoder, both 512-wide numerical attributes in one launch (encoder.py:156-160,174-175,194-198):
  * h[t] += sum_j [code_j[t] == 0] (x_j[t] W_j^T + b_j), x_j bf16 [T,512], W_j bf16 [256][512], b_j f32 [256],

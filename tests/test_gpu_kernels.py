@@ -972,6 +972,46 @@ def test_mlp_fused_bwd(T):
     assert_close(dy2, want, 2e-2, 1e-2, "dy2 vs double")
 
 
+@pytest.mark.parametrize("T,p", [(4096, 0.1), (128 * 5, 0.0), (32768, 0.1)])
+def test_mlp_bwd_ln(T, p):
+    """mfp_mlp_bwd_ln (the backward of LN2 in the epilogue of the MLP half's input-gradient launch) against the two launches
+    it replaces, mfp_mlp_fused_bwd + mfp_layernorm_bwd_res16 on the same operands: dh bit-identical (same code), dx / the
+    dropout-masked copy equal up to an occasional bf16 step (the row arithmetic may contract differently), the parameter-gradient
+    and bias-gradient sums to f32 summation-order noise -- through both reduction routes (in line, batched job)."""
+    ops = _ops()
+    D, F = 256, 512
+    g = torch.Generator().manual_seed(T + 9)
+    dd = (torch.randn(T, D, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    hd = torch.randn(T, F, generator=g).clamp(min=0).to(DEV, torch.bfloat16)
+    W2t = (torch.randn(F, D, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    W1t = (torch.randn(D, F, generator=g) * 0.06).to(DEV, torch.bfloat16)
+    x = (torch.randn(T, D, generator=g) * 1.5 + 0.2).to(DEV)
+    gamma, beta = (torch.rand(D, generator=g) + 0.5).to(DEV), torch.randn(D, generator=g).to(DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, torch.bfloat16)
+    dres = torch.randn(T, D, generator=g).to(DEV, torch.bfloat16)
+    step = torch.full((1,), 3, dtype=torch.int32, device=DEV)
+    new = lambda: (torch.full((D,), float("nan"), device=DEV), torch.full((D,), float("nan"), device=DEV),
+                   torch.full((D,), float("nan"), device=DEV))
+    dg0, db0, cs0 = new()
+    dh0, dy2 = ops.mlp_fused_bwd(dd, hd, W2t, W1t)
+    dx0, do0 = ops.layernorm_bwd(dy2, x, gamma, mean, rstd, dres, dg0, db0, drop=(cs0, p, 11, 5, step))
+    for batched in (False, True):
+        dg1, db1, cs1 = new()
+        jobs = [] if batched else None
+        dh1, dx1, do1 = ops.mlp_bwd_ln(dd, hd, W2t, W1t, x, gamma, mean, rstd, dres, dg1, db1, (cs1, p, 11, 5, step), jobs=jobs)
+        if batched:
+            assert len(jobs) == 1
+            ops.reduce_partials_batch(jobs)
+        assert torch.equal(dh1, dh0)
+        assert dx1.dtype == torch.bfloat16 and do1.dtype == torch.bfloat16
+        assert (dx1 != dx0).float().mean().item() < 1e-4 and (do1 != do0).float().mean().item() < 1e-4
+        assert_close(dx1, dx0.float().cpu().double(), 2e-2, 1e-2, "dx")
+        assert torch.equal(do1 == 0, do0 == 0)
+        for a, b, what in ((dg1, dg0, "dgamma"), (db1, db0, "dbeta"), (cs1, cs0, "colsum")):
+            assert torch.isfinite(a).all(), what
+            assert_close(a, b.cpu().double(), 2e-3 * float(b.abs().max()), 1e-4, what)
+
+
 @pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
 def test_qkv_fused_fwd(T):
     """mfp_qkv_fused_fwd: qkv = LN(x) Wqkv^T + b in one launch (transformer.py:216-217,85-90) against ln_fwd + the
@@ -1275,6 +1315,57 @@ def test_attn_block_bwd(B, S):
     assert_close(dqkv, want, 3e-2, 3e-2, "dqkv vs double")
     want_dy1 = dqkv.float().cpu().double() @ Wqkv.double()
     assert_close(dy1, want_dy1, 1e-2, 1e-2, "dy1 vs double (from the kernel's own dqkv)")
+
+
+@pytest.mark.parametrize("B,S,drop", [(5, 128, True), (6, 64, True), (256, 128, True), (4, 128, False)])
+def test_attn_block_bwd_ln(B, S, drop):
+    """mfp_attn_block_bwd_ln (the backward of LN1 in the epilogue of the attention half's input-gradient launch) against the two
+    launches it replaces, mfp_attn_block_bwd + mfp_layernorm_bwd_res16: dqkv bit-identical (same code), dx / the dropout-masked
+    copy equal up to an occasional bf16 step, parameter-gradient sums to summation-order noise; with and without the masked copy
+    (block 0 has no consumer for one)."""
+    ops = _ops()
+    D, H = 256, 8
+    T = B * S
+    g = torch.Generator().manual_seed(900 + B)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    bf = torch.bfloat16
+    qkv = (rn(T, 3 * D) * 0.7).to(DEV, bf)
+    nvalid = torch.randint(1, S + 1, (B,), generator=g).to(torch.int32).to(DEV)
+    a, lse = ops.attention_fwd(qkv, nvalid, B, S, H)
+    Wot, Wqt = (rn(D, D) * 0.06).to(DEV, bf), (rn(D, 3 * D) * 0.08).to(DEV, bf)
+    d_o1 = (rn(T, D) * 0.5).to(DEV, bf)
+    x = (rn(T, D) * 1.5 + 0.2).to(DEV)
+    gamma, beta = (torch.rand(D, generator=g) + 0.5).to(DEV), rn(D).to(DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, bf)
+    dres = rn(T, D).to(DEV, bf)
+    step = torch.full((1,), 2, dtype=torch.int32, device=DEV)
+    new = lambda: (torch.full((D,), float("nan"), device=DEV), torch.full((D,), float("nan"), device=DEV),
+                   torch.full((D,), float("nan"), device=DEV))
+    dg0, db0, cs0 = new()
+    dqkv0, dy1 = ops.attn_block_bwd(d_o1, Wot, qkv, a, lse, nvalid, Wqt, B, S, H)
+    if drop:
+        dx0, do0 = ops.layernorm_bwd(dy1, x, gamma, mean, rstd, dres, dg0, db0, drop=(cs0, 0.1, 13, 4, step))
+    else:
+        dx0, do0 = ops.layernorm_bwd(dy1, x, gamma, mean, rstd, dres, dg0, db0), None
+    for batched in (False, True):
+        dg1, db1, cs1 = new()
+        jobs = [] if batched else None
+        dqkv1, dx1, do1 = ops.attn_block_bwd_ln(d_o1, Wot, qkv, a, lse, nvalid, Wqt, B, S, H, x, gamma, mean, rstd, dres, dg1, db1,
+                                                drop=(cs1, 0.1, 13, 4, step) if drop else None, jobs=jobs)
+        if batched:
+            ops.reduce_partials_batch(jobs)
+        assert torch.equal(dqkv1, dqkv0)
+        assert (dx1 != dx0).float().mean().item() < 1e-4
+        assert_close(dx1, dx0.float().cpu().double(), 2e-2, 1e-2, "dx")
+        sums = [(dg1, dg0, "dgamma"), (db1, db0, "dbeta")]
+        if drop:
+            assert (do1 != do0).float().mean().item() < 1e-4 and torch.equal(do1 == 0, do0 == 0)
+            sums.append((cs1, cs0, "colsum"))
+        else:
+            assert do1 is None
+        for u, v, what in sums:
+            assert torch.isfinite(u).all(), what
+            assert_close(u, v.cpu().double(), 2e-3 * float(v.abs().max()), 1e-4, what)
 
 
 @pytest.mark.parametrize("B,p", [(3, 0.0), (4, 0.1)])

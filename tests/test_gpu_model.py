@@ -603,7 +603,7 @@ def test_seq64_two_documents_per_tile_parity_vs_oracle(route):
         probe = _model(ic, params, D, L, "bf16")
         names = set(_kernel_names(lambda: _run(probe, ic, batch, modified, masks)))
         assert any(n.startswith("attn_block_fwd_kernel<") and n.endswith(", 64>") for n in names), sorted(names)
-        assert ("attn_block_bwd_kernel<64>" in names) == (route == "timed"), sorted(names)
+        assert any(n.startswith("attn_block_bwd_kernel<64") for n in names) == (route == "timed"), sorted(names)
         model = _model(ic, params, D, L, "bf16")
         loss, sums, outputs = _run(model, ic, batch, modified, masks)
     want = float(info["data_loss"])
