@@ -141,7 +141,8 @@ __device__ __forceinline__ float dot8(const u32x4& x, const u32x4& y) {
 // SDOC = positions per document: 128 (a tile is a document) or 64 (two documents per tile, see csrc/block_attn.hip): a wave owns
 // 32 keys of ONE document (key block w4: document w4 >> 1) and walks all four 32-query blocks -- the blocks of the other
 // document get the padding term (P = dS = 0 exactly), so the barrier structure is the same for both forms.
-template <int SDOC, bool LNB = false>
+// LNB: 0 = dy1 leaves as bf16 rows; 1 = LN1 backward in the epilogue from x (f32); 2 = from the x-hat stash (bf16)
+template <int SDOC, int LNB = 0>
 __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams p) {
   static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -464,12 +465,17 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
   if constexpr (LNB) {
     // ---- backward of LN1 on the tile (ln_bwd_tile.h): dy1 is read from its image, the partial sums go through the q image
     // (dead: the barrier behind the last product)
-    f32x4 xv[16];
-    ln_tile_load_x(ln_tile_x_rsrc(p.ln, p.T), row0, wave, lane, xv);
     const int c16 = lane >> 1, sub = (lane & 1) * 8;
-    ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wave, lane, tid, xv,
-                [&](int r) { return *reinterpret_cast<const u32x2*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4) + sub); },
-                reinterpret_cast<float*>(smem + BB_Q));
+    auto dy_of = [&](int r) { return *reinterpret_cast<const u32x2*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4) + sub); };
+    if constexpr (LNB == 2) {
+      u32x2 xhv[16];
+      ln_tile_load_xh(ln_tile_xh_rsrc(p.ln, p.T), row0, wave, lane, xhv);
+      ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wave, lane, tid, xhv, dy_of, reinterpret_cast<float*>(smem + BB_Q));
+    } else {
+      f32x4 xv[16];
+      ln_tile_load_x(ln_tile_x_rsrc(p.ln, p.T), row0, wave, lane, xv);
+      ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wave, lane, tid, xv, dy_of, reinterpret_cast<float*>(smem + BB_Q));
+    }
     return;
   }
 #pragma unroll
@@ -513,11 +519,12 @@ extern "C" int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void*
 }
 
 extern "C" int mfp_attn_block_bwd_ln(const void* d_o1, const void* Wot, const void* qkv, const void* a, const float* lse,
-                                     const int32_t* nvalid, const void* Wqkvt, void* dqkv, const float* x, const float* gamma,
+                                     const int32_t* nvalid, const void* Wqkvt, void* dqkv, const float* x, const void* xhat, const float* gamma,
                                      const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop, float* part,
                                      size_t part_bytes, int32_t B, int32_t S, int32_t D, int32_t H, float drop_p, uint64_t seed,
                                      uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
-  MFP_CHECK_ARG(d_o1 && Wot && qkv && a && lse && nvalid && Wqkvt && dqkv && x && gamma && mean && rstd && dres && dx && part);
+  MFP_CHECK_ARG(d_o1 && Wot && qkv && a && lse && nvalid && Wqkvt && dqkv && gamma && rstd && dres && dx && part);
+  MFP_CHECK_ARG((xhat != nullptr || (x != nullptr && mean != nullptr)) && ((uintptr_t)xhat % 16) == 0);
   MFP_CHECK_ARG(B > 0 && B <= 16384 && (S == BB_ROWS || (S == 64 && B % 2 == 0)) && D == BB_D && H == 8 && drop_p >= 0.f && drop_p < 1.f);
   MFP_CHECK_ARG(((uintptr_t)d_o1 % 16) == 0 && ((uintptr_t)Wot % 16) == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 &&
                 ((uintptr_t)Wqkvt % 16) == 0 && ((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
@@ -533,22 +540,31 @@ extern "C" int mfp_attn_block_bwd_ln(const void* d_o1, const void* Wot, const vo
   p.lse = lse; p.nvalid = nvalid; p.Wqkvt = reinterpret_cast<const unsigned short*>(Wqkvt);
   p.dqkv = reinterpret_cast<unsigned short*>(dqkv); p.dy1 = nullptr;
   p.T = T; p.H = H; p.scale = 1.0f / sqrtf(32.0f);
-  p.ln.x = x; p.ln.gamma = gamma; p.ln.mean = mean; p.ln.rstd = rstd; p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
+  p.ln.x = x; p.ln.xhat = reinterpret_cast<const unsigned short*>(xhat); p.ln.gamma = gamma; p.ln.mean = mean; p.ln.rstd = rstd;
+  p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
   p.ln.dx = reinterpret_cast<unsigned short*>(dx); p.ln.ddrop = reinterpret_cast<unsigned short*>(ddrop); p.ln.part = part;
   p.ln.drop_p = drop_p; p.ln.seed = seed; p.ln.offset = offset; p.ln.step_ptr = step_ptr;
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block_bwd_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
     if (e != hipSuccess) {
       mfp_set_error("mfp_attn_block_bwd_ln: cannot raise dynamic LDS to %d: %s", BB_LDS, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  if (S == 64) hipLaunchKernelGGL((attn_block_bwd_kernel<64, true>), dim3(B / 2), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL((attn_block_bwd_kernel<128, true>), dim3(B), dim3(512), BB_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (xhat != nullptr) {
+    if (S == 64) hipLaunchKernelGGL((attn_block_bwd_kernel<64, 2>), dim3(B / 2), dim3(512), BB_LDS, st, p);
+    else hipLaunchKernelGGL((attn_block_bwd_kernel<128, 2>), dim3(B), dim3(512), BB_LDS, st, p);
+  } else {
+    if (S == 64) hipLaunchKernelGGL((attn_block_bwd_kernel<64, 1>), dim3(B / 2), dim3(512), BB_LDS, st, p);
+    else hipLaunchKernelGGL((attn_block_bwd_kernel<128, 1>), dim3(B), dim3(512), BB_LDS, st, p);
+  }
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

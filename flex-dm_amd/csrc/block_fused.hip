@@ -548,7 +548,8 @@ struct MlpBwdParams {
   LnTileArgs ln;                   // LNB form (mfp_mlp_bwd_ln): the backward of LN2 in the epilogue -- dy2 never leaves the CU
 };
 
-template <bool LNB>
+// LNB: 0 = dy2 leaves as bf16 rows; 1 = LN2 backward in the epilogue from x1 (f32); 2 = from the x-hat stash (bf16)
+template <int LNB>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Hs = smem;
@@ -627,12 +628,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   // LNB: the x1 rows of the LN2-backward epilogue (wave w: rows 16 w .. + 15, a lane 4 columns) are requested at the head of
   // chunk 14 -- the d_o2 fragments are dead by then, the 64 registers change hands -- and cross the last two chunks in flight
   constexpr int LN_PF = LNB ? 16 : 0;
-  f32x4 xv[16];      // (dead registers in the plain form)
-  const __amdgpu_buffer_rsrc_t rs_x = ln_tile_x_rsrc(p.ln, LNB ? p.T : 0);
+  f32x4 xv[16];      // (dead registers in the other forms)
+  u32x2 xhv[16];
+  const __amdgpu_buffer_rsrc_t rs_x = LNB == 2 ? ln_tile_xh_rsrc(p.ln, p.T) : ln_tile_x_rsrc(p.ln, LNB ? p.T : 0);
   auto chunk = [&](auto cc_) {
     constexpr int c = decltype(cc_)::value;
     constexpr int q = c >> 2, ffn2 = (c >> 1) & 1, j = c & 1;
-    if constexpr (LNB && c == MLP_CHUNKS - 2) ln_tile_load_x(rs_x, row0, wv, lane, xv);
+    if constexpr (LNB == 1 && c == MLP_CHUNKS - 2) ln_tile_load_x(rs_x, row0, wv, lane, xv);
+    if constexpr (LNB == 2 && c == MLP_CHUNKS - 2) ln_tile_load_xh(rs_x, row0, wv, lane, xhv);
     // the next quarter's h goes into its image while the two dy2 chunks of this quarter run (the masks of this
     // quarter were read before the barrier that ended the previous chunk); waited for at the end of the next chunk
     if (ffn2 && j == 0 && q < 3) hload(q + 1);
@@ -759,9 +762,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
     // buffer 1 (free since that barrier)
     const unsigned char* img = Ws + ((lane >> 5) ? 0 : 2) * MLP_WS_B;      // this lane's column half
     const int c16 = (lane & 31) >> 1, sub = (lane & 1) * 8;
-    ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xv,
-                [&](int r) { return *reinterpret_cast<const u32x2*>(img + r * 256 + ((c16 ^ (r & 15)) << 4) + sub); },
-                reinterpret_cast<float*>(Ws + 1 * MLP_WS_B));
+    auto dy_of = [&](int r) { return *reinterpret_cast<const u32x2*>(img + r * 256 + ((c16 ^ (r & 15)) << 4) + sub); };
+    if constexpr (LNB == 2) ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xhv, dy_of, reinterpret_cast<float*>(Ws + 1 * MLP_WS_B));
+    else ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xv, dy_of, reinterpret_cast<float*>(Ws + 1 * MLP_WS_B));
   }
 }
 
@@ -1364,23 +1367,25 @@ extern "C" int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2
   bool& attr_set = attr_done[mfp_device_slot()];
   constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;      // 160 KB: all of a CU's LDS
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_mlp_fused_bwd: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(mlp_bwd_kernel<0>, dim3((T + MLP_ROWS - 1) / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }
 
 extern "C" int mfp_mlp_bwd_ln(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, const float* x,
-                              const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop,
+                              const void* xhat, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop,
                               float* part, size_t part_bytes, int32_t T, int32_t D, float drop_p, uint64_t seed, uint64_t offset,
                               const int32_t* step_ptr, mfp_stream_t stream) {
-  MFP_CHECK_ARG(d_o2 && h && W2t && W1t && dh && x && gamma && mean && rstd && dres && dx && ddrop && part);
+  MFP_CHECK_ARG(d_o2 && h && W2t && W1t && dh && gamma && rstd && dres && dx && ddrop && part);
+  MFP_CHECK_ARG(xhat != nullptr || (x != nullptr && mean != nullptr));
+  MFP_CHECK_ARG(((uintptr_t)xhat % 16) == 0);
   MFP_CHECK_ARG(T > 0 && T % MLP_ROWS == 0 && T <= (1 << 21) && D == MLP_D && drop_p >= 0.f && drop_p < 1.f);
   MFP_CHECK_ARG(((uintptr_t)d_o2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)W2t % 16) == 0 && ((uintptr_t)W1t % 16) == 0 &&
                 ((uintptr_t)dh % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)dres % 16) == 0 &&
@@ -1397,21 +1402,24 @@ extern "C" int mfp_mlp_bwd_ln(const void* d_o2, const void* h, const void* W2t, 
 #ifdef MFP_GEMM_TRACE
   p.trace = g_mlp_trace;
 #endif
-  p.ln.x = x; p.ln.gamma = gamma; p.ln.mean = mean; p.ln.rstd = rstd; p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
+  p.ln.x = x; p.ln.xhat = reinterpret_cast<const unsigned short*>(xhat); p.ln.gamma = gamma; p.ln.mean = mean; p.ln.rstd = rstd;
+  p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
   p.ln.dx = reinterpret_cast<unsigned short*>(dx); p.ln.ddrop = reinterpret_cast<unsigned short*>(ddrop); p.ln.part = part;
   p.ln.drop_p = drop_p; p.ln.seed = seed; p.ln.offset = offset; p.ln.step_ptr = step_ptr;
   static bool attr_done[MFP_MAX_DEVICES] = {};
   bool& attr_set = attr_done[mfp_device_slot()];
   constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       mfp_set_error("mfp_mlp_bwd_ln: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(T / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  if (xhat != nullptr) hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(T / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(mlp_bwd_kernel<1>, dim3(T / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -5,6 +5,9 @@
 //     xh = (x - mean) rstd,  gy = dy gamma,  dx = dres + rstd (gy - mean_c(gy) - xh mean_c(gy xh)),
 //     ddrop = Dropout-mask(dx) / keep  (the stream of mfp_dropout_bwd for (seed, offset, *step_ptr); ddrop == nullptr: none)
 //     part[tile][3][256] = sum over the tile's rows of  dy xh | dy | ddrop   (dgamma, dbeta, the consuming Dense's bias gradient)
+// x-hat form (round 5, LnTileArgs::xhat != nullptr): the forward pass left xh = (x - mean) rstd in bf16 (in the place of
+// y = LN(x): the launch that stashes it is mfp_block_fwd with xhat_stash = 1) and the epilogue reads 0.5 KB per element
+// instead of x's 1 KB; mean is not needed then.
 // bf16 residual-gradient stream (dres in, dx out: mfp_layernorm_bwd_res16's types).  Wave w owns rows 16 w .. + 15, a lane 4
 // consecutive columns: x in whole 1 KB rows, dres / dx / ddrop in 512-byte rows.  Every load is issued before the first store:
 // a load between two rows' stores would wait for them (vmcnt counts both).
@@ -13,6 +16,7 @@
 
 struct LnTileArgs {
   const float* x; const float* gamma; const float* mean; const float* rstd;
+  const unsigned short* xhat;      // bf16 [T][256] or nullptr: x-hat form (x, mean unused)
   const unsigned short* dres;      // bf16 [T][256]
   unsigned short* dx;              // bf16 [T][256]
   unsigned short* ddrop;           // bf16 [T][256] or nullptr
@@ -24,6 +28,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ln_tile_x_rsrc(const LnTileArg
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.x), 0, (unsigned int)T * 1024u, 0x00020000);
 }
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ln_tile_xh_rsrc(const LnTileArgs& q, int T) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(q.xhat), 0, (unsigned int)T * 512u, 0x00020000);
+}
+__device__ __forceinline__ void ln_tile_load_xh(const __amdgpu_buffer_rsrc_t rs_xh, int row0, int wv, int lane, u32x2 (&xv)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    xv[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xh, (unsigned int)(row0 + wv * 16 + i) * 512u + lane * 8, 0, 0));
+}
+
 // the x rows of wave `wv` (may be issued early by the caller: 64 registers in flight)
 __device__ __forceinline__ void ln_tile_load_x(const __amdgpu_buffer_rsrc_t rs_x, int row0, int wv, int lane, f32x4 (&xv)[16]) {
 #pragma unroll
@@ -33,9 +46,11 @@ __device__ __forceinline__ void ln_tile_load_x(const __amdgpu_buffer_rsrc_t rs_x
 
 // dy_of(r) = the 4 bf16 values (u32x2) of tile row r at this lane's columns 4 lane .. + 3; red = 24 KB of free LDS; every wave
 // of the 512-thread workgroup calls it (one __syncthreads inside)
-template <typename DyOf>
+// XT = f32x4 (x rows) or u32x2 (x-hat rows, bf16)
+template <typename XT, typename DyOf>
 __device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0, int tile, int wv, int lane, int tid,
-                                            const f32x4 (&xv)[16], DyOf dy_of, float* red) {
+                                            const XT (&xv)[16], DyOf dy_of, float* red) {
+  constexpr bool XH = sizeof(XT) == 8;
   constexpr int D = 256;
   const unsigned int rbytes = (unsigned int)T * (D * 2);
   const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(q.dres), 0, rbytes, 0x00020000);
@@ -49,7 +64,7 @@ __device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0
   const f32x4 gam = *reinterpret_cast<const f32x4*>(q.gamma + lane * 4);
   // the 16 rows' statistics in lanes 0..15, broadcast per row by v_readlane
   float mu_l = 0.f, rs_l = 0.f;
-  if (lane < 16 && row0 + r0 + lane < T) { mu_l = q.mean[row0 + r0 + lane]; rs_l = q.rstd[row0 + r0 + lane]; }
+  if (lane < 16 && row0 + r0 + lane < T) { mu_l = XH ? 0.f : q.mean[row0 + r0 + lane]; rs_l = q.rstd[row0 + r0 + lane]; }
   const unsigned long long rng_off = q.offset + (q.step_ptr ? (unsigned long long)(*q.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
   const float inv_keep = q.drop_p > 0.f ? 1.f / (1.f - q.drop_p) : 1.f;
   const unsigned int dkey = drop_key(q.seed, rng_off), dthr = drop_thr16(q.drop_p);
@@ -64,9 +79,13 @@ __device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0
     const float d[4] = {__uint_as_float(dv[0] << 16), __uint_as_float(dv[0] & 0xFFFF0000u), __uint_as_float(dv[1] << 16),
                         __uint_as_float(dv[1] & 0xFFFF0000u)};
     float xh[4], gy[4];
+    if constexpr (XH) {
+      xh[0] = __uint_as_float(xv[i][0] << 16); xh[1] = __uint_as_float(xv[i][0] & 0xFFFF0000u);
+      xh[2] = __uint_as_float(xv[i][1] << 16); xh[3] = __uint_as_float(xv[i][1] & 0xFFFF0000u);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      xh[e] = (xv[i][e] - mu) * rs;
+      if constexpr (!XH) xh[e] = (xv[i][e] - mu) * rs;
       dg[e] += d[e] * xh[e];
       db[e] += d[e];
       gy[e] = d[e] * gam[e];

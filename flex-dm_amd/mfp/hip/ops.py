@@ -554,7 +554,7 @@ def attn_block_bwd(d_o1, Wot, qkv, a, lse, nvalid, Wqkvt, B: int, S: int, H: int
 
 
 def attn_block_bwd_ln(d_o1, Wot, qkv, a, lse, nvalid, Wqkvt, B: int, S: int, H: int, x, gamma, mean, rstd, dres, dgamma, dbeta,
-                      drop=None, jobs: Optional[list] = None):
+                      drop=None, jobs: Optional[list] = None, xhat=None):
     """:func:`attn_block_bwd` with the backward of LN1 in its epilogue (``mfp_attn_block_bwd_ln``; bf16 residual-gradient
     stream): returns (dqkv, dx, ddrop) -- dy1 never written.  ``drop`` = (colsum_out [D], p, seed, offset, step_ptr) or None
     (block 0: no masked copy, ddrop = None); ``jobs`` as in :func:`mlp_bwd_ln`."""
@@ -571,7 +571,7 @@ def attn_block_bwd_ln(d_o1, Wot, qkv, a, lse, nvalid, Wqkvt, B: int, S: int, H: 
     nb = T * (D * 2 * 2 + 3 * D * 2 * 2 + D * (4 + 2 + 2 + (2 if drop is not None else 0))) + 4 * D * D * 2
     with _timed("attn_block_bwd_kernel", flops, nb):
         check(lib.mfp_attn_block_bwd_ln(_ptr(d_o1), _ptr(Wot), _ptr(qkv), _ptr(a), _ptr(lse), _ptr(nvalid), _ptr(Wqkvt), _ptr(dqkv),
-                                        _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part),
+                                        _ptr(x), _ptr(xhat), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part),
                                         part.numel() * 4, B, S, D, H, float(p_), int(seed_), int(off_), _ptr(sp_), _stream()),
               "mfp_attn_block_bwd_ln")
     n = 3 * D if drop is not None else 2 * D
@@ -632,11 +632,12 @@ def mlp_fused_bwd(d_o2, h, W2t, W1t):
     return dh, dy2
 
 
-def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, drop, jobs: Optional[list] = None):
+def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, drop, jobs: Optional[list] = None, xhat=None):
     """:func:`mlp_fused_bwd` with the backward of LN2 in its epilogue (``mfp_mlp_bwd_ln``; bf16 residual-gradient stream):
     returns (dh, dx, ddrop) -- what ``mlp_fused_bwd`` + ``layernorm_bwd(dy2, x, ..., dres, drop=drop)`` return, dy2 never
     written.  ``drop`` = (colsum_out [D], p, seed, offset, step_ptr); ``jobs``: the parameter-gradient partials (one row per
-    128-row tile) join the batched reduction at the end of the backward pass, else they are reduced here."""
+    128-row tile) join the batched reduction at the end of the backward pass, else they are reduced here.  ``xhat``: the bf16
+    stash (x - mean) rstd of ``block_fwd(xhat_stash=True)`` -- x and mean are then not read."""
     lib = load()
     T, D = d_o2.shape
     dev = d_o2.device
@@ -647,7 +648,7 @@ def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, dro
     P = T // 128
     part = torch.empty((P, 3 * D), dtype=torch.float32, device=dev)
     with _timed("mlp_bwd_kernel", 2 * 2 * T * D * 2 * D, T * (D * 2 + 2 * D * 2 * 2 + D * (4 + 2 + 2 + 2)) + 2 * D * 2 * D * 2):
-        check(lib.mfp_mlp_bwd_ln(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(x), _ptr(gamma), _ptr(mean),
+        check(lib.mfp_mlp_bwd_ln(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(x), _ptr(xhat), _ptr(gamma), _ptr(mean),
                                  _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part), part.numel() * 4, T, D, float(p_),
                                  int(seed_), int(off_), _ptr(sp_), _stream()), "mfp_mlp_bwd_ln")
     if jobs is not None:

@@ -250,7 +250,8 @@ int mfp_mlp_fused_bwd(const void* d_o2, const void* h, const void* W2t, const vo
  * (P = T / 128, pstride = 768).  The bf16 residual-gradient stream only (mfp_layernorm_bwd_res16's types); T % 128 == 0.
  * Replaces mfp_mlp_fused_bwd + mfp_layernorm_bwd_res16 (reference: Keras autodiff of transformer.py:161-171, 222-225). */
 int mfp_mlp_bwd_ln(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, const float* x,
-                   const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop,
+                   const void* xhat /* bf16 [T,256] = (x - mean) rstd as stashed by mfp_block_fwd(xhat_stash = 1), or NULL; not
+                   NULL: x and mean are not read (0.5 KB per element less) */, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop,
                    float* part, size_t part_bytes, int32_t T, int32_t D, float drop_p, uint64_t seed, uint64_t offset,
                    const int32_t* step_ptr, mfp_stream_t stream);
 
@@ -274,7 +275,7 @@ int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void* qkv, const
  * ddrop = its dropout-masked copy or nullptr (block 0: nothing consumes one), part[T / 128][3][256].  Replaces
  * mfp_attn_block_bwd + mfp_layernorm_bwd_res16. */
 int mfp_attn_block_bwd_ln(const void* d_o1, const void* Wot, const void* qkv, const void* a, const float* lse,
-                          const int32_t* nvalid, const void* Wqkvt, void* dqkv, const float* x, const float* gamma,
+                          const int32_t* nvalid, const void* Wqkvt, void* dqkv, const float* x, const void* xhat, const float* gamma,
                           const float* mean, const float* rstd, const void* dres, void* dx, void* ddrop, float* part,
                           size_t part_bytes, int32_t B, int32_t S, int32_t D, int32_t H, float drop_p, uint64_t seed,
                           uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);

@@ -972,6 +972,23 @@ def test_mlp_fused_bwd(T):
     assert_close(dy2, want, 2e-2, 1e-2, "dy2 vs double")
 
 
+def _check_ln_from_xhat(dy, xh, gamma, rstd, dres, dx, ddrop, dg, db, cs, p):
+    """LayerNorm backward restated in double from the bf16 x-hat stash (what the x-hat form of ln_bwd_tile computes)."""
+    d64, x64, g64 = dy.double().cpu(), xh.double().cpu(), gamma.double().cpu()
+    gy = d64 * g64
+    want = rstd.double().cpu()[:, None] * (gy - gy.mean(-1, keepdim=True) - x64 * (gy * x64).mean(-1, keepdim=True)) + dres.double().cpu()
+    assert_close(dx, want, 2e-2, 1e-2, "dx from x-hat")
+    assert_close(dg, (d64 * x64).sum(0), 2e-3 * float((d64 * x64).sum(0).abs().max()), 1e-4, "dgamma from x-hat")
+    assert_close(db, d64.sum(0), 2e-3 * float(d64.sum(0).abs().max()), 1e-4, "dbeta from x-hat")
+    if ddrop is not None:
+        keep = (ddrop != 0).cpu()
+        scale = 1.0 / (1.0 - p)
+        assert abs(keep.double().mean().item() - (1.0 - p)) < 0.02
+        assert_close(ddrop.double().cpu()[keep], (want * scale)[keep], 3e-2, 2e-2, "masked copy from x-hat")
+        # (the kernel sums the f32 values, the reference here their bf16 roundings: sqrt(T) roundings of ~2^-8 |v|)
+        assert_close(cs, ddrop.double().cpu().sum(0), 0.03 * dy.shape[0] ** 0.5, 1e-3, "colsum from x-hat")
+
+
 @pytest.mark.parametrize("T,p", [(4096, 0.1), (128 * 5, 0.0), (32768, 0.1)])
 def test_mlp_bwd_ln(T, p):
     """mfp_mlp_bwd_ln (the backward of LN2 in the epilogue of the MLP half's input-gradient launch) against the two launches
@@ -1010,6 +1027,12 @@ def test_mlp_bwd_ln(T, p):
         for a, b, what in ((dg1, dg0, "dgamma"), (db1, db0, "dbeta"), (cs1, cs0, "colsum")):
             assert torch.isfinite(a).all(), what
             assert_close(a, b.cpu().double(), 2e-3 * float(b.abs().max()), 1e-4, what)
+    # x-hat form: the epilogue reads the bf16 stash (x - mean) rstd instead of x -- against a double restatement from that stash
+    xh = ((x - mean[:, None]) * rstd[:, None]).to(torch.bfloat16)
+    dg2, db2, cs2 = new()
+    dh2, dx2, do2 = ops.mlp_bwd_ln(dd, hd, W2t, W1t, None, gamma, None, rstd, dres, dg2, db2, (cs2, p, 11, 5, step), xhat=xh)
+    assert torch.equal(dh2, dh0)
+    _check_ln_from_xhat(dy2, xh, gamma, rstd, dres, dx2, do2, dg2, db2, cs2, p)
 
 
 @pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
@@ -1366,6 +1389,13 @@ def test_attn_block_bwd_ln(B, S, drop):
         for u, v, what in sums:
             assert torch.isfinite(u).all(), what
             assert_close(u, v.cpu().double(), 2e-3 * float(v.abs().max()), 1e-4, what)
+    # x-hat form
+    xh = ((x - mean[:, None]) * rstd[:, None]).to(bf)
+    dg2, db2, cs2 = new()
+    dqkv2, dx2, do2 = ops.attn_block_bwd_ln(d_o1, Wot, qkv, a, lse, nvalid, Wqt, B, S, H, None, gamma, None, rstd, dres, dg2, db2,
+                                            drop=(cs2, 0.1, 13, 4, step) if drop else None, xhat=xh)
+    assert torch.equal(dqkv2, dqkv0)
+    _check_ln_from_xhat(dy1, xh, gamma, rstd, dres, dx2, do2, dg2, db2, cs2, 0.1)
 
 
 @pytest.mark.parametrize("B,p", [(3, 0.0), (4, 0.1)])
