@@ -734,6 +734,7 @@ int wgrad_group_launch(const mfp_wgrad_job* jobs, int32_t njobs, int32_t K, int3
   for (int i = 0; i < njobs; ++i) {
     const mfp_wgrad_job& j = jobs[i];
     MFP_CHECK_ARG(j.A && j.B && j.C && j.M > 0 && j.N > 0);
+    MFP_CHECK_ARG(defer || j.n_affine == nullptr);      // (the x-hat correction lives in mfp_wgrad_reduce)
     MFP_CHECK_ARG(j.M % 8 == 0 && j.N % 8 == 0 && j.lda % 8 == 0 && j.ldb % 8 == 0 && j.ldc % 4 == 0);
     MFP_CHECK_ARG(j.lda >= j.M && j.ldb >= j.N && j.ldc >= j.N);
     MFP_CHECK_ARG(((uintptr_t)j.A % 16) == 0 && ((uintptr_t)j.B % 16) == 0 && ((uintptr_t)j.C % 16) == 0);
@@ -805,7 +806,8 @@ extern "C" int mfp_wgrad_reduce(const mfp_wgrad_pending* groups, int32_t ngroups
       const mfp_wgrad_job& j = s.jobs[i];
       MFP_CHECK_ARG(j.C && j.M > 0 && j.N > 0 && j.N % 8 == 0 && j.ldc % 4 == 0 && j.ldc >= j.N && ((uintptr_t)j.C % 16) == 0);
       WgrJob& d = G.job[i];
-      d.C = j.C; d.colsum = j.colsum; d.M = j.M; d.N = j.N; d.ldc = j.ldc;
+      MFP_CHECK_ARG(j.n_affine == nullptr || (j.colsum != nullptr && j.N % 4 == 0 && ((uintptr_t)j.n_affine % 16) == 0));
+      d.C = j.C; d.colsum = j.colsum; d.nfix = j.n_affine; d.M = j.M; d.N = j.N; d.ldc = j.ldc;
       d.tiles_n = (j.N + 127) / 128; d.tile0 = tile0; d.pad_ = 0;
       tile0 += ((j.M + 127) / 128) * d.tiles_n;
     }

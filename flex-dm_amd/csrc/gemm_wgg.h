@@ -543,7 +543,7 @@ inline int launch_wgt(const WggParams& p, hipStream_t st) {
 
 // ------------------------------------------------------------------ deferred split-K reduction, all groups of a step
 constexpr int WGR_MAX_GROUPS = 8;
-struct WgrJob { float* C; float* colsum; int M, N, ldc, tiles_n, tile0, pad_; };
+struct WgrJob { float* C; float* colsum; const float* nfix; int M, N, ldc, tiles_n, tile0, pad_; };
 struct WgrGroup {
   const float* ws; const float* ws_col;
   long long zstride;
@@ -587,6 +587,20 @@ __global__ __launch_bounds__(256) void wgg_reduce_kernel(WgrParams p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) { acc[h][0] += v[u][h][0]; acc[h][1] += v[u][h][1]; acc[h][2] += v[u][h][2]; acc[h][3] += v[u][h][3]; }
       }
+  }
+  if (jb.nfix != nullptr && n0 + colh[0] < jb.N) {
+    // the B operand was x-hat = (x - mean) rstd instead of y = x-hat gamma + beta (mfp_wgrad_job::n_affine): C[m][n] =
+    // gamma[n] sum_t A[t][m] xhat[t][n] + beta[n] sum_t A[t][m]; the row sums are this job's bias-gradient partials
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(jb.nfix + n0 + colh[0]);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(jb.nfix + jb.N + n0 + colh[0]);
+    const int tile_c = jb.tile0 + tm * jb.tiles_n;      // the tile of this row block that carries the column-sum partials
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float sr = 0.f;
+      for (int z = 0; z < G.splitk; ++z) sr += G.ws_col[((long long)z * G.ntiles + tile_c) * 128 + rowh[h]];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[h][e] = gm[e] * acc[h][e] + bt[e] * sr;
+    }
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h)

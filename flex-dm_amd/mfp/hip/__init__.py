@@ -45,7 +45,8 @@ class GemmArgs(Structure):
 class WgradJob(Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("colsum", c_void_p), ("rowcode", c_void_p),
-        ("M", c_int32), ("N", c_int32), ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
+        ("M", c_int32), ("N", c_int32), ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("_pad", c_int32),
+        ("n_affine", c_void_p),
     ]
 
 

@@ -305,6 +305,9 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defe
     in ONE launch -- see ``mfp_wgrad_group`` in include/mfp_hip.h.  jobs: dicts with A, B (bf16
     [K, ld]), out (f32 [M, ldc] view), M, N and optionally colsum (f32 [M]), rowskip (u8 [K]).
 
+    ``naffine`` (f32 [2 N] = gamma | beta, deferred form only): B holds x-hat = (x - mean) rstd of the LayerNorm whose output
+    is the operand meant; the reduction writes gamma[n] (A^T x-hat)[m][n] + beta[n] colsum[m].
+
     ``defer`` (a list): the launch only leaves its split-K partial tiles (``mfp_wgrad_group_partial``) and appends a
     record to the list; ``wgrad_reduce(defer)`` later writes the gradients of every recorded group in one launch."""
     lib = load()
@@ -321,6 +324,10 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defe
         a.M, a.N = j["M"], j["N"]
         a.lda, a.ldb = A.stride(0), B.stride(0)
         a.ldc = out.stride(0) if out.dim() == 2 else j["N"]
+        na = j.get("naffine")      # f32 [2 N] = gamma | beta: B holds x-hat of that LayerNorm (deferred form only)
+        if na is not None:
+            assert defer is not None and j.get("colsum") is not None and na.dtype == torch.float32 and na.numel() == 2 * a.N and na.is_contiguous()
+        a.n_affine = _ptr(na)
         flops += 2 * K * a.M * a.N
         nbytes += K * (a.M + a.N) * 2 + a.M * a.N * 4
     dev = jobs[0]["A"].device

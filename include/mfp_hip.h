@@ -126,6 +126,12 @@ typedef struct mfp_wgrad_job {
   float* colsum;
   const uint8_t* rowcode;
   int32_t M, N, lda, ldb, ldc;
+  int32_t _pad;
+  const float* n_affine;   /* NULL, or gamma[N] followed by beta[N] (device): B holds x-hat = (x - mean) rstd of a LayerNorm whose
+                              output y = x-hat gamma + beta is the operand meant -- the reduction then writes
+                              C[m][n] = gamma[n] (A^T x-hat)[m][n] + beta[n] colsum[m].  Deferred form only (mfp_wgrad_group_partial
+                              + mfp_wgrad_reduce), colsum required.  The train step stashes x-hat instead of y (mfp_block_fwd
+                              xhat_stash) so that the LayerNorm backward reads 0.5 KB per element instead of x's 1 KB. */
 } mfp_wgrad_job;
 int32_t mfp_wgrad_group_tiles(const mfp_wgrad_job* jobs /*host*/, int32_t njobs);
 int32_t mfp_wgrad_group_splitk(const mfp_wgrad_job* jobs /*host*/, int32_t njobs, int32_t K, int32_t deferred /* the split for

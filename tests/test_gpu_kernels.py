@@ -1398,6 +1398,40 @@ def test_attn_block_bwd_ln(B, S, drop):
     _check_ln_from_xhat(dy1, xh, gamma, rstd, dres, dx2, do2, dg2, db2, cs2, 0.1)
 
 
+@pytest.mark.parametrize("T", [4096, 32768])
+def test_wgrad_group_xhat_operand(T):
+    """mfp_wgrad_job::n_affine: the B operand of a weight-gradient job is x-hat = (x - mean) rstd of a LayerNorm instead of
+    its output y = x-hat gamma + beta; mfp_wgrad_reduce writes gamma[n] (A^T x-hat)[m][n] + beta[n] colsum[m].  Block-shaped
+    group (both x-hat jobs + two plain ones, 128 x 128 tiles at 4 096 tokens, macro tiles at 32 768) against A^T y in double
+    with y NOT rounded to bf16; the plain jobs of the same launch are untouched."""
+    ops = _ops()
+    D = 256
+    g = torch.Generator().manual_seed(T + 77)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    bf = torch.bfloat16
+    dqkv, dh, d_o2, d_o1 = (rn(T, 3 * D) * 0.3).to(DEV, bf), (rn(T, 2 * D) * 0.3).to(DEV, bf), (rn(T, D) * 0.3).to(DEV, bf), (rn(T, D) * 0.3).to(DEV, bf)
+    xh1, xh2 = rn(T, D).to(DEV, bf), rn(T, D).to(DEV, bf)
+    h, a = rn(T, 2 * D).clamp(min=0).to(DEV, bf), rn(T, D).to(DEV, bf)
+    ga1 = torch.cat([1.0 + 0.3 * rn(D), 0.2 * rn(D)]).to(DEV)      # gamma | beta
+    ga2 = torch.cat([1.0 + 0.3 * rn(D), 0.2 * rn(D)]).to(DEV)
+    nan = lambda *s: torch.full(s, float("nan"), device=DEV)
+    Wq, W1, W2, Wo = nan(3 * D, D), nan(2 * D, D), nan(D, 2 * D), nan(D, D)
+    bq, b1 = nan(3 * D), nan(2 * D)
+    pending = []
+    ops.wgrad_group([dict(A=dqkv, B=xh1, out=Wq, M=3 * D, N=D, colsum=bq, naffine=ga1),
+                     dict(A=dh, B=xh2, out=W1, M=2 * D, N=D, colsum=b1, naffine=ga2),
+                     dict(A=d_o2, B=h, out=W2, M=D, N=2 * D),
+                     dict(A=d_o1, B=a, out=Wo, M=D, N=D)], T, defer=pending)
+    ops.wgrad_reduce(pending)
+    d64 = lambda t: t.double().cpu()
+    y1 = d64(xh1) * d64(ga1[:D]) + d64(ga1[D:])
+    y2 = d64(xh2) * d64(ga2[:D]) + d64(ga2[D:])
+    for got, want, what in ((Wq, d64(dqkv).t() @ y1, "dWqkv"), (W1, d64(dh).t() @ y2, "dW1"), (W2, d64(d_o2).t() @ d64(h), "dW2"),
+                            (Wo, d64(d_o1).t() @ d64(a), "dWo"), (bq, d64(dqkv).sum(0), "bqkv"), (b1, d64(dh).sum(0), "b1")):
+        assert torch.isfinite(got).all(), what
+        assert_close(got, want, 2e-4 * float(want.abs().max()), 1e-4, what)
+
+
 @pytest.mark.parametrize("B,p", [(3, 0.0), (4, 0.1)])
 def test_block_fwd(B, p):
     """mfp_block_fwd: a whole DeepSVG block forward in ONE launch against mfp_attn_block_fwd + mfp_mlp_fused_fwd (same
