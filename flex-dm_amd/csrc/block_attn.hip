@@ -44,6 +44,7 @@ struct AttnBlockParams {
   const unsigned short* W2; const float* b2;           // [256][512] bf16, f32 [256]
   unsigned short* y2; float* mean2; float* rstd2; unsigned short* h; float* x2; unsigned short* x2c;
   unsigned long long offset2;                          // dropout stream of the MLP half
+  int xhat;                                            // 1: the y1 / y2 buffers receive x-hat = (x - mean) rstd (bf16) instead of LN(x) (mfp_block_fwd_xhat)
   int stash;                                           // 0 = inference form (mfp_block_infer, template flag STASH): y1, qkv, a, lse, y2, h are not written
 };
 
@@ -87,7 +88,9 @@ __device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
 // 51 positions long -- data/crello-spec.yml:6-13, rico-spec.yml:3-10 -- so --seq_len 64 is the shape real runs have).  Everything
 // but the attention is row-wise; in the attention a wave's 16 queries belong to one document (queries 16 w .. + 15: document
 // w >> 2) and it visits only that document's 64 keys (rows kb .. kb + 63 of the k / v images): half the score work per head.
-template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128>
+// XHAT (round 5): the y1 / y2 buffers receive x-hat = (x - mean) rstd instead of LN(x) (mfp_block_fwd_xhat).  A template flag,
+// not a runtime one: with both forms in one kernel the training instance spilled a register across the last MLP chunks.
+template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128, bool XHAT = false>
 __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) {
   static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
   constexpr int NCH = MLP ? 2 * AB_CHUNKS : AB_CHUNKS;
@@ -217,17 +220,27 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + col), b1 = *reinterpret_cast<const f32x4*>(Bs + col + 4);
       float y[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { y[e] = v[ks][e] * rs * g0[e] + b0[e]; y[4 + e] = v[ks][4 + e] * rs * g1[e] + b1[e]; }
+      for (int e = 0; e < 8; ++e) y[e] = v[ks][e] * rs;      // x-hat
+      if constexpr (XHAT) {
+        // x-hat stash: straight from the operand layout (a lane's 8 columns = 16 bytes; the four g-lanes of a row cover 64
+        // contiguous bytes), the SAME eight stores per lane as the y rows below issue -- the counted waits see no difference
+        const u32x4 px = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(px, rs_y, (unsigned int)row * (AB_D * 2) + ks * 64 + g * 16, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] = y[e] * g0[e] + b0[e]; y[4 + e] = y[4 + e] * g1[e] + b1[e]; }
       const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
       *reinterpret_cast<u32x4*>(smem + lrow * 512 + (((ks * 4 + g) ^ li) << 4)) = pk;
     }
   }
   __syncthreads();
+  if constexpr (!XHAT) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int idx = tid + 512 * i, r = idx >> 5, c16 = idx & 31;
-    const u32x4 yv = *reinterpret_cast<const u32x4*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4));
-    __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y, (unsigned int)(row0 + r) * (AB_D * 2) + c16 * 16, 0, 0);
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 512 * i, r = idx >> 5, c16 = idx & 31;
+      const u32x4 yv = *reinterpret_cast<const u32x4*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4));
+      __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y, (unsigned int)(row0 + r) * (AB_D * 2) + c16 * 16, 0, 0);
+    }
   }
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -518,7 +531,16 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         const f32x4 gg = *reinterpret_cast<const f32x4*>(G2s + n), bb = *reinterpret_cast<const f32x4*>(Be2s + n);
         float y[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = (acc2[ct][rt][r] - mu[rt]) * rs2[rt] * gg[r] + bb[r];
+        for (int r = 0; r < 4; ++r) y[r] = (acc2[ct][rt][r] - mu[rt]) * rs2[rt];      // x-hat
+        // x-hat stash: 8-byte pieces from the accumulator layout (four consecutive tiles of a lane's row = 128 contiguous
+        // bytes over four stores); SIXTEEN stores instead of the eight y rows below -- the counted wait of the first MLP chunk
+        // allows for them
+        if constexpr (XHAT)      // (one address register per row: the tile's column offset is a constant of the unrolled loop)
+          __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])}, rs_y2,
+                                                (unsigned int)(row0 + lrow) * (AB_D * 2) + (nh * 64 + 4 * g_m) * 2,
+                                                ((ct >> 2) * 8 + (ct & 3)) * 32, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = y[r] * gg[r] + bb[r];
         const u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
         *reinterpret_cast<u32x2*>(irow + (((tl * 2 + (g_m >> 1)) ^ (lrow & 15)) << 4) + (g_m & 1) * 8) = pk;
       }
@@ -528,11 +550,13 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, rs2[rt]), rs_r2, so, 0, 0);
     }
     __syncthreads();
+    if constexpr (!XHAT) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid_m + 512 * i, r = idx >> 5, c16 = idx & 31;
-      const u32x4 yv = *reinterpret_cast<const u32x4*>(smem + r * 512 + (r >= 96 ? 32768 : 0) + ((c16 ^ (r & 15)) << 4));
-      __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y2, (unsigned int)(row0 + r) * (AB_D * 2) + c16 * 16, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid_m + 512 * i, r = idx >> 5, c16 = idx & 31;
+        const u32x4 yv = *reinterpret_cast<const u32x4*>(smem + r * 512 + (r >= 96 ? 32768 : 0) + ((c16 ^ (r & 15)) << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y2, (unsigned int)(row0 + r) * (AB_D * 2) + c16 * 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -649,7 +673,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         constexpr int st_this = cm == 0 ? 32 : cm == 14 ? 24 : 0;
         constexpr int allowed = st_prev + (c + 2 < NCH ? 4 : 0) + st_this;
         if (c + 1 < NCH) {
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
+          if (cm == 0 && XHAT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed + 8) : "memory");      // (16 x-hat stores, not 8 y rows)
+          else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
           __builtin_amdgcn_s_barrier();
         }
       }
@@ -693,6 +718,10 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 64>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 64>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, false, 64>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 128, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 64, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 64, true>, AB_LDS_MLP);
     if (e != hipSuccess) {
       mfp_set_error("mfp_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS_MLP, hipGetErrorString(e));
       return MFP_ELAUNCH;
@@ -701,6 +730,17 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
   }
   const bool drop = p.dropout_p > 0.f;
   const dim3 grid(tiles), blk(512);
+  if (p.xhat) {       // (mfp_block_fwd_xhat: the whole-block training forms)
+    if (!mlp || !p.stash) { mfp_set_error("mfp_block_fwd_xhat: whole-block training form only"); return MFP_EINVAL; }
+    if (S == 64) {
+      if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 64, true>), grid, blk, AB_LDS_MLP, st, p);
+      else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 64, true>), grid, blk, AB_LDS_MLP, st, p);
+    } else {
+      if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 128, true>), grid, blk, AB_LDS_MLP, st, p);
+      else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 128, true>), grid, blk, AB_LDS_MLP, st, p);
+    }
+    return MFP_OK;
+  }
   if (S == 64) {      // (two documents per tile: the whole-block forms only)
     if (!mlp) { mfp_set_error("mfp_attn_block_fwd: S = 64 is provided by mfp_block_fwd / mfp_block_infer only"); return MFP_EINVAL; }
     if (!p.stash) hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, false, 64>), grid, blk, AB_LDS_MLP, st, p);
@@ -728,7 +768,7 @@ static int fill_attn(AttnBlockParams& p, const float* x, const float* gamma, con
   MFP_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)Wqkv % 16) == 0 && ((uintptr_t)Wo % 16) == 0 && ((uintptr_t)y1 % 16) == 0 &&
                 ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)bqkv % 16) == 0 &&
                 ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)bo % 16) == 0);
-  p.x = x; p.gamma = gamma; p.beta = beta;
+  p.x = x; p.gamma = gamma; p.beta = beta; p.xhat = 0;
   p.Wqkv = reinterpret_cast<const unsigned short*>(Wqkv); p.bqkv = bqkv;
   p.Wo = reinterpret_cast<const unsigned short*>(Wo); p.bo = bo; p.nvalid = nvalid;
   p.y1 = reinterpret_cast<unsigned short*>(y1); p.mean = mean; p.rstd = rstd;
@@ -754,16 +794,17 @@ extern "C" int mfp_attn_block_fwd(const float* x, const float* gamma, const floa
   return MFP_OK;
 }
 
-extern "C" int mfp_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
-                             const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
-                             void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
-                             const void* W1, const float* b1, const void* W2, const float* b2, void* y2, float* mean2,
-                             float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
-                             float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
-                             const int32_t* step_ptr, mfp_stream_t stream) {
+static int block_fwd_impl(int xhat, const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                          const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
+                          void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
+                          const void* W1, const float* b1, const void* W2, const float* b2, void* y2, float* mean2,
+                          float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
+                          float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
+                          const int32_t* step_ptr, mfp_stream_t stream) {
   AttnBlockParams p;
   if (int rc = fill_attn(p, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, y1, mean, rstd, qkv, a, lse, x1, B, S, D, H, eps, dropout_p,
                          seed, offset_attn, step_ptr)) return rc;
+  p.xhat = xhat;
   MFP_CHECK_ARG(gamma2 && beta2 && W1 && b1 && W2 && b2 && y2 && mean2 && rstd2 && h && x2);
   MFP_CHECK_ARG(((uintptr_t)W1 % 16) == 0 && ((uintptr_t)W2 % 16) == 0 && ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)h % 16) == 0 &&
                 ((uintptr_t)x2 % 16) == 0 && ((uintptr_t)x2_bf16 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)b2 % 16) == 0 &&
@@ -777,6 +818,31 @@ extern "C" int mfp_block_fwd(const float* x, const float* gamma, const float* be
   if (int rc = launch_block(p, true, B * S / AB_ROWS, S, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
+}
+
+extern "C" int mfp_block_fwd(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                             const void* Wo, const float* bo, const int32_t* nvalid, void* y1, float* mean, float* rstd,
+                             void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
+                             const void* W1, const float* b1, const void* W2, const float* b2, void* y2, float* mean2,
+                             float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
+                             float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
+                             const int32_t* step_ptr, mfp_stream_t stream) {
+  return block_fwd_impl(0, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, y1, mean, rstd, qkv, a, lse, x1, gamma2, beta2, W1, b1, W2, b2,
+                        y2, mean2, rstd2, h, x2, x2_bf16, B, S, D, H, eps, dropout_p, seed, offset_attn, offset_mlp, step_ptr, stream);
+}
+
+// The same launch leaving x-hat = (x - mean) rstd (bf16) in the y1 / y2 buffers instead of LN1(x) / LN2(x1): what the x-hat
+// forms of mfp_attn_block_bwd_ln / mfp_mlp_bwd_ln read (0.5 KB per element instead of the f32 rows) and what
+// mfp_wgrad_job::n_affine turns back into the Q|K|V / FFN1 weight gradients.
+extern "C" int mfp_block_fwd_xhat(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                                  const void* Wo, const float* bo, const int32_t* nvalid, void* xhat1, float* mean, float* rstd,
+                                  void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
+                                  const void* W1, const float* b1, const void* W2, const float* b2, void* xhat2, float* mean2,
+                                  float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
+                                  float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
+                                  const int32_t* step_ptr, mfp_stream_t stream) {
+  return block_fwd_impl(1, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, xhat1, mean, rstd, qkv, a, lse, x1, gamma2, beta2, W1, b1, W2, b2,
+                        xhat2, mean2, rstd2, h, x2, x2_bf16, B, S, D, H, eps, dropout_p, seed, offset_attn, offset_mlp, step_ptr, stream);
 }
 
 // Inference form of mfp_block_fwd (MFP.__call__(training=False), iterative_decode, eval.py: reference mfp.py:141-207,

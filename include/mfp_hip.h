@@ -204,6 +204,16 @@ int mfp_block_fwd(const float* x, const float* gamma, const float* beta, const v
                   float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
                   float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
                   const int32_t* step_ptr, mfp_stream_t stream);
+/* The same launch leaving x-hat = (x - mean) rstd (bf16) in the place of y1 = LN1(x) / y2 = LN2(x1): what the x-hat forms of
+ * mfp_attn_block_bwd_ln / mfp_mlp_bwd_ln read instead of the f32 rows (0.5 KB per element and LayerNorm less) and what
+ * mfp_wgrad_job::n_affine turns back into the Q|K|V / FFN1 weight gradients.  Everything else as mfp_block_fwd. */
+int mfp_block_fwd_xhat(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                  const void* Wo, const float* bo, const int32_t* nvalid, void* xhat1, float* mean, float* rstd,
+                  void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
+                  const void* W1, const float* b1, const void* W2, const float* b2, void* xhat2, float* mean2,
+                  float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
+                  float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
+                  const int32_t* step_ptr, mfp_stream_t stream);
 
 /* --------------------------------------------------------------------------- Dense layers of a block at d_model 512
  * (csrc/block_d512.hip; BASELINE config 5 = Crello Ours-EXP-FT: reference args.py:29-38 --latent_dim 512 --num_blocks 8;

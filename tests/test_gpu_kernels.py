@@ -1474,6 +1474,16 @@ def test_block_fwd(B, p):
         # mfp_block_infer: the same launch with nothing saved (inference callers) -- x2 bit for bit
         x2i = ops.block_infer(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H)
         assert torch.equal(x2i, x2)
+    # mfp_block_fwd_xhat: the y1 / y2 buffers receive x-hat = (x - mean) rstd; everything else bit for bit
+    x2x, (xh1, m1x, r1x, qkvx, ax, lsex, x1x, xh2, m2x, r2x, hx) = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2),
+                                                                              B, S, H, p, 7, 3, 4, step, xhat_stash=True)
+    for got, want in ((x2x, x2), (qkvx, qkv), (ax, a), (lsex, lse), (x1x, x1), (hx, h), (m1x, m1), (r1x, r1), (m2x, m2), (r2x, r2)):
+        assert torch.equal(got, want)
+    for xh, xin, m, r, what in ((xh1, d(x), m1, r1, "x-hat 1"), (xh2, x1, m2, r2, "x-hat 2")):
+        want = ((xin.double() - m.double()[:, None]) * r.double()[:, None]).cpu()
+        assert_close(xh, want, 1e-2, 8e-3, what)
+        # (bf16 roundings of f32 values that may differ in the last bit)
+        assert (xh != want.to(DEV, torch.float32).to(bf)).float().mean().item() < 2e-3, what
 
 
 # ------------------------------------------------------------------------------------ d_model 512 (csrc/block_d512.hip)
