@@ -44,6 +44,19 @@ BLOCK_INFER = os.environ.get("MFP_BLOCK_INFER", "1") == "1"
 MLP_BWD_LN = os.environ.get("MFP_MLP_BWD_LN", "1") == "1"
 # ... and the backward of LN1 in the epilogue of the attention half's (mfp_attn_block_bwd_ln: dy1 never leaves the CU)
 ATTN_BWD_LN = os.environ.get("MFP_ATTN_BWD_LN", "1") == "1"
+# ... and the one-launch block forward stashes x-hat = (x - mean) rstd (bf16) in the place of LN(x): the LayerNorm-backward
+# epilogues read it instead of the f32 rows (-134 MB per c2 step), the Q|K|V / FFN1 weight gradients are formed from it and
+# corrected by gamma / beta in the split-K reduction (mfp_block_fwd_xhat, mfp_wgrad_job::n_affine); 0 = LN(x) stash (A/B switch)
+XHAT_STASH = os.environ.get("MFP_XHAT_STASH", "1") == "1"
+
+
+def _xhat_ok(ctx) -> bool:
+    """Forward-time decision for the x-hat stash: the train step whose backward pass runs the LayerNorm backward in the
+    input-gradient launches and leaves its weight gradients to the deferred grouped reduction.  (A backward pass that finds
+    one of these missing still works: the stand-alone LayerNorm backward reads x, and y is rebuilt from x-hat for a weight
+    gradient outside the deferred reduction.)"""
+    return (XHAT_STASH and MLP_BWD_LN and ATTN_BWD_LN and WGRAD_GROUP and ctx.wgrad_pending is not None and _res16_ok(ctx)
+            and ctx.store.layout.D == 256)
 # the gradient of the residual stream (what one block's backward hands to the next) in bf16 instead of f32 on the bf16
 # train step: every LayerNorm backward then reads and writes 0.5 KB instead of 1 KB per element for it.  autograd sees
 # stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  ON by
@@ -441,15 +454,18 @@ class BlockFn(torch.autograd.Function):
             # the whole block in one launch (csrc/block_attn.hip); the last block also leaves the heads' bf16 operand
             x2_c = (torch.empty((T, D), dtype=cdt, device=x.device)
                     if ctx.tail["fuse"] and i == st.layout.L - 1 else None)
+            xhat = fctx.needs_input_grad[0] and _xhat_ok(ctx)
             x2, saved = ops.block_fwd(
                 x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), st.cw(p + "attn/dense_query/kernel", rows=3 * D),
                 st.span(st.w, p + "attn/dense_query/bias", 3 * D), st.cw(p + "attn/combine_heads/kernel"),
                 st.weight(p + "attn/combine_heads/bias"), ctx.nvalid, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
                 st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"),
-                st.weight(p + "mlp/dense_1/bias"), B, S, NUM_HEADS, ctx.p, ctx.seed, 2 * i + 1, 2 * i + 2, ctx.step_ptr, x2_c=x2_c)
-            y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = saved
+                st.weight(p + "mlp/dense_1/bias"), B, S, NUM_HEADS, ctx.p, ctx.seed, 2 * i + 1, 2 * i + 2, ctx.step_ptr, x2_c=x2_c,
+                xhat_stash=xhat)
+            y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = saved      # (xhat: y1 / y2 hold x-hat)
             ctx.tail["x_c"] = (x2, x2_c) if x2_c is not None else None
             fctx.ctx, fctx.i = ctx, i
+            fctx.xhat = xhat
             fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
             return x2
         if _fused512_ok(ctx, D):
@@ -536,12 +552,24 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = fctx.saved
+        xhat = getattr(fctx, "xhat", False)      # y1 / y2 hold x-hat = (x - mean) rstd (mfp_block_fwd_xhat)
         r16 = ctx.res_grad is not None      # the residual gradient arrives in bf16 through the context (RES_GRAD_BF16)
         if r16:
             dx2, ctx.res_grad = ctx.res_grad, None
         else:
             dx2 = dx2.contiguous()
         sk = ops.wgrad_splitk
+        grouped = WGRAD_GROUP and cdt == torch.bfloat16
+        xh1, xh2 = (y1, y2) if xhat else (None, None)      # what the LayerNorm-backward epilogues read
+        na1 = na2 = None
+        if xhat:
+            if grouped and ctx.wgrad_pending is not None:
+                # x-hat operands: the deferred reduction writes gamma[n] (A^T x-hat)[m][n] + beta[n] colsum[m]  (gamma | beta
+                # are neighbours in the flat parameter buffer)
+                na1, na2 = st.span(st.w, p + "norm1/gamma", 2 * D), st.span(st.w, p + "norm2/gamma", 2 * D)
+            else:      # (a weight gradient outside the deferred reduction: rebuild the LayerNorm outputs)
+                y1 = (y1.float() * st.weight(p + "norm1/gamma") + st.weight(p + "norm1/beta")).to(cdt)
+                y2 = (y2.float() * st.weight(p + "norm2/gamma") + st.weight(p + "norm2/beta")).to(cdt)
         # ---- MLP: x2 = x1 + drop(h W2 + b2)
         d_o2 = ctx.handoff.pop(i, None)   # produced by the LN1 backward of block i+1 (fused)
         if d_o2 is None:
@@ -556,7 +584,7 @@ class BlockFn(torch.autograd.Function):
             dh, dx1, d_o1 = ops.mlp_bwd_ln(d_o2, h, wt, wt0, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
                                            st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
                                            (st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1, ctx.step_ptr),
-                                           jobs=ctx.ln_jobs)
+                                           jobs=ctx.ln_jobs, xhat=xh2)
             ln_fused = True
         elif fused_bwd:      # both input-gradient products of the half in one launch (csrc/block_fused.hip)
             dh, dy2 = ops.mlp_fused_bwd(d_o2, h, wt, wt0)
@@ -565,8 +593,6 @@ class BlockFn(torch.autograd.Function):
         else:
             dh = ops.gemm(d_o2, wt if wt is not None else st.cw(p + "mlp/dense_1/kernel"), T, 2 * D, D, a_kmajor=True,
                           b_kmajor=wt is not None, out_dtype=cdt, relu_bwd_aux=h)
-
-        grouped = WGRAD_GROUP and cdt == torch.bfloat16
 
         def wgrads_mlp():
             ops.gemm(d_o2, h, D, 2 * D, T, a_kmajor=False, b_kmajor=False, out=st.grad(p + "mlp/dense_1/kernel"),
@@ -600,7 +626,7 @@ class BlockFn(torch.autograd.Function):
                 dqkv, dx, nxt = ops.attn_block_bwd_ln(d_o1, wt, qkv, a, lse, ctx.nvalid, wtq, B, S, NUM_HEADS, x,
                                                       st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
                                                       st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), drop=drop1,
-                                                      jobs=ctx.ln_jobs)
+                                                      jobs=ctx.ln_jobs, xhat=xh1)
                 ln1_fused = True
             else:
                 # da = d_o1 Wo, attention backward and dy1 = dqkv Wqkv in one launch (csrc/block_attn_bwd.hip)
@@ -626,9 +652,9 @@ class BlockFn(torch.autograd.Function):
                 ops.wgrad_reduce(ctx.wgrad_pending)      # (more than 6 blocks: reduce what has accumulated)
             ops.wgrad_group([
                 dict(A=dqkv, B=y1, out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D), M=3 * D, N=D,
-                     colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D)),
+                     colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D), naffine=na1),
                 dict(A=dh, B=y2, out=st.grad(p + "mlp/dense_0/kernel"), M=2 * D, N=D,
-                     colsum=st.grad(p + "mlp/dense_0/bias")),
+                     colsum=st.grad(p + "mlp/dense_0/bias"), naffine=na2),
                 dict(A=d_o2, B=h, out=st.grad(p + "mlp/dense_1/kernel"), M=D, N=2 * D,
                      colsum=st.grad(p + "mlp/dense_1/bias") if i in ctx.tail["bias_wgg"] else None),
                 dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)], T, defer=ctx.wgrad_pending)
