@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(hip.MaskCol) == 72
     # pointers, size_t, ints, float(+pad), u64 x2, ptr
     assert ctypes.sizeof(hip.GemmArgs) == 8 * 9 + 8 + 4 * 12 + 4 + 4 + 8 + 8 + 8
-    assert ctypes.sizeof(hip.WgradJob) == 5 * 8 + 5 * 4 + 4
+    assert ctypes.sizeof(hip.WgradJob) == 5 * 8 + 6 * 4 + 8      # (+ _pad, n_affine: round 5)
     assert hip.GemmArgs.M.offset == 80 and hip.GemmArgs.seed.offset % 8 == 0
 
 
