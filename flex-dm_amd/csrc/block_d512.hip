@@ -78,7 +78,9 @@ struct As512Params {
   unsigned long long* trace;                                    // D5_TRACE builds: [workgroup][8 waves][64] clock stamps
 };
 
-template <int ASRC, int EPI>
+// XH (LayerNorm form only, round 5): the y buffer receives x-hat = (x - mean) rstd (bf16) instead of LN(x) -- straight from the
+// operand layout, BEFORE the first weight chunk is requested (so the stores are older than every counted load and P_STORES = 0)
+template <int ASRC, int EPI, bool XH = false>
 __global__ __launch_bounds__(512) void as512_kernel(As512Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Ws = smem;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(512) void as512_kernel(As512Params p) {
   }
 
   bf16x8 xf[2][16];
-  constexpr int P_STORES = ASRC == A5_SRC_LN ? 16 : 0;      // y row stores issued behind the first three weight chunks
+  constexpr int P_STORES = (ASRC == A5_SRC_LN && !XH) ? 16 : 0;      // y row stores issued behind the first three weight chunks
   if constexpr (ASRC == A5_SRC_LN) {
     // LayerNorm in the MFMA operand layout: wave w normalises rows 16 w .. + 15, lane (li, g) holds row li's columns
     // 32 ks + 8 g .. + 7 (statistics = two cross-lane steps); the bf16 result passes through a [128][1024 B] image
@@ -182,7 +184,13 @@ __global__ __launch_bounds__(512) void as512_kernel(As512Params p) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + col), b1 = *reinterpret_cast<const f32x4*>(Bs + col + 4);
         float y[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { y[e] = v[ks][e] * rs * g0[e] + b0[e]; y[4 + e] = v[ks][4 + e] * rs * g1[e] + b1[e]; }
+        for (int e = 0; e < 8; ++e) y[e] = v[ks][e] * rs;      // x-hat
+        if constexpr (XH) {      // a lane's 8 columns = 16 bytes; the four g-lanes of a row cover 64 contiguous bytes
+          const u32x4 px = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+          __builtin_amdgcn_raw_buffer_store_b128(px, rs_y, (unsigned int)row * (A5_K * 2) + ks * 64 + g * 16, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] = y[e] * g0[e] + b0[e]; y[4 + e] = y[4 + e] * g1[e] + b1[e]; }
         const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
         *reinterpret_cast<u32x4*>(smem + lrow * 1024 + (((ks * 4 + g) ^ li) << 4)) = pk;
       }
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(512) void as512_kernel(As512Params p) {
     for (int ks = 0; ks < 16; ++ks)
       xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rp * 32 + rt * 16 + li) * 1024 + (((ks * 4 + g) ^ li) << 4));
   u32x4 yv[P_STORES ? P_STORES : 1];
-  if constexpr (ASRC == A5_SRC_LN) {
+  if constexpr (ASRC == A5_SRC_LN && !XH) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int r = wave + 8 * i;                      // (tid + 512 i) >> 6
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(512) void as512_kernel(As512Params p) {
   // (compiler fence: the counted waits below assume this ISSUE order -- without it hipcc moved 12 of the 16 y stores in front
   //  of the weight loads, and the first group's wait let chunk 1 be read before its last pieces had landed)
   asm volatile("" ::: "memory");
-  if constexpr (ASRC == A5_SRC_LN) {
+  if constexpr (ASRC == A5_SRC_LN && !XH) {
     // y leaves in whole rows (1 KB per wave instruction), BEHIND the first weight chunks
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -543,12 +551,12 @@ int as512_nsplit(int T, int N) {
   return ns;
 }
 
-template <int ASRC, int EPI>
+template <int ASRC, int EPI, bool XH = false>
 int launch_as512(As512Params& p, hipStream_t st) {
   static bool done[MFP_MAX_DEVICES] = {};
   bool& attr = done[mfp_device_slot()];
   if (!attr) {
-    if (int rc = set_lds(as512_kernel<ASRC, EPI>, A5_LDS, "as512")) return rc;
+    if (int rc = set_lds(as512_kernel<ASRC, EPI, XH>, A5_LDS, "as512")) return rc;
     attr = true;
   }
   const int ns = as512_nsplit(p.T, p.N);
@@ -556,7 +564,7 @@ int launch_as512(As512Params& p, hipStream_t st) {
 #if D5_TRACE
   p.trace = g_d5_trace;
 #endif
-  hipLaunchKernelGGL((as512_kernel<ASRC, EPI>), dim3((p.T + A5_ROWS - 1) / A5_ROWS, ns), dim3(512), A5_LDS, st, p);
+  hipLaunchKernelGGL((as512_kernel<ASRC, EPI, XH>), dim3((p.T + A5_ROWS - 1) / A5_ROWS, ns), dim3(512), A5_LDS, st, p);
   return MFP_OK;
 }
 
@@ -580,9 +588,8 @@ bool al16(const void* q) { return ((uintptr_t)q % 16) == 0; }
 
 }  // namespace
 
-extern "C" int mfp_ln_dense_d512(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
-                                 float* mean, float* rstd, void* out, int32_t T, int32_t N, int32_t relu, float eps,
-                                 mfp_stream_t stream) {
+static int ln_dense_d512_impl(bool xhat, const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
+                              float* mean, float* rstd, void* out, int32_t T, int32_t N, int32_t relu, float eps, mfp_stream_t stream) {
   MFP_CHECK_ARG(x && gamma && beta && W && y && mean && rstd && out);
   MFP_CHECK_ARG(T > 0 && T <= (1 << 20) && N > 0 && N % 128 == 0 && N <= 8192 && eps > 0.f && (long long)T * N * 2 < 0x40000000LL);
   MFP_CHECK_ARG(al16(x) && al16(gamma) && al16(beta) && al16(W) && al16(y) && al16(out) && (bias == nullptr || al16(bias)));
@@ -592,11 +599,25 @@ extern "C" int mfp_ln_dense_d512(const float* x, const float* gamma, const float
   p.y = reinterpret_cast<unsigned short*>(y); p.mean = mean; p.rstd = rstd;
   p.out = reinterpret_cast<unsigned short*>(out); p.ldo = N;
   p.T = T; p.N = N; p.eps = eps;
-  const int rc = relu ? launch_as512<A5_SRC_LN, A5_EPI_RELU>(p, reinterpret_cast<hipStream_t>(stream))
-                      : launch_as512<A5_SRC_LN, A5_EPI_BIAS>(p, reinterpret_cast<hipStream_t>(stream));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rc = xhat ? (relu ? launch_as512<A5_SRC_LN, A5_EPI_RELU, true>(p, st) : launch_as512<A5_SRC_LN, A5_EPI_BIAS, true>(p, st))
+                      : (relu ? launch_as512<A5_SRC_LN, A5_EPI_RELU>(p, st) : launch_as512<A5_SRC_LN, A5_EPI_BIAS>(p, st));
   if (rc) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
+}
+
+extern "C" int mfp_ln_dense_d512(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
+                                 float* mean, float* rstd, void* out, int32_t T, int32_t N, int32_t relu, float eps,
+                                 mfp_stream_t stream) {
+  return ln_dense_d512_impl(false, x, gamma, beta, W, bias, y, mean, rstd, out, T, N, relu, eps, stream);
+}
+
+// The same launch leaving x-hat = (x - mean) rstd (bf16) in the place of y = LN(x) (see mfp_block_fwd_xhat)
+extern "C" int mfp_ln_dense_d512_xhat(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* xhat,
+                                      float* mean, float* rstd, void* out, int32_t T, int32_t N, int32_t relu, float eps,
+                                      mfp_stream_t stream) {
+  return ln_dense_d512_impl(true, x, gamma, beta, W, bias, xhat, mean, rstd, out, T, N, relu, eps, stream);
 }
 
 extern "C" int mfp_dense_relumask_d512(const void* A, const void* W, const void* aux, void* out, int32_t T, int32_t N,

@@ -78,7 +78,9 @@ static int ln_bwd_rows(int T) {
 // bias gradient) as a third partial vector -- saving a full re-read of dx and two launches.
 // TRES = type of the residual gradient stream (dres in, dx out): float, or bf16 (unsigned short) when the step carries
 // the residual gradient in the compute dtype (mfp_layernorm_bwd_res16: 1 KB per element and layer less).
-template <typename TDY, int NVEC, typename TRES = float, int LN_BWD_ROWS = 32>
+// XH: `x` holds x-hat = (x - mean) rstd in bf16 (the stash of mfp_ln_dense_d512_xhat / mfp_block_fwd_xhat) -- 2 instead of 4 bytes
+// per element read, mean unused (mfp_layernorm_bwd_xhat).
+template <typename TDY, int NVEC, typename TRES = float, int LN_BWD_ROWS = 32, bool XH = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
                                                      const float* __restrict__ x,
                                                      const float* __restrict__ gamma,
@@ -111,15 +113,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
   };
   auto load_row = [&](int row, RowIn& in) {
     const float* xr = x + (long long)row * D;
+    const unsigned short* xhr = reinterpret_cast<const unsigned short*>(x) + (long long)row * D;
     const TDY* dyr = dy + (long long)row * D;
     const TRES* drr = dres ? dres + (long long)row * D : nullptr;
-    in.mu = mean[row];
+    in.mu = XH ? 0.f : mean[row];
     in.rs = rstd[row];
 #pragma unroll
     for (int i = 0; i < NVEC; ++i) {
       const int c = lane * 4 + i * 256;
       if (c >= D) continue;
-      in.xv[i] = *reinterpret_cast<const float4*>(xr + c);
+      if constexpr (XH) {
+        const u32x2 t = *reinterpret_cast<const u32x2*>(xhr + c);
+        in.xv[i] = make_float4(__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xFFFF0000u), __uint_as_float(t[1] << 16),
+                               __uint_as_float(t[1] & 0xFFFF0000u));
+      } else {
+        in.xv[i] = *reinterpret_cast<const float4*>(xr + c);
+      }
       if constexpr (sizeof(TDY) == 4) {
         in.dvf[i] = *reinterpret_cast<const float4*>(dyr + c);
       } else {
@@ -160,8 +169,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         d0 = bf16_to_f32((unsigned short)(t0 & 0xffff)); d1 = bf16_to_f32((unsigned short)(t0 >> 16));
         d2 = bf16_to_f32((unsigned short)(t1 & 0xffff)); d3 = bf16_to_f32((unsigned short)(t1 >> 16));
       }
-      xh[j] = (xv.x - mu) * rs; xh[j + 1] = (xv.y - mu) * rs;
-      xh[j + 2] = (xv.z - mu) * rs; xh[j + 3] = (xv.w - mu) * rs;
+      if constexpr (XH) {
+        xh[j] = xv.x; xh[j + 1] = xv.y; xh[j + 2] = xv.z; xh[j + 3] = xv.w;
+      } else {
+        xh[j] = (xv.x - mu) * rs; xh[j + 1] = (xv.y - mu) * rs;
+        xh[j + 2] = (xv.z - mu) * rs; xh[j + 3] = (xv.w - mu) * rs;
+      }
       dg[j] += d0 * xh[j]; dg[j + 1] += d1 * xh[j + 1]; dg[j + 2] += d2 * xh[j + 2]; dg[j + 3] += d3 * xh[j + 3];
       db[j] += d0; db[j + 1] += d1; db[j + 2] += d2; db[j + 3] += d3;
       gy[j] = d0 * g.x; gy[j + 1] = d1 * g.y; gy[j + 2] = d2 * g.z; gy[j + 3] = d3 * g.w;
@@ -268,12 +281,12 @@ extern "C" size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D) {
   return nblk * 3 * D * sizeof(float);
 }
 
-template <typename TRES>
+template <typename TRES, bool XH = false>
 static int ln_bwd_impl(const char* who, const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const TRES* dres, TRES* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                        int32_t T, int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p, uint64_t seed,
                        uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
-  MFP_CHECK_ARG(dy && x && gamma && mean && rstd && dx && (dgamma != nullptr) == (dbeta != nullptr));
+  MFP_CHECK_ARG(dy && x && gamma && (XH || mean) && rstd && dx && (dgamma != nullptr) == (dbeta != nullptr));
   MFP_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024);
   MFP_CHECK_ARG((ddrop == nullptr) == (drop_colsum == nullptr) && drop_p >= 0.f && drop_p < 1.f);
   if (!workspace || workspace_bytes < mfp_layernorm_bwd_workspace_bytes(T, D)) {
@@ -286,7 +299,7 @@ static int ln_bwd_impl(const char* who, const void* dy, const float* x, const fl
   float* part = reinterpret_cast<float*>(workspace);
   MFP_CHECK_ARG(dy_dtype == MFP_F32 || dy_dtype == MFP_BF16);
   const int nvec = (D + 255) / 256;
-#define LN_BWD_(TT, NV, R) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV, TRES, R>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D, (TT*)ddrop, drop_p, seed, offset, step_ptr)
+#define LN_BWD_(TT, NV, R) hipLaunchKernelGGL((ln_bwd_kernel<TT, NV, TRES, R, XH>), dim3(nblk), dim3(256), 0, st, (const TT*)dy, x, gamma, mean, rstd, dres, dx, part, T, D, (TT*)ddrop, drop_p, seed, offset, step_ptr)
 #define LN_BWD(TT, NV) do { if (rows == 16) LN_BWD_(TT, NV, 16); else LN_BWD_(TT, NV, 32); } while (0)
   if (dy_dtype == MFP_F32) {
     if (nvec == 1) LN_BWD(float, 1); else if (nvec == 2) LN_BWD(float, 2); else LN_BWD(float, 4);
@@ -320,6 +333,15 @@ extern "C" int mfp_layernorm_bwd_res16(const void* dy, const float* x, const flo
   return ln_bwd_impl<unsigned short>("mfp_layernorm_bwd_res16", dy, x, gamma, mean, rstd, reinterpret_cast<const unsigned short*>(dres),
                                      reinterpret_cast<unsigned short*>(dx), dgamma, dbeta, workspace, workspace_bytes, T, D, dy_dtype,
                                      ddrop, drop_colsum, drop_p, seed, offset, step_ptr, stream);
+}
+
+extern "C" int mfp_layernorm_bwd_xhat(const void* dy, const void* xhat, const float* gamma, const float* rstd, const void* dres, void* dx,
+                                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int32_t T, int32_t D,
+                                      int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p, uint64_t seed, uint64_t offset,
+                                      const int32_t* step_ptr, mfp_stream_t stream) {
+  return ln_bwd_impl<unsigned short, true>("mfp_layernorm_bwd_xhat", dy, reinterpret_cast<const float*>(xhat), gamma, nullptr, rstd,
+                                           reinterpret_cast<const unsigned short*>(dres), reinterpret_cast<unsigned short*>(dx), dgamma, dbeta,
+                                           workspace, workspace_bytes, T, D, dy_dtype, ddrop, drop_colsum, drop_p, seed, offset, step_ptr, stream);
 }
 
 extern "C" int32_t mfp_layernorm_bwd_partial_rows(int32_t T) { const int rows = ln_bwd_rows(T); return (T + rows - 1) / rows; }

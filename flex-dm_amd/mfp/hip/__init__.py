@@ -103,6 +103,7 @@ SIGNATURES = {
     "mfp_block_fwd_xhat": (c_int32, [c_void_p] * 27 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_block_infer": (c_int32, [c_void_p] * 17 + [c_int32] * 4 + [c_float, c_void_p]),
     "mfp_ln_dense_d512": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "mfp_ln_dense_d512_xhat": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_float, c_void_p]),
     "mfp_dense_relumask_d512": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_void_p]),
     "mfp_dense_n512_res": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_dense_n512": (c_int32, [c_void_p] * 3 + [c_int32, c_int32, c_void_p]),
@@ -121,6 +122,8 @@ SIGNATURES = {
                                     c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_layernorm_bwd_res16": (c_int32, [c_void_p] * 10 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                           c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "mfp_layernorm_bwd_xhat": (c_int32, [c_void_p] * 9 + [c_size_t, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                         c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "mfp_layernorm_bwd_partial_rows": (c_int32, [c_int32]),
     "mfp_reduce_partials": (c_int32, [c_void_p] * 4 + [c_int64, c_int64, c_int32, c_int64, c_int64, c_void_p]),

@@ -56,7 +56,7 @@ def _xhat_ok(ctx) -> bool:
     one of these missing still works: the stand-alone LayerNorm backward reads x, and y is rebuilt from x-hat for a weight
     gradient outside the deferred reduction.)"""
     return (XHAT_STASH and MLP_BWD_LN and ATTN_BWD_LN and WGRAD_GROUP and ctx.wgrad_pending is not None and _res16_ok(ctx)
-            and ctx.store.layout.D == 256)
+            and ctx.store.layout.D in (256, 512))
 # the gradient of the residual stream (what one block's backward hands to the next) in bf16 instead of f32 on the bf16
 # train step: every LayerNorm backward then reads and writes 0.5 KB instead of 1 KB per element for it.  autograd sees
 # stride-0 placeholders of the activations' dtype and shape; the real gradient travels in StepCtx.res_grad.  ON by
@@ -465,10 +465,12 @@ class BlockFn(torch.autograd.Function):
             y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = saved      # (xhat: y1 / y2 hold x-hat)
             ctx.tail["x_c"] = (x2, x2_c) if x2_c is not None else None
             fctx.ctx, fctx.i = ctx, i
-            fctx.xhat = xhat
+            fctx.xhat = (xhat, xhat)
             fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
             return x2
         if _fused512_ok(ctx, D):
+            xhat5 = fctx.needs_input_grad[0] and _xhat_ok(ctx)      # (the LN + Dense launches of csrc/block_d512.hip stash x-hat)
+            xh1_5 = xh2_5 = False
             # d_model 512: LN1 + Q|K|V | attention | output projection + dropout + residual | LN2 + FFN1 + ReLU | FFN2 + dropout +
             # residual = five launches (csrc/block_d512.hip); the last block also leaves the heads' bf16 operand.  fp8 mode: the
             # two LN + Dense launches are ln_fwd + the MX block-scaled product instead (csrc/gemm_fp8.hip)
@@ -476,7 +478,8 @@ class BlockFn(torch.autograd.Function):
                 wq = (_w8_as_bf16(st, p + "attn/dense_query/kernel", 3 * D) if st.fp8 and FP8_WEIGHTS_ONLY and "qkv" in FP8_PRODUCTS
                       else st.cw(p + "attn/dense_query/kernel", rows=3 * D))
                 qkv, y1, mean1, rstd1 = ops.ln_dense_d512(x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), wq,
-                                                          st.span(st.w, p + "attn/dense_query/bias", 3 * D), 3 * D)
+                                                          st.span(st.w, p + "attn/dense_query/bias", 3 * D), 3 * D, xhat_stash=xhat5)
+                xh1_5 = xhat5
             else:
                 qkv, y1, mean1, rstd1 = _ln_dense(ctx, x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"),
                                                   st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
@@ -489,7 +492,8 @@ class BlockFn(torch.autograd.Function):
                 w1 = (_w8_as_bf16(st, p + "mlp/dense_0/kernel", 2 * D) if st.fp8 and FP8_WEIGHTS_ONLY and "ffn1" in FP8_PRODUCTS
                       else st.cw(p + "mlp/dense_0/kernel"))
                 h, y2, mean2, rstd2 = ops.ln_dense_d512(x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"), w1,
-                                                        st.weight(p + "mlp/dense_0/bias"), 2 * D, relu=True)
+                                                        st.weight(p + "mlp/dense_0/bias"), 2 * D, relu=True, xhat_stash=xhat5)
+                xh2_5 = xhat5
             else:
                 h, y2, mean2, rstd2 = _ln_dense(ctx, x1, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
                                                 st.cw(p + "mlp/dense_0/kernel"), T, 2 * D, D, st.weight(p + "mlp/dense_0/bias"),
@@ -500,6 +504,7 @@ class BlockFn(torch.autograd.Function):
                                     (ctx.p, ctx.seed, 2 * i + 2), ctx.step_ptr, out_bf16=x2_c)
             ctx.tail["x_c"] = (x2, x2_c) if x2_c is not None else None
             fctx.ctx, fctx.i = ctx, i
+            fctx.xhat = (xh1_5, xh2_5)
             fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
             return x2
         if ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T):
@@ -552,7 +557,7 @@ class BlockFn(torch.autograd.Function):
         T, B, S, cdt = ctx.T, ctx.B, ctx.S, ctx.cdt
         p = "blocks/seq2seq_%d/" % i
         x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = fctx.saved
-        xhat = getattr(fctx, "xhat", False)      # y1 / y2 hold x-hat = (x - mean) rstd (mfp_block_fwd_xhat)
+        xhat1, xhat2 = getattr(fctx, "xhat", (False, False))      # y1 / y2 hold x-hat = (x - mean) rstd (mfp_block_fwd_xhat, mfp_ln_dense_d512_xhat)
         r16 = ctx.res_grad is not None      # the residual gradient arrives in bf16 through the context (RES_GRAD_BF16)
         if r16:
             dx2, ctx.res_grad = ctx.res_grad, None
@@ -560,16 +565,20 @@ class BlockFn(torch.autograd.Function):
             dx2 = dx2.contiguous()
         sk = ops.wgrad_splitk
         grouped = WGRAD_GROUP and cdt == torch.bfloat16
-        xh1, xh2 = (y1, y2) if xhat else (None, None)      # what the LayerNorm-backward epilogues read
+        # what the LayerNorm backward reads (the bf16 residual-gradient stream's kernels only)
+        xh1, xh2 = (y1 if xhat1 and r16 else None), (y2 if xhat2 and r16 else None)
         na1 = na2 = None
-        if xhat:
+        if xhat1 or xhat2:
             if grouped and ctx.wgrad_pending is not None:
                 # x-hat operands: the deferred reduction writes gamma[n] (A^T x-hat)[m][n] + beta[n] colsum[m]  (gamma | beta
                 # are neighbours in the flat parameter buffer)
-                na1, na2 = st.span(st.w, p + "norm1/gamma", 2 * D), st.span(st.w, p + "norm2/gamma", 2 * D)
+                na1 = st.span(st.w, p + "norm1/gamma", 2 * D) if xhat1 else None
+                na2 = st.span(st.w, p + "norm2/gamma", 2 * D) if xhat2 else None
             else:      # (a weight gradient outside the deferred reduction: rebuild the LayerNorm outputs)
-                y1 = (y1.float() * st.weight(p + "norm1/gamma") + st.weight(p + "norm1/beta")).to(cdt)
-                y2 = (y2.float() * st.weight(p + "norm2/gamma") + st.weight(p + "norm2/beta")).to(cdt)
+                if xhat1:
+                    y1 = (y1.float() * st.weight(p + "norm1/gamma") + st.weight(p + "norm1/beta")).to(cdt)
+                if xhat2:
+                    y2 = (y2.float() * st.weight(p + "norm2/gamma") + st.weight(p + "norm2/beta")).to(cdt)
         # ---- MLP: x2 = x1 + drop(h W2 + b2)
         d_o2 = ctx.handoff.pop(i, None)   # produced by the LN1 backward of block i+1 (fused)
         if d_o2 is None:
@@ -611,7 +620,7 @@ class BlockFn(torch.autograd.Function):
             dx1, d_o1 = ops.layernorm_bwd(dy2, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
                                           st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
                                           drop=(st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1,
-                                                ctx.step_ptr), jobs=ctx.ln_jobs)
+                                                ctx.step_ptr), jobs=ctx.ln_jobs, xhat=xh2)
         # ---- attention: x1 = x + drop(a Wo + bo)
         wt = st.cwt(p + "attn/combine_heads/kernel")
         wtq = st.cwt(p + "attn/dense_query/kernel")    # [D][3D]
@@ -681,11 +690,11 @@ class BlockFn(torch.autograd.Function):
             dx, nxt = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
                                         st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"),
                                         drop=(st.grad(pp + "mlp/dense_1/bias"), ctx.p, ctx.seed, 2 * (i - 1) + 2,
-                                              ctx.step_ptr), jobs=ctx.ln_jobs)
+                                              ctx.step_ptr), jobs=ctx.ln_jobs, xhat=xh1)
             ctx.handoff[i - 1] = nxt
         elif r16:      # block 0: dx IS the compute-dtype gradient the encoder's weight-gradient products read
             dx = ops.layernorm_bwd(dy1, x, st.weight(p + "norm1/gamma"), mean1, rstd1, dx1,
-                                   st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), jobs=ctx.ln_jobs)
+                                   st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), jobs=ctx.ln_jobs, xhat=xh1)
             ctx.dh_c = dx
         else:
             if cdt == torch.bfloat16:

@@ -454,8 +454,9 @@ def block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1,
 
 
 # ---------------------------------------------------------------- d_model 512 (csrc/block_d512.hip)
-def ln_dense_d512(x, gamma, beta, W, bias, N: int, relu: bool = False):
-    """out = (relu?)(LN(x) W^T + bias) in one launch, d_model 512 (see mfp_ln_dense_d512).  Returns (out, y, mean, rstd)."""
+def ln_dense_d512(x, gamma, beta, W, bias, N: int, relu: bool = False, xhat_stash: bool = False):
+    """out = (relu?)(LN(x) W^T + bias) in one launch, d_model 512 (see mfp_ln_dense_d512).  Returns (out, y, mean, rstd);
+    ``xhat_stash``: y holds x-hat = (x - mean) rstd instead of LN(x) (mfp_ln_dense_d512_xhat)."""
     lib = load()
     T, D = x.shape
     assert D == 512 and x.dtype == torch.float32 and W.dtype == torch.bfloat16
@@ -465,7 +466,7 @@ def ln_dense_d512(x, gamma, beta, W, bias, N: int, relu: bool = False):
     mean = torch.empty((T,), dtype=torch.float32, device=dev)
     rstd = torch.empty((T,), dtype=torch.float32, device=dev)
     with _timed("as512_kernel", 2 * T * D * N, T * (D * 4 + D * 2 + N * 2) + N * D * 2):
-        check(lib.mfp_ln_dense_d512(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(W), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd),
+        check((lib.mfp_ln_dense_d512_xhat if xhat_stash else lib.mfp_ln_dense_d512)(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(W), _ptr(bias), _ptr(y), _ptr(mean), _ptr(rstd),
                                     _ptr(out), T, N, int(relu), LN_EPS, _stream()), "mfp_ln_dense_d512")
     return out, y, mean, rstd
 
@@ -669,7 +670,7 @@ def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, dro
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma: torch.Tensor,
                   dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop=None, defer=None,
-                  jobs: Optional[list] = None):
+                  jobs: Optional[list] = None, xhat: Optional[torch.Tensor] = None):
     """``drop`` = (colsum_out [D], p, seed, offset, step_ptr): also return the dropout-masked,
     compute-dtype copy of dx for the consuming Dense backward (fused mfp_dropout_bwd).
     ``defer(fn, *tensors)``: the parameter-gradient reduction (dgamma, dbeta, colsum -- only the
@@ -677,6 +678,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma
     ``jobs``: instead, append the reduction to this list for ONE batched launch at the end of the
     backward pass (:func:`reduce_partials_batch`)."""
     lib = load()
+    if xhat is not None:      # the bf16 stash (x - mean) rstd instead of x, mean (mfp_layernorm_bwd_xhat; bf16 residual stream only)
+        assert xhat.dtype == torch.bfloat16 and dres is not None and dres.dtype == torch.bfloat16
+        x = xhat
     T, D = x.shape
     # the residual gradient stream (dres in, dx out) is f32, or bf16 when the caller carries it in bf16 (res16)
     res16 = (dres is not None and dres.dtype == torch.bfloat16) or (dx is not None and dx.dtype == torch.bfloat16)
@@ -689,9 +693,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres: Optional[torch.Tensor], dgamma
     # deferred reduction: the partials must outlive this call -> their own buffer, not the shared one
     own_ws = defer is not None or jobs is not None
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if own_ws else workspace(nbytes, x.device)
-    nb = T * D * (_esz(dy) + 4 + (_esz(dx) if dres is not None else 0) + _esz(dx) + (_esz(dy) if drop is not None else 0))
+    nb = T * D * (_esz(dy) + _esz(x) + (_esz(dx) if dres is not None else 0) + _esz(dx) + (_esz(dy) if drop is not None else 0))
     with _timed("ln_bwd_kernel", 0, nb):
-        check((lib.mfp_layernorm_bwd_res16 if res16 else lib.mfp_layernorm_bwd)(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
+        if xhat is not None:
+            check(lib.mfp_layernorm_bwd_xhat(_ptr(dy), _ptr(xhat), _ptr(gamma), _ptr(rstd), _ptr(dres), _ptr(dx),
+                                             _ptr(None if own_ws else dgamma), _ptr(None if own_ws else dbeta), ws.data_ptr(), ws.numel(),
+                                             T, D, dt_code(dy.dtype), _ptr(ddrop), _ptr(colsum), float(p_), int(seed_), int(off_),
+                                             _ptr(sp_), _stream()), "mfp_layernorm_bwd_xhat")
+        else:
+            check((lib.mfp_layernorm_bwd_res16 if res16 else lib.mfp_layernorm_bwd)(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
                                     _ptr(dx), _ptr(None if own_ws else dgamma),
                                     _ptr(None if own_ws else dbeta), ws.data_ptr(), ws.numel(), T, D,
                                     dt_code(dy.dtype), _ptr(ddrop), _ptr(colsum), float(p_), int(seed_), int(off_),

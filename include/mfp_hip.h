@@ -231,6 +231,10 @@ int mfp_block_fwd_xhat(const float* x, const float* gamma, const float* beta, co
  * N % 128 == 0.  Never allocate, never synchronise. */
 int mfp_ln_dense_d512(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* y,
                       float* mean, float* rstd, void* out, int32_t T, int32_t N, int32_t relu, float eps, mfp_stream_t stream);
+/* The same launch leaving x-hat = (x - mean) rstd (bf16) in the place of y (see mfp_block_fwd_xhat, mfp_layernorm_bwd_xhat,
+ * mfp_wgrad_job::n_affine). */
+int mfp_ln_dense_d512_xhat(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* xhat,
+                      float* mean, float* rstd, void* out, int32_t T, int32_t N, int32_t relu, float eps, mfp_stream_t stream);
 int mfp_dense_relumask_d512(const void* A, const void* W, const void* aux, void* out, int32_t T, int32_t N, mfp_stream_t stream);
 int mfp_dense_n512_res(const void* A, const void* W, const float* bias, const float* residual, float* out, void* out_bf16,
                        int32_t T, int32_t K, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
@@ -338,6 +342,12 @@ int mfp_layernorm_bwd_res16(const void* dy, const float* x, const float* gamma, 
                             float* dbeta, void* workspace, size_t workspace_bytes, int32_t T,
                             int32_t D, int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p,
                             uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
+/* mfp_layernorm_bwd_res16 from the bf16 x-hat stash (xhat [T,D] = (x - mean) rstd as mfp_ln_dense_d512_xhat / mfp_block_fwd_xhat
+ * leave it) instead of x and mean: 2 instead of 4 bytes per element read. */
+int mfp_layernorm_bwd_xhat(const void* dy, const void* xhat, const float* gamma, const float* rstd, const void* dres, void* dx,
+                           float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, int32_t T, int32_t D,
+                           int32_t dy_dtype, void* ddrop, float* drop_colsum, float drop_p, uint64_t seed, uint64_t offset,
+                           const int32_t* step_ptr, mfp_stream_t stream);
 size_t mfp_layernorm_bwd_workspace_bytes(int32_t T, int32_t D);
 /* dgamma == dbeta == NULL: mfp_layernorm_bwd leaves the per-workgroup partials
  * [P = ceil(T/32)][3][D] (dgamma | dbeta | colsum(ddrop)) in `workspace` and the caller sums them

@@ -664,6 +664,11 @@ def test_layernorm_bwd_res16(T, D):
                             dx=torch.empty(T, D, dtype=torch.bfloat16, device=DEV))
     dxf = ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, torch.empty(D, device=DEV), torch.empty(D, device=DEV))
     assert (dxn != dxf.to(torch.bfloat16)).float().mean().item() < 1e-5
+    # mfp_layernorm_bwd_xhat: the same from the bf16 stash (x - mean) rstd -- against a double restatement from that stash
+    xh = ((x - mean[:, None]) * rstd[:, None]).to(torch.bfloat16)
+    dgx, dbx, csx = torch.empty(D, device=DEV), torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    dxx, ddx = ops.layernorm_bwd(dy, None, gamma, None, rstd, dres16, dgx, dbx, drop=(csx, 0.1, 7, 3, step), xhat=xh)
+    _check_ln_from_xhat(dy, xh, gamma, rstd, dres16, dxx, ddx, dgx, dbx, csx, 0.1)
     # mfp_dropout_bwd_res16 (bf16 in, bf16 out) == mfp_dropout_bwd on the same values in f32
     c32, c16 = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
     m32 = ops.dropout_bwd(dres16.float(), torch.bfloat16, c32, 0.1, 7, 5, step)
@@ -1511,6 +1516,11 @@ def test_ln_dense_d512(T, N, relu):
     if relu:
         want = torch.relu(want)
     assert_close(out, want, 2e-2, 8e-3, "out vs double (from the kernel's own y)")
+    # mfp_ln_dense_d512_xhat: the y buffer receives x-hat = (x - mean) rstd; the product and the statistics bit for bit
+    out2, xh, mean2, rstd2 = ops.ln_dense_d512(x.to(DEV), gam.to(DEV), bet.to(DEV), W.to(DEV, torch.bfloat16), b.to(DEV), N, relu=relu,
+                                               xhat_stash=True)
+    assert torch.equal(out2, out) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
+    assert_close(xh, (xd - mu[:, None]) * rs[:, None], 1e-2, 8e-3, "x-hat")
 
 
 @pytest.mark.parametrize("T,N", [(256, 1024), (1000, 1024), (16384, 1024), (128, 256)])

@@ -918,7 +918,7 @@ def test_bf16_residual_gradient_stream_vs_f32(B, S, D, L):
             torch.cuda.synchronize()
             ln = [n for n in names if n.startswith("ln_bwd_kernel")]
             import re
-            assert ln and all((re.search(r", (unsigned short|float), \d+>$", n).group(1) == "unsigned short") == r16 for n in ln), (r16, ln)
+            assert ln and all((re.search(r", (unsigned short|float), \d+(, (true|false))?>$", n).group(1) == "unsigned short") == r16 for n in ln), (r16, ln)
             grads.append((model.model.store.grads_state_dict(), holder["sums"].clone()))
     finally:
         functions.RES_GRAD_BF16 = old
