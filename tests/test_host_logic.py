@@ -133,6 +133,15 @@ def test_param_layout_and_state_dict_roundtrip():
     q = L.segments["blocks/seq2seq_0/attn/dense_query/kernel"]
     k = L.segments["blocks/seq2seq_0/attn/dense_key/kernel"]
     assert k.offset == q.offset + 256 * 256
+    # gamma | beta of a LayerNorm layer are neighbours, 16-byte aligned: ONE pointer serves mfp_wgrad_job::n_affine (the x-hat
+    # stash: the Q|K|V / FFN1 weight gradients are corrected by gamma[n] (.) + beta[n] colsum[m] in the split-K reduction)
+    for D_, L_ in ((256, 4), (512, 8)):
+        LL = ModelLayout(ic, D_, L_)
+        for i in range(L_):
+            for ln in ("norm1", "norm2"):
+                g = LL.segments["blocks/seq2seq_%d/%s/gamma" % (i, ln)]
+                b = LL.segments["blocks/seq2seq_%d/%s/beta" % (i, ln)]
+                assert b.offset == g.offset + D_ and g.offset % 4 == 0 and g.size == b.size == D_
     from mfp.models.params import ParamStore
     st = ParamStore(ModelLayout(ic, 64, 1), "cpu", torch.float32, l2=1e-2, seed=3)
     params = np_ref.init_params(ic, 64, 1, seed=-5)
