@@ -406,7 +406,9 @@ __global__ __launch_bounds__(512) void os512_kernel(Os512Params p) {
   // 1 KB per wave (8 rows each), W: 4 pieces.  The source slot of a lane is its destination slot ^ swizzle(row); a piece's rows
   // are 8 i + (lane >> 3) behind a multiple of 16, so swizzle = 4 (i & 1) + (lane >> 4): piece i differs from piece 0 by one XOR.
   const unsigned int sl0 = (unsigned int)(((lane & 7) ^ (lane >> 4)) << 4);
-  const unsigned int a_off0 = (unsigned int)(row0 + wave * 16 + (lane >> 3)) * (unsigned int)(p.lda * 2) + sl0;
+  // (the slot XOR is applied to the slot, not to the whole offset: an A row need not be a multiple of 128 bytes long --
+  //  mfp_dense_n512_lda)
+  const unsigned int a_row0 = (unsigned int)(row0 + wave * 16 + (lane >> 3)) * (unsigned int)(p.lda * 2);
   const unsigned int w_off0 = (unsigned int)(n0 + wave * 32 + (lane >> 3)) * kb2 + sl0;
   const int nst = p.K >> 6;
   auto sload = [&](int s, int buf) {
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(512) void os512_kernel(Os512Params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_u8*)(base + wave * 2048 + i * 1024), 16,
-                                               ((a_off0 ^ ((i & 1) << 6)) + (unsigned int)i * 8u * (unsigned int)(p.lda * 2)) + oob, so, 0, 0);
+                                               (a_row0 + (sl0 ^ ((i & 1) << 6)) + (unsigned int)i * 8u * (unsigned int)(p.lda * 2)) + oob, so, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_u8*)(base + O5_A_B + wave * 4096 + i * 1024), 16,
@@ -661,6 +663,25 @@ extern "C" int mfp_dense_n512(const void* A, const void* W, void* out, int32_t T
   MFP_CHECK_ARG(al16(A) && al16(W) && al16(out));
   Os512Params p = {};
   p.A = reinterpret_cast<const unsigned short*>(A); p.lda = K; p.K = K;
+  p.W = reinterpret_cast<const unsigned short*>(W);
+  p.outb = reinterpret_cast<unsigned short*>(out);
+  p.T = T;
+  if (int rc = launch_os512<O5_EPI_BF16, false>(p, reinterpret_cast<hipStream_t>(stream))) return rc;
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+// The same product from an A whose rows are `lda` (<= K) elements apart and whose columns lda .. K - 1 do not exist: the k-range
+// is rounded up to the 64 the stages move, the weight's columns >= lda MUST be zero (what the stage reads past a row's end is
+// the head of the next row -- finite values -- or, behind the last row, zeros from the bounds check).  The decoder heads' input
+// gradient at d_model 512: A = d(logits) [T][U], W = the transposed heads [512][U rounded up to 128] (decoder.py:39-43).
+extern "C" int mfp_dense_n512_lda(const void* A, int32_t lda, const void* W, void* out, int32_t T, int32_t K, mfp_stream_t stream) {
+  MFP_CHECK_ARG(A && W && out);
+  MFP_CHECK_ARG(T > 0 && T <= (1 << 19) && K >= 128 && K % 64 == 0 && K <= 8192 && (long long)T * K * 2 < 0x40000000LL);
+  MFP_CHECK_ARG(lda > K - 128 && lda <= K && lda % 8 == 0);
+  MFP_CHECK_ARG(al16(A) && al16(W) && al16(out));
+  Os512Params p = {};
+  p.A = reinterpret_cast<const unsigned short*>(A); p.lda = lda; p.K = K;
   p.W = reinterpret_cast<const unsigned short*>(W);
   p.outb = reinterpret_cast<unsigned short*>(out);
   p.T = T;

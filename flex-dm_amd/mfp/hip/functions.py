@@ -767,6 +767,9 @@ def _heads_bwd(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor, out_dtype=to
             ctx.tail["bias_wgg"].add(last)
             return dh
         return ops.dgrad_rows(dl_c, wt, U)        # activation-stationary (csrc/block_fused.hip)
+    if (D512_FUSE and wt is not None and D == 512 and out_dtype == torch.bfloat16 and dl_c.dtype == torch.bfloat16 and dl_c.is_contiguous()
+            and T <= (1 << 19)):
+        return ops.dense_n512_lda(dl_c, wt)      # 128 x 256 output tiles (csrc/block_d512.hip) on the transposed, zero-padded heads
     dh = ops.gemm(dl_c, st.cw("decoder/decoder_%s/kernel" % first, rows=U), T, D, U, a_kmajor=True,
                   b_kmajor=False, out_dtype=out_dtype)
     return dh

@@ -507,6 +507,19 @@ def dense_n512(A, W):
     return out
 
 
+def dense_n512_lda(A, W):
+    """out bf16 [T, 512] = A W[:, :U]^T for A bf16 [T, U] and W bf16 [512, K], K = U rounded up (W's columns >= U are zero):
+    see mfp_dense_n512_lda."""
+    lib = load()
+    T, U = A.shape
+    K = W.shape[1]
+    assert A.dtype == torch.bfloat16 and A.is_contiguous() and W.shape[0] == 512 and W.is_contiguous() and K - 128 < U <= K
+    out = torch.empty((T, 512), dtype=torch.bfloat16, device=A.device)
+    with _timed("os512_kernel", 2 * T * K * 512, T * (U * 2 + 512 * 2) + 512 * K * 2):
+        check(lib.mfp_dense_n512_lda(_ptr(A), U, _ptr(W), _ptr(out), T, K, _stream()), "mfp_dense_n512_lda")
+    return out
+
+
 def block_infer(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1, W2, b2, B: int, S: int, H: int):
     """A whole DeepSVG block forward in ONE launch with nothing saved for a backward pass (see mfp_block_infer): the
     inference callers' form (``MFP.__call__(training=False)``, ``iterative_decode``, eval.py).  Returns x2."""

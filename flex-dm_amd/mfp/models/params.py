@@ -217,7 +217,7 @@ class ParamStore:
             # concatenated decoder heads [Upad][D] -> [D][Upad rounded up to 128] (zero pad columns), behind the end of
             # the buffer: the activation-stationary input gradient of the heads (csrc/block_fused.hip)
             self._heads_t = None
-            if layout.D == 256:
+            if layout.D in (256, 512):      # (d_model 512: csrc/block_d512.hip, mfp_dense_n512_lda)
                 ldw = (layout.Upad + 127) // 128 * 128
                 segs.append((layout.heads_start, layout.Upad, layout.D, n, ldw))
                 self._heads_t = (n, ldw)

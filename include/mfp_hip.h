@@ -240,6 +240,9 @@ int mfp_dense_n512_res(const void* A, const void* W, const float* bias, const fl
                        int32_t T, int32_t K, float dropout_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr,
                        mfp_stream_t stream);
 int mfp_dense_n512(const void* A, const void* W, void* out, int32_t T, int32_t K, mfp_stream_t stream);
+/* mfp_dense_n512 for an A with row stride lda in (K - 128, K]: its columns lda .. K - 1 do not exist, W's columns >= lda must be
+ * zero.  The decoder heads' input gradient at d_model 512 (A = d(logits) [T][U], W = the transposed heads zero-padded to K). */
+int mfp_dense_n512_lda(const void* A, int32_t lda, const void* W, void* out, int32_t T, int32_t K, mfp_stream_t stream);
 
 /* Inference form of mfp_block_fwd (what MFP.__call__(training=False), iterative_decode and eval.py run: reference
  * models/mfp.py:141-207, eval.py:35-118): the same single launch with nothing saved for a backward pass -- y1, qkv, a, lse,

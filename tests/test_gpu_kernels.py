@@ -1578,6 +1578,22 @@ def test_dense_n512(T, K):
     assert_close(out, A.double() @ W.double().t(), 2e-2, 8e-3, "out vs double")
 
 
+@pytest.mark.parametrize("T,U", [(384, 1384), (16384, 1384), (200, 1400)])
+def test_dense_n512_lda(T, U):
+    """mfp_dense_n512_lda: the decoder heads' input gradient at d_model 512 -- A = d(logits) [T][U] with NO padding columns, W = the
+    transposed heads [512][U rounded up to 128] whose pad columns are zero (decoder.py:39-43 under autodiff) -- against a double
+    reference; the k-range read past a row's end (the head of the next row, zeros behind the last) must not leak."""
+    ops = _ops()
+    K = (U + 127) // 128 * 128
+    g = torch.Generator().manual_seed(810 + T + U)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    A = bf16_round(rn(T, U) * 3.0)                                  # (large next-row values: a leak would show)
+    W = torch.zeros(512, K)
+    W[:, :U] = bf16_round(rn(512, U) * 0.04)
+    out = ops.dense_n512_lda(A.to(DEV, torch.bfloat16), W.to(DEV, torch.bfloat16))
+    assert_close(out, A.double() @ W[:, :U].double().t(), 6e-2, 8e-3, "out vs double")
+
+
 @pytest.mark.parametrize("B,p", [(2, 0.0), (6, 0.1)])
 def test_block_fwd_two_documents_per_tile(B, p):
     """mfp_block_fwd / mfp_block_infer at S = 64 (two documents per 128-row tile: the shape of real Crello / RICO batches,
