@@ -44,7 +44,7 @@ struct AttnBlockParams {
   const unsigned short* W2; const float* b2;           // [256][512] bf16, f32 [256]
   unsigned short* y2; float* mean2; float* rstd2; unsigned short* h; float* x2; unsigned short* x2c;
   unsigned long long offset2;                          // dropout stream of the MLP half
-  int xhat;                                            // 1: the y1 / y2 buffers receive x-hat = (x - mean) rstd (bf16) instead of LN(x) (mfp_block_fwd_xhat)
+  int xhat;                                            // 1: the y1 / y2 buffers receive x-hat = (x - mean) rstd (bf16) instead of LN(x) (mfp_block_fwd_xhat); 2: ... on half-document tiles
   int stash;                                           // 0 = inference form (mfp_block_infer, template flag STASH): y1, qkv, a, lse, y2, h are not written
 };
 
@@ -58,6 +58,9 @@ constexpr int AB_LDS = AB_VEC_OFF + (768 + 3 * 256 + 128) * 4;
 constexpr int AB_VEC2_OFF = AB_LDS;
 constexpr int AB_LDS_MLP = AB_VEC2_OFF + (512 + 3 * 256 + 256) * 4;
 constexpr int AB_F = 512;
+#ifndef AB_RES_AT
+#define AB_RES_AT 13
+#endif
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
@@ -90,9 +93,20 @@ __device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
 // w >> 2) and it visits only that document's 64 keys (rows kb .. kb + 63 of the k / v images): half the score work per head.
 // XHAT (round 5): the y1 / y2 buffers receive x-hat = (x - mean) rstd instead of LN(x) (mfp_block_fwd_xhat).  A template flag,
 // not a runtime one: with both forms in one kernel the training instance spilled a register across the last MLP chunks.
-template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128, bool XHAT = false>
-__global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) {
+// HALF (round 5, second half): TWO workgroups per document, four waves each (one per SIMD: up to 512 registers), for batches
+// with fewer documents than CUs (BASELINE config c4's per-GPU share: 128 documents on 256 CUs).  A workgroup owns 64 query
+// rows: LN1 runs over the whole document, the q / output-projection / MLP chunks over the own rows, the k / v chunks over BOTH
+// halves (the other half's K / V are recomputed, not exchanged: + 1/3 of the Q|K|V products on a pipe that is ~15 % busy; each
+// weight fragment then feeds four products), the attention over the own 64 queries and all 128 keys.  Every value is produced
+// by the same instruction sequence on the same operands as in the one-workgroup form: results are bit-identical to it
+// (tests/test_gpu_kernels.py::test_block_fwd_half).  Per-wave op counts that the counted waits rest on: a weight chunk is 8
+// LDS-DMA pieces per wave instead of 4 (LD); every store loop covers half the rows with half the threads, i.e. the same count.
+template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128, bool XHAT = false, bool HALF = false>
+__global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBlockParams p) {
   static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
+  static_assert(!HALF || (SDOC == 128 && MLP && XHAT && STASH), "half-document tiles: the x-hat training form at S = 128");
+  constexpr int NT = HALF ? 256 : 512;                 // threads
+  constexpr int LD = HALF ? 8 : 4;                     // 1 KB LDS-DMA pieces per wave and weight chunk
   constexpr int NCH = MLP ? 2 * AB_CHUNKS : AB_CHUNKS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Im = smem;                      // Im + t * AB_IMG, t = 0 (q, then a), 1 (k), 2 (v)
@@ -104,15 +118,22 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   float* const Mb = reinterpret_cast<float*>(smem + AB_VEC_OFF + (768 + 3 * 256) * 4);
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rp = wave & 3, nh = wave >> 2;
-  const int doc = blockIdx.x, row0 = doc * AB_ROWS;
+  const int rp = HALF ? (wave & 1) : (wave & 3), nh = HALF ? (wave >> 1) : (wave >> 2);
+  // HALF: the two halves of a document are workgroups b and b + 8 of a group of 16 -- the same XCD (workgroups go round the
+  // eight XCDs), so the second fetch of the document's x rows and of the weights is a hit in that XCD's L2; a trailing partial
+  // group pairs neighbours
+  const int bi = (int)blockIdx.x, bfull = (int)(gridDim.x >> 4) << 4;
+  const int doc = !HALF ? bi : bi < bfull ? (bi >> 4) * 8 + (bi & 7) : (bfull >> 1) + ((bi - bfull) >> 1);
+  const int row0 = doc * AB_ROWS;
+  const int rb = !HALF ? 0 : (bi < bfull ? (bi >> 3) & 1 : (bi - bfull) & 1) * 64;      // first own row of the document (image rows are document rows)
+  const int rbase = rb + rp * 32;                            // this wave's two row tiles: document rows rbase + 16 rt + li
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   // (the step counter and the document's length are read first: their loads must not sit between the counted waits)
   const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
   const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[SDOC == 128 ? doc : 2 * doc]);
   const int nv1 = SDOC == 128 ? 0 : __builtin_amdgcn_readfirstlane(p.nvalid[2 * doc + 1]);
 
-  const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(doc * 8 + wave) * 64;
+  const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(blockIdx.x * (HALF ? 4 : 8) + wave) * 64;
   AB_TR(0);
   const unsigned int xbytes = (unsigned int)p.T * (AB_D * 4);
   // inference form: the saved tensors are zero-sized buffers -- their stores are issued all the same (the counted waits
@@ -132,10 +153,11 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   // ---- weight chunk c = 4 p + t.  t = 0, 1, 2 (q, k, v): Wqkv rows t * 256 + 64 p .. + 63, all 256 k -> image [64][512 B],
   // slot ^ (row & 15) (2 rows per 1 KB piece).  t = 3 (o): Wo rows 0 .. 255, k = 64 p .. + 63 -> image [256][128 B],
   // slot ^ ((row >> 1) & 7) (8 rows per piece).  Four pieces per wave and chunk.
-  const unsigned int w1off = (unsigned int)((wave * 8 + (lane >> 5)) * 512 + (((lane & 31) ^ ((wave & 1) * 8 + (lane >> 5))) << 4));
+  const unsigned int w1off = HALF ? (unsigned int)((wave * 16 + (lane >> 5)) * 512 + (((lane & 31) ^ (lane >> 5)) << 4))
+                                  : (unsigned int)((wave * 8 + (lane >> 5)) * 512 + (((lane & 31) ^ ((wave & 1) * 8 + (lane >> 5))) << 4));
   auto wload = [&](int c) {
     const int pr = c >> 2, t = c & 3;
-    unsigned char* dst = Ws + ((c + 1) % 3) * AB_WS_B + wave * 4096;
+    unsigned char* dst = Ws + ((c + 1) % 3) * AB_WS_B + wave * (LD * 1024);
     if (MLP && c >= AB_CHUNKS) {
       // MLP chunks (mlp_fused_kernel): c' & 3 = 0, 1: W1 rows q * 128 + 64 j .. + 63, all 256 k -> [64][512 B];
       // c' & 3 = 2, 3: W2 rows 128 j .. + 127, k = q * 128 .. + 127 -> [128][256 B]
@@ -143,27 +165,27 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       if (!ffn2) {
         const int base = (q * 128 + j * 64) * (AB_D * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < LD; ++i)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w1, (lds_u8*)(dst + i * 1024), 16, w1off ^ (i << 5), base + i * 1024, 0, 0);
       } else {
         const int base = (j * 128) * (AB_F * 2) + q * 256;
         // (recomputed per chunk: not a register kept alive across the attention stage, which sits at the limit)
-        const unsigned int w2off = (unsigned int)((wave * 16 + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
+        const unsigned int w2off = (unsigned int)((wave * (LD * 4) + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_u8*)(dst + i * 1024), 16, w2off ^ (i << 6), base + i * 4096, 0, 0);
+        for (int i = 0; i < LD; ++i)      // row wave * 4 LD + 4 i + (lane >> 4): its low four bits are 4 (i & 3) + (lane >> 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, (lds_u8*)(dst + i * 1024), 16, w2off ^ ((i & 3) << 6), base + i * 4096, 0, 0);
       }
       return;
     }
     if (t < 3) {
       const int base = (t * 256 + pr * 64) * (AB_D * 2);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < LD; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wq, (lds_u8*)(dst + i * 1024), 16, w1off ^ (i << 5), base + i * 1024, 0, 0);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + (lane >> 3);
+      for (int i = 0; i < LD; ++i) {
+        const int row = wave * (LD * 8) + i * 8 + (lane >> 3);
         const unsigned int vo = (unsigned int)(row * (AB_D * 2) + (((lane & 7) ^ isw(row)) << 4));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wo, (lds_u8*)(dst + i * 1024), 16, vo, pr * 128, 0, 0);
       }
@@ -171,66 +193,85 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   };
   wload(0);
   wload(1);
-  if (tid < (768 + 3 * 256) / 4) {     // per-column vectors -> LDS
-    const float* src = tid < 192 ? p.bqkv + tid * 4 : tid < 256 ? p.gamma + (tid - 192) * 4
-                     : tid < 320 ? p.beta + (tid - 256) * 4 : p.bo + (tid - 320) * 4;
-    *reinterpret_cast<f32x4*>(smem + AB_VEC_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(src);
-  }
-  if (MLP && tid < (512 + 3 * 256) / 4) {
-    const float* src = tid < 128 ? p.b1 + tid * 4 : tid < 192 ? p.b2 + (tid - 128) * 4
-                     : tid < 256 ? p.gamma2 + (tid - 192) * 4 : p.beta2 + (tid - 256) * 4;
-    *reinterpret_cast<f32x4*>(smem + AB_VEC2_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+  for (int t0 = 0; t0 < 512; t0 += NT) {     // per-column vectors -> LDS
+    const int t4 = t0 + tid;
+    if (t4 < (768 + 3 * 256) / 4) {
+      const float* src = t4 < 192 ? p.bqkv + t4 * 4 : t4 < 256 ? p.gamma + (t4 - 192) * 4
+                       : t4 < 320 ? p.beta + (t4 - 256) * 4 : p.bo + (t4 - 320) * 4;
+      *reinterpret_cast<f32x4*>(smem + AB_VEC_OFF + t4 * 16) = *reinterpret_cast<const f32x4*>(src);
+    }
+    if (MLP && t4 < (512 + 3 * 256) / 4) {
+      const float* src = t4 < 128 ? p.b1 + t4 * 4 : t4 < 192 ? p.b2 + (t4 - 128) * 4
+                       : t4 < 256 ? p.gamma2 + (t4 - 192) * 4 : p.beta2 + (t4 - 256) * 4;
+      *reinterpret_cast<f32x4*>(smem + AB_VEC2_OFF + t4 * 16) = *reinterpret_cast<const f32x4*>(src);
+    }
   }
   // additive key term (exp2 domain); no row past S.  SDOC = 64: key's validity inside ITS document (a wave only visits the
   // 64 keys of its queries' document)
   if (tid < 128) Mb[tid] = (SDOC == 128 ? tid < nv : (tid & 63) < (tid >> 6 ? nv1 : nv)) ? 0.f : -1e9f * LOG2E;
 
-  // ---- LN1 (as qkv_fused_kernel): wave w normalises rows 16 w .. + 15 in the MFMA operand layout
+  // ---- LN1 (as qkv_fused_kernel): wave w normalises rows 16 w .. + 15 in the MFMA operand layout.  HALF: two passes of 16
+  // rows per wave -- the own half's (statistics and x-hat leave for HBM) and the other half's (K / V operands only); every load
+  // of both passes is requested before the first is consumed
   bf16x8 xf[2][8];
+  bf16x8 xo[HALF ? 2 : 1][8];      // HALF: LN1 of the other half's rows rbase ^ 64 + 16 rt + li, operands of the k / v chunks
   {
-    const int lrow = wave * 16 + li, row = row0 + lrow;
-    float v[8][8];
-    float s = 0.f;
+    constexpr int NP = HALF ? 2 : 1;
+    float v[NP][8][8];
+    float s[NP];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const unsigned int vo = (unsigned int)row * (AB_D * 4) + g * 32;
-      const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + ks * 128, 0, 0));
-      const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + ks * 128 + 16, 0, 0));
+    for (int ps = 0; ps < NP; ++ps) {
+      const int row = row0 + (HALF ? (rb ^ (ps * 64)) : 0) + wave * 16 + li;
+      s[ps] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[ks][e] = a[e]; v[ks][4 + e] = b[e]; s += a[e] + b[e]; }
+      for (int ks = 0; ks < 8; ++ks) {
+        const unsigned int vo = (unsigned int)row * (AB_D * 4) + g * 32;
+        const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + ks * 128, 0, 0));
+        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo + ks * 128 + 16, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[ps][ks][e] = a[e]; v[ps][ks][4 + e] = b[e]; s[ps] += a[e] + b[e]; }
+      }
     }
     __syncthreads();      // gamma / beta are in LDS
     AB_TR(1);
-    s += lane_xor16(s);
-    s += lane_xor32(s);
-    const float mu = s * (1.0f / AB_D);
-    float qq = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+    for (int ps = 0; ps < NP; ++ps) {
+      const int lrow = (HALF ? (rb ^ (ps * 64)) : 0) + wave * 16 + li, row = row0 + lrow;
+      float sm_ = s[ps];
+      sm_ += lane_xor16(sm_);
+      sm_ += lane_xor32(sm_);
+      const float mu = sm_ * (1.0f / AB_D);
+      float qq = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[ks][e] -= mu; qq += v[ks][e] * v[ks][e]; }
-    qq += lane_xor16(qq);
-    qq += lane_xor32(qq);
-    const float rs = rsqrtf(qq * (1.0f / AB_D) + p.eps);
-    if (g == 0) { p.mean[row] = mu; p.rstd[row] = rs; }
+      for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int col = ks * 32 + 8 * g;
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gs + col), g1 = *reinterpret_cast<const f32x4*>(Gs + col + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + col), b1 = *reinterpret_cast<const f32x4*>(Bs + col + 4);
-      float y[8];
+        for (int e = 0; e < 8; ++e) { v[ps][ks][e] -= mu; qq += v[ps][ks][e] * v[ps][ks][e]; }
+      qq += lane_xor16(qq);
+      qq += lane_xor32(qq);
+      const float rs = rsqrtf(qq * (1.0f / AB_D) + p.eps);
+      if (ps == 0 && g == 0) { p.mean[row] = mu; p.rstd[row] = rs; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = v[ks][e] * rs;      // x-hat
-      if constexpr (XHAT) {
-        // x-hat stash: straight from the operand layout (a lane's 8 columns = 16 bytes; the four g-lanes of a row cover 64
-        // contiguous bytes), the SAME eight stores per lane as the y rows below issue -- the counted waits see no difference
-        const u32x4 px = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(px, rs_y, (unsigned int)row * (AB_D * 2) + ks * 64 + g * 16, 0, 0);
+      for (int ks = 0; ks < 8; ++ks) {
+        const int col = ks * 32 + 8 * g;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gs + col), g1 = *reinterpret_cast<const f32x4*>(Gs + col + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + col), b1 = *reinterpret_cast<const f32x4*>(Bs + col + 4);
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = v[ps][ks][e] * rs;      // x-hat
+        if constexpr (XHAT) {
+          // x-hat stash: straight from the operand layout (a lane's 8 columns = 16 bytes; the four g-lanes of a row cover 64
+          // contiguous bytes), the SAME eight stores per lane as the y rows below issue -- the counted waits see no difference
+          if (ps == 0) {
+            const u32x4 px = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(px, rs_y, (unsigned int)row * (AB_D * 2) + ks * 64 + g * 16, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] = y[e] * g0[e] + b0[e]; y[4 + e] = y[4 + e] * g1[e] + b1[e]; }
+        const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+        *reinterpret_cast<u32x4*>(smem + lrow * 512 + (((ks * 4 + g) ^ li) << 4)) = pk;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { y[e] = y[e] * g0[e] + b0[e]; y[4 + e] = y[4 + e] * g1[e] + b1[e]; }
-      const u32x4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-      *reinterpret_cast<u32x4*>(smem + lrow * 512 + (((ks * 4 + g) ^ li) << 4)) = pk;
     }
   }
   __syncthreads();
@@ -245,8 +286,11 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rp * 32 + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+    for (int ks = 0; ks < 8; ++ks) {
+      xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rbase + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+      if constexpr (HALF)
+        xo[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + ((rbase ^ 64) + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+    }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();       // chunks 0, 1 are in LDS (first memory operations of the kernel); the LN image has been read
   AB_TR(2);
@@ -259,7 +303,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     const unsigned char* img = Im + (t == 3 ? 0 : t) * AB_IMG;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 512 * i, r = idx >> 3, c16 = idx & 7;
+      const int idx = tid + NT * i, r = rb + (idx >> 3), c16 = idx & 7;      // (HALF: the own 64 rows)
       const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * 128 + ((c16 ^ isw(r)) << 4));
       if (t < 3) __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, (unsigned int)(row0 + r) * (768 * 2) + t * 512 + pr * 128 + c16 * 16, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b128(v, rs_a, (unsigned int)(row0 + r) * (AB_D * 2) + pr * 128 + c16 * 16, 0, 0);
@@ -267,12 +311,28 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
   };
 
   f32x4 acc2[8][2];      // x1 accumulators: column tile T = (ct >> 2) * 8 + nh * 4 + (ct & 3), rows 32 rp + 16 rt + li
+  f32x4 resa[HALF ? 4 : 1][2][2];      // HALF: the x1 epilogue's sixteen residual loads, requested at the head of chunk AB_RES_AT
   const float c2 = p.scale * LOG2E;
 
   auto chunk = [&](auto cc_) {
     constexpr int c = decltype(cc_)::value;
     constexpr int pr = c >> 2, t = c & 3;
     if (c + 2 < NCH) wload(c + 2);
+    if constexpr (HALF && c == AB_RES_AT) {
+      // behind this chunk's weight loads (fenced: the counted waits below assume that order).  Loads return in order, so the
+      // weight chunk requested NEXT (head of chunk c + 1, needed at the end of chunk c + 2) waits for these rows: chunk 13 leaves
+      // it the attention phase of pair 3 (~5 us; the rows take ~5 us to arrive while every CU asks at once)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int hf2 = 0; hf2 < 4; ++hf2)
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const int row = row0 + rbase + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
+            resa[hf2][q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
+          }
+    }
     // stores of finished images, AFTER the weight loads (counted waits): q at the head of k, k at the head of v, v and a
     // at the head of o (behind the barrier that ended the attention of the pair)
     if (t == 1) stash(pr, 0);
@@ -282,15 +342,29 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     if (t < 3) {
       // 64 columns of q / k / v: acc[nt][rt], wave (rp, nh) owns column tiles 2 nh + nt of the chunk
       const unsigned char* wa = wb + ((nh * 2) * 16 + li) * 512;
-      f32x4 acc[2][2];
+      constexpr bool both = HALF && t != 0;      // k / v of the other half's rows too (acco: same products on xo)
+      f32x4 acc[2][2], acco[both ? 2 : 1][2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      bf16x8 wf[2][2];
+      if constexpr (both)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[0]);
+        for (int nt = 0; nt < 2; ++nt) acco[nt][0] = acco[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (HALF: one wave per SIMD, nobody to hide the fragment reads' latency behind, and registers to spare: all sixteen
+      //  fragments of the chunk are requested before the first product -- 0.85 -> us per chunk, profiles/r05_half_trace.txt)
+      constexpr int WFD = HALF ? 8 : 2;
+      bf16x8 wf[WFD][2];
+      if constexpr (HALF) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) wf[ks][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[ks & 3] + (ks >> 2) * 256);
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[0]);
+      }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 1 < 8) {
+        if (!HALF && ks + 1 < 8) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
@@ -298,8 +372,10 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+          for (int rt = 0; rt < 2; ++rt) {
+            acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+            if constexpr (both) acco[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], xo[rt][ks], acco[nt][rt], 0, 0, 0);
+          }
       }
       unsigned char* img = Im + t * AB_IMG;
 #pragma unroll
@@ -307,26 +383,42 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         const f32x4 bb = *reinterpret_cast<const f32x4*>(Bq + t * 256 + pr * 64 + (nh * 2 + nt) * 16 + 4 * g);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          const int row = rp * 32 + rt * 16 + li;
+          const int row = rbase + rt * 16 + li;
           const u32x2 pk = {pack_bf16x2(acc[nt][rt][0] + bb[0], acc[nt][rt][1] + bb[1]), pack_bf16x2(acc[nt][rt][2] + bb[2], acc[nt][rt][3] + bb[3])};
           *reinterpret_cast<u32x2*>(img + row * 128 + ((((nh * 2 + nt) * 2 + (g >> 1)) ^ isw(row)) << 4) + (g & 1) * 8) = pk;
+          if constexpr (both) {      // (row ^ 64: the slot swizzle, bits 1..3 of the row, is unchanged)
+            const u32x2 po = {pack_bf16x2(acco[nt][rt][0] + bb[0], acco[nt][rt][1] + bb[1]), pack_bf16x2(acco[nt][rt][2] + bb[2], acco[nt][rt][3] + bb[3])};
+            *reinterpret_cast<u32x2*>(img + (row ^ 64) * 128 + ((((nh * 2 + nt) * 2 + (g >> 1)) ^ isw(row)) << 4) + (g & 1) * 8) = po;
+          }
         }
       }
     } else {
       // x1 accumulators += a_pair (image 0) Wo[:, 64 pr .. + 63]^T: K = 64, two k-steps
       const unsigned char* ai = Im;
+      bf16x8 wo[HALF ? 2 : 1][HALF ? 8 : 1];      // HALF: every fragment of the chunk up front (see the q / k / v chunks)
+      if constexpr (HALF) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < 8; ++ct) {
+            const int wrow = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + li;
+            wo[ks][ct] = *reinterpret_cast<const bf16x8*>(wb + wrow * 128 + (((ks * 4 + g) ^ isw(wrow)) << 4));
+          }
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 hf[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          const int row = rp * 32 + rt * 16 + li;
+          const int row = rbase + rt * 16 + li;
           hf[rt] = *reinterpret_cast<const bf16x8*>(ai + row * 128 + (((ks * 4 + g) ^ isw(row)) << 4));
         }
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
           const int wrow = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + li;
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + wrow * 128 + (((ks * 4 + g) ^ isw(wrow)) << 4));
+          bf16x8 wf;
+          if constexpr (HALF) wf = wo[ks][ct];
+          else wf = *reinterpret_cast<const bf16x8*>(wb + wrow * 128 + (((ks * 4 + g) ^ isw(wrow)) << 4));
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt)
             acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf[rt], (pr == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[ct][rt], 0, 0, 0);
@@ -342,7 +434,8 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       constexpr int st_prev = c == 0 ? 0 : (tp == 1 || tp == 2) ? 2 : tp == 3 ? 4 : 0;
       constexpr int at_prev = (c >= 1 && tp == 2) ? 2 : 0;
       constexpr int st_this = (t == 1 || t == 2) ? 2 : t == 3 ? 4 : 0;
-      constexpr int allowed = c == 0 ? 14 : st_prev + at_prev + (c + 2 < NCH ? 4 : 0) + st_this;
+      // (HALF: the sixteen residual loads at the head of chunk AB_RES_AT are younger than the loads this chunk and the next wait for)
+      constexpr int allowed = c == 0 ? 10 + LD : st_prev + at_prev + (c + 2 < NCH ? LD : 0) + st_this + ((HALF && (c == AB_RES_AT || c == AB_RES_AT + 1)) ? 16 : 0);
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -351,7 +444,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       const unsigned char* qi = Im;
       const unsigned char* ki = Im + AB_IMG;
       const unsigned char* vi = Im + 2 * AB_IMG;
-      const int qrow = 16 * wave + li;
+      const int qrow = rb + 16 * wave + li;
       constexpr int NKT = SDOC / 16;                                    // key tiles a query sees
       const int kb = SDOC == 128 ? 0 : (wave >> 2) * 64;                // first key row of this wave's queries' document
       const unsigned char* const kid = ki + kb * 128;                   // ((row >> 1) & 7, the slot swizzle, is the same for row + 64)
@@ -360,71 +453,147 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       // (the output tile of a head overwrites this wave's own rows of the q image: nobody else reads these rows -- their q
       //  columns left for HBM at the head of the k chunk)
       unsigned char* ai = Im;
+      if constexpr (HALF) {
+        // One wave per SIMD and registers to spare: ONE pass over the keys (the 32 scores of a head stay in registers: 16 fewer
+        // LDS reads per head on a port this phase keeps > 50 % busy) and both heads of the pair in the same loops (two
+        // independent dependency chains per wave).  Per head the same operations on the same values in the same order as the
+        // two-pass form below: bit-identical.
+        bf16x8 bq[2];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        // (head 0's output goes over the head-0 columns of this wave's q rows; head 1's q columns are still intact)
-        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(qi + qrow * 128 + (((hh * 4 + g) ^ isw(qrow)) << 4));
-        // Two passes over the keys instead of 32 live score registers (the kernel sits at the 256-register limit, a spill
-        // is a scratch access on the in-order memory counter, and the matrix pipe is ~10 % busy): pass 1 = the row
-        // maximum, pass 2 recomputes the scores tile by tile, exponentiates and feeds P V.
-        float m = -INFINITY;
+        for (int hh = 0; hh < 2; ++hh) bq[hh] = *reinterpret_cast<const bf16x8*>(qi + qrow * 128 + (((hh * 4 + g) ^ isw(qrow)) << 4));
+        f32x4 sc[2][NKT];
+        float m[2] = {-INFINITY, -INFINITY};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
           const int krow = kt * 16 + li;
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
-          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
           const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mbq + kt * 16 + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fmaf(sa[r], c2, mb4[r]));
+          for (int hh = 0; hh < 2; ++hh) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq[hh], z, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              sc[hh][kt][r] = __builtin_fmaf(sa[r], c2, mb4[r]);
+              m[hh] = fmaxf(m[hh], sc[hh][kt][r]);
+            }
+          }
         }
-        m = fmaxf(m, lane_xor16(m));
-        m = fmaxf(m, lane_xor32(m));
-        float l = 0.f;
-        f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int u = 0; u < NKT / 2; ++u) {
-          f32x4 pe[2];
+        for (int hh = 0; hh < 2; ++hh) {
+          m[hh] = fmaxf(m[hh], lane_xor16(m[hh]));
+          m[hh] = fmaxf(m[hh], lane_xor32(m[hh]));
+        }
+        float l[2] = {0.f, 0.f};
+        f32x4 oo[2][2];
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const int kt = 2 * u + hf, krow = kt * 16 + li;
+        for (int hh = 0; hh < 2; ++hh) oo[hh][0] = oo[hh][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NKT / 2; ++u)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            f32x4 pe[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                pe[hf][r] = __builtin_amdgcn_exp2f(sc[hh][2 * u + hf][r] - m[hh]);
+                l[hh] += pe[hf][r];
+              }
+            const bf16x8 bp = ab_pack(pe[0], pe[1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const int vrow = 32 * u + 4 * g + (li >> 2);
+              const int P = hh * 8 + dt * 4 + (li & 3);
+              const unsigned char* ptr = vid + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
+              const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+              const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
+              const bf16x8 vt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              oo[hh][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, bp, oo[hh][dt], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float lt = l[hh];
+          lt += lane_xor16(lt);
+          lt += lane_xor32(lt);
+          const float inv = 1.f / lt;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const u32x2 pk = {pack_bf16x2(oo[hh][dt][0] * inv, oo[hh][dt][1] * inv), pack_bf16x2(oo[hh][dt][2] * inv, oo[hh][dt][3] * inv)};
+            *reinterpret_cast<u32x2*>(ai + qrow * 128 + (((hh * 4 + dt * 2 + (g >> 1)) ^ isw(qrow)) << 4) + (g & 1) * 8) = pk;
+          }
+          const float lv = (m[hh] + __builtin_amdgcn_logf(lt)) * LN2;      // natural-log lse
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, lv), rs_l,
+                                                g != 0 ? 0xFFFFFFF0u : (unsigned int)(((doc * p.H + 2 * pr + hh) * AB_ROWS + qrow) * 4), 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          // (head 0's output goes over the head-0 columns of this wave's q rows; head 1's q columns are still intact)
+          const bf16x8 bq = *reinterpret_cast<const bf16x8*>(qi + qrow * 128 + (((hh * 4 + g) ^ isw(qrow)) << 4));
+          // Two passes over the keys instead of 32 live score registers (the kernel sits at the 256-register limit, a spill
+          // is a scratch access on the in-order memory counter, and the matrix pipe is ~10 % busy): pass 1 = the row
+          // maximum, pass 2 recomputes the scores tile by tile, exponentiates and feeds P V.
+          float m = -INFINITY;
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt) {
+            const int krow = kt * 16 + li;
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
             const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mbq + kt * 16 + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              pe[hf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, mb4[r]) - m);
-              l += pe[hf][r];
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, __builtin_fmaf(sa[r], c2, mb4[r]));
+          }
+          m = fmaxf(m, lane_xor16(m));
+          m = fmaxf(m, lane_xor32(m));
+          float l = 0.f;
+          f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int u = 0; u < NKT / 2; ++u) {
+            f32x4 pe[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int kt = 2 * u + hf, krow = kt * 16 + li;
+              const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
+              const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+              const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq, z, 0, 0, 0);
+              const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mbq + kt * 16 + 4 * g);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                pe[hf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, mb4[r]) - m);
+                l += pe[hf][r];
+              }
+            }
+            const bf16x8 bp = ab_pack(pe[0], pe[1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              // V^T fragment: for column hh * 32 + 16 dt + li the key rows {32 u + 4 g + j} and {32 u + 16 + 4 g + j}
+              const int vrow = 32 * u + 4 * g + (li >> 2);
+              const int P = hh * 8 + dt * 4 + (li & 3);                 // 8-byte piece of the 128-byte row
+              const unsigned char* ptr = vid + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
+              const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
+              // (row + 16: bits 1..3 of the row, hence the swizzle, are unchanged)
+              const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
+              const bf16x8 vt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              oo[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, bp, oo[dt], 0, 0, 0);
             }
           }
-          const bf16x8 bp = ab_pack(pe[0], pe[1]);
+          l += lane_xor16(l);
+          l += lane_xor32(l);
+          const float inv = 1.f / l;
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            // V^T fragment: for column hh * 32 + 16 dt + li the key rows {32 u + 4 g + j} and {32 u + 16 + 4 g + j}
-            const int vrow = 32 * u + 4 * g + (li >> 2);
-            const int P = hh * 8 + dt * 4 + (li & 3);                 // 8-byte piece of the 128-byte row
-            const unsigned char* ptr = vid + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
-            // (row + 16: bits 1..3 of the row, hence the swizzle, are unchanged)
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
-            const bf16x8 vt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            oo[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, bp, oo[dt], 0, 0, 0);
+            const u32x2 pk = {pack_bf16x2(oo[dt][0] * inv, oo[dt][1] * inv), pack_bf16x2(oo[dt][2] * inv, oo[dt][3] * inv)};
+            *reinterpret_cast<u32x2*>(ai + qrow * 128 + (((hh * 4 + dt * 2 + (g >> 1)) ^ isw(qrow)) << 4) + (g & 1) * 8) = pk;
           }
+          const float lv = (m + __builtin_amdgcn_logf(l)) * LN2;      // natural-log lse
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, lv), rs_l,
+                                                g != 0 ? 0xFFFFFFF0u
+                                                : SDOC == 128 ? (unsigned int)(((doc * p.H + 2 * pr + hh) * AB_ROWS + qrow) * 4)
+                                                              : (unsigned int)((((2 * doc + (wave >> 2)) * p.H + 2 * pr + hh) * 64 + (qrow & 63)) * 4), 0, 0);
         }
-        l += lane_xor16(l);
-        l += lane_xor32(l);
-        const float inv = 1.f / l;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const u32x2 pk = {pack_bf16x2(oo[dt][0] * inv, oo[dt][1] * inv), pack_bf16x2(oo[dt][2] * inv, oo[dt][3] * inv)};
-          *reinterpret_cast<u32x2*>(ai + qrow * 128 + (((hh * 4 + dt * 2 + (g >> 1)) ^ isw(qrow)) << 4) + (g & 1) * 8) = pk;
-        }
-        const float lv = (m + __builtin_amdgcn_logf(l)) * LN2;      // natural-log lse
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, lv), rs_l,
-                                              g != 0 ? 0xFFFFFFF0u
-                                              : SDOC == 128 ? (unsigned int)(((doc * p.H + 2 * pr + hh) * AB_ROWS + qrow) * 4)
-                                                            : (unsigned int)((((2 * doc + (wave >> 2)) * p.H + 2 * pr + hh) * 64 + (qrow & 63)) * 4), 0, 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();      // the pair's a image is complete
@@ -447,15 +616,16 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-          const int row = row0 + rp * 32 + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
-          res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
+          const int row = row0 + rbase + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
+          if constexpr (HALF) res[q4][rt] = resa[hf2][q4][rt];
+          else res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
         }
 #pragma unroll
       for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           const int ct = (hf2 >> 1) * 4 + (hf2 & 1) * 2 + q4;
-          const int row = row0 + rp * 32 + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
+          const int row = row0 + rbase + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
           const f32x4 bb = *reinterpret_cast<const f32x4*>(Bo + n);
           bool keep[4] = {true, true, true, true};
           if (DROPOUT) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
@@ -520,7 +690,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
     }
     AB_TR(20);
     // y2 (bf16) -> the [128][512 B] image (slot ^ (row & 15)); rows >= 96 sit behind ring buffer 0 (which holds a
-    // prefetched weight chunk): + 32 KB
+    // prefetched weight chunk): + 32 KB.  (HALF: the MLP stage's images are indexed by the LOCAL row 32 rp + 16 rt + li < 64)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int lrow = rp * 32 + rt * 16 + li_m;
@@ -537,7 +707,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         // allows for them
         if constexpr (XHAT)      // (one address register per row: the tile's column offset is a constant of the unrolled loop)
           __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])}, rs_y2,
-                                                (unsigned int)(row0 + lrow) * (AB_D * 2) + (nh * 64 + 4 * g_m) * 2,
+                                                (unsigned int)(row0 + rb + lrow) * (AB_D * 2) + (nh * 64 + 4 * g_m) * 2,
                                                 ((ct >> 2) * 8 + (ct & 3)) * 32, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[r] = y[r] * gg[r] + bb[r];
@@ -545,7 +715,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         *reinterpret_cast<u32x2*>(irow + (((tl * 2 + (g_m >> 1)) ^ (lrow & 15)) << 4) + (g_m & 1) * 8) = pk;
       }
       // statistics: one writer per row (wave nh = 0, lanes g_m = 0); the others issue the same two stores out of range
-      const unsigned int so = (nh == 0 && g_m == 0) ? (unsigned int)(row0 + lrow) * 4u : 0xFFFFFFF0u;
+      const unsigned int so = (nh == 0 && g_m == 0) ? (unsigned int)(row0 + rb + lrow) * 4u : 0xFFFFFFF0u;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, mu[rt]), rs_m2, so, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, rs2[rt]), rs_r2, so, 0, 0);
     }
@@ -581,13 +751,15 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       // (the output stage's addresses are worked out here, from fresh opaque copies: hoisted to the head of the MLP stage
       //  they were spilled across it, and each reload is a scratch access that drains the x2 stores issued before it)
       int li_e = li_m, g_e = g_m;
+      // (HALF, measured: requesting these rows two chunks early made the tail SLOWER, 8.0 vs 7.4 us -- loads return in order, so
+      //  the weight chunks requested behind a load that misses L2 wait for it; profiles/r05_half_trace.txt)
       if (q == 3 && ffn2) {
         asm volatile("" : "+v"(li_e), "+v"(g_e));
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
-            const int row = row0 + rp * 32 + rt * 16 + li_e;
+            const int row = row0 + rbase + rt * 16 + li_e;
             res[nt][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 rs_x1, (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_e) * 4 + (j * 8 + nt) * 64, 0, 0));
           }
@@ -598,12 +770,20 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         f32x4 acc[2][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 wf[2][2];
+        constexpr int WFD = HALF ? 8 : 2;      // (HALF: every fragment of the chunk up front, as in the q / k / v chunks)
+        bf16x8 wf[WFD][2];
+        if constexpr (HALF) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs_m[0]);
+          for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wf[ks][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs_m[ks & 3] + (ks >> 2) * 256);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs_m[0]);
+        }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          if (ks + 1 < 8) {
+          if (!HALF && ks + 1 < 8) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
               wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs_m[(ks + 1) & 3] + ((ks + 1) >> 2) * 256);
@@ -612,7 +792,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
-              acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
+              acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -627,12 +807,20 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
       } else {
         constexpr bool last = q == 3;
         const unsigned char* wa = wb + ((nh * 4) * 16 + li_m) * 256;
-        bf16x8 wf[2][4];
+        constexpr int WFD = HALF ? 4 : 2;
+        bf16x8 wf[WFD][4];
+        if constexpr (HALF) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs_m[0]);
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[ks][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs_m[ks]);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) wf[0][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs_m[0]);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          if (ks + 1 < 4) {
+          if (!HALF && ks + 1 < 4) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) wf[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(wa + nt * 4096 + xs_m[ks + 1]);
           }
@@ -640,13 +828,13 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
           for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
-              acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
+              acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], hf[rt][ks],
                                                                            (q == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
         }
         if (last) {
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
-            const int row = row0 + rp * 32 + rt * 16 + li_e;
+            const int row = row0 + rbase + rt * 16 + li_e;
             const unsigned int rowh = drop_row(dkey2, (unsigned int)row);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -671,7 +859,7 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         // last o chunk and the 28 stores of the x1 / LN2 stage (16 + 8 + 4) are younger than the loads of chunk c + 1
         constexpr int st_prev = (cm & 3) == 2 ? 4 : 0;
         constexpr int st_this = cm == 0 ? 32 : cm == 14 ? 24 : 0;
-        constexpr int allowed = st_prev + (c + 2 < NCH ? 4 : 0) + st_this;
+        constexpr int allowed = st_prev + (c + 2 < NCH ? LD : 0) + st_this;
         if (c + 1 < NCH) {
           if (cm == 0 && XHAT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed + 8) : "memory");      // (16 x-hat stores, not 8 y rows)
           else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
@@ -683,9 +871,9 @@ __global__ __launch_bounds__(512) void attn_block_fwd_kernel(AttnBlockParams p) 
         asm volatile("" : "+v"(tid_h));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int idx = tid_h + 512 * i, r = idx >> 4, c16 = idx & 15;
+          const int idx = tid_h + NT * i, r = idx >> 4, c16 = idx & 15;
           __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(Hs + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_h,
-                                                 (unsigned int)(row0 + r) * (AB_F * 2) + c16 * 16 + q * 256, 0, 0);
+                                                 (unsigned int)(row0 + rb + r) * (AB_F * 2) + c16 * 16 + q * 256, 0, 0);
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -722,6 +910,8 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 64, true>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 64, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 128, true, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true, true>, AB_LDS_MLP);
     if (e != hipSuccess) {
       mfp_set_error("mfp_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS_MLP, hipGetErrorString(e));
       return MFP_ELAUNCH;
@@ -732,6 +922,12 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
   const dim3 grid(tiles), blk(512);
   if (p.xhat) {       // (mfp_block_fwd_xhat: the whole-block training forms)
     if (!mlp || !p.stash) { mfp_set_error("mfp_block_fwd_xhat: whole-block training form only"); return MFP_EINVAL; }
+    if (p.xhat == 2) {      // mfp_block_fwd_xhat_half: two four-wave workgroups per document
+      if (S != AB_ROWS) { mfp_set_error("mfp_block_fwd_xhat_half: documents of 128 positions"); return MFP_EINVAL; }
+      if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 128, true, true>), dim3(2 * tiles), dim3(256), AB_LDS_MLP, st, p);
+      else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 128, true, true>), dim3(2 * tiles), dim3(256), AB_LDS_MLP, st, p);
+      return MFP_OK;
+    }
     if (S == 64) {
       if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 64, true>), grid, blk, AB_LDS_MLP, st, p);
       else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 64, true>), grid, blk, AB_LDS_MLP, st, p);
@@ -842,6 +1038,21 @@ extern "C" int mfp_block_fwd_xhat(const float* x, const float* gamma, const floa
                                   float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
                                   const int32_t* step_ptr, mfp_stream_t stream) {
   return block_fwd_impl(1, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, xhat1, mean, rstd, qkv, a, lse, x1, gamma2, beta2, W1, b1, W2, b2,
+                        xhat2, mean2, rstd2, h, x2, x2_bf16, B, S, D, H, eps, dropout_p, seed, offset_attn, offset_mlp, step_ptr, stream);
+}
+
+// mfp_block_fwd_xhat on HALF-document tiles: two four-wave workgroups per document (64 query rows each, the other half's K / V
+// recomputed), for batches with fewer documents than CUs (BASELINE config c4: 128 documents per GPU).  S = 128 only; results
+// are bit-identical to mfp_block_fwd_xhat.
+extern "C" int mfp_block_fwd_xhat_half(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
+                                       const void* Wo, const float* bo, const int32_t* nvalid, void* xhat1, float* mean, float* rstd,
+                                       void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
+                                       const void* W1, const float* b1, const void* W2, const float* b2, void* xhat2, float* mean2,
+                                       float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
+                                       float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
+                                       const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(S == AB_ROWS);
+  return block_fwd_impl(2, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, xhat1, mean, rstd, qkv, a, lse, x1, gamma2, beta2, W1, b1, W2, b2,
                         xhat2, mean2, rstd2, h, x2, x2_bf16, B, S, D, H, eps, dropout_p, seed, offset_attn, offset_mlp, step_ptr, stream);
 }
 

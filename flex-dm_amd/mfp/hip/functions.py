@@ -87,6 +87,17 @@ def _attn_block_bwd_on(ctx) -> bool:
         return ATTN_BLOCK_BWD == "1"
     return ctx.T // 128 >= ops.cu_count(ctx.store.w.device)      # (128-row tiles: documents at S = 128, document pairs at S = 64)
 FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 32-bit byte offsets
+# the one-launch block forward on HALF-document tiles (two four-wave workgroups per document, mfp_block_fwd_xhat_half); unset:
+# when two workgroups per document still fit the chip in one round (c4: 128 documents per GPU on 256 CUs); "0" / "1" = A/B
+BLOCK_HALF = os.environ.get("MFP_BLOCK_HALF", "")
+
+
+def _block_half_on(ctx, B: int, S: int) -> bool:
+    if S != 128:
+        return False
+    if BLOCK_HALF != "":
+        return BLOCK_HALF == "1"
+    return 2 * B <= ops.cu_count(ctx.store.w.device)
 
 
 def _doc_tile_ok(B: int, S: int, T: int) -> bool:
@@ -461,7 +472,7 @@ class BlockFn(torch.autograd.Function):
                 st.weight(p + "attn/combine_heads/bias"), ctx.nvalid, st.weight(p + "norm2/gamma"), st.weight(p + "norm2/beta"),
                 st.cw(p + "mlp/dense_0/kernel"), st.weight(p + "mlp/dense_0/bias"), st.cw(p + "mlp/dense_1/kernel"),
                 st.weight(p + "mlp/dense_1/bias"), B, S, NUM_HEADS, ctx.p, ctx.seed, 2 * i + 1, 2 * i + 2, ctx.step_ptr, x2_c=x2_c,
-                xhat_stash=xhat)
+                xhat_stash=xhat, half_tiles=xhat and _block_half_on(ctx, B, S))
             y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h = saved      # (xhat: y1 / y2 hold x-hat)
             ctx.tail["x_c"] = (x2, x2_c) if x2_c is not None else None
             fctx.ctx, fctx.i = ctx, i

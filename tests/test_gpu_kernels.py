@@ -1437,7 +1437,7 @@ def test_wgrad_group_xhat_operand(T):
         assert_close(got, want, 2e-4 * float(want.abs().max()), 1e-4, what)
 
 
-@pytest.mark.parametrize("B,p", [(3, 0.0), (4, 0.1)])
+@pytest.mark.parametrize("B,p", [(3, 0.0), (4, 0.1), (9, 0.1)])      # (9: one full group of 16 half-document workgroups + a pair)
 def test_block_fwd(B, p):
     """mfp_block_fwd: a whole DeepSVG block forward in ONE launch against mfp_attn_block_fwd + mfp_mlp_fused_fwd (same
     dropout streams): the attention half bit for bit, the MLP half within bf16 rounding (LN2 statistics are summed in
@@ -1489,6 +1489,16 @@ def test_block_fwd(B, p):
         assert_close(xh, want, 1e-2, 8e-3, what)
         # (bf16 roundings of f32 values that may differ in the last bit)
         assert (xh != want.to(DEV, torch.float32).to(bf)).float().mean().item() < 2e-3, what
+    # mfp_block_fwd_xhat_half: two four-wave workgroups per document (the other half's K / V recomputed) -- every output of the
+    # x-hat form bit for bit (the same instruction sequence on the same operands produces every value)
+    x2c_h = torch.zeros(T, D, dtype=bf, device=DEV)
+    x2h, saved_h = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H, p, 7, 3, 4, step, x2_c=x2c_h,
+                                 xhat_stash=True, half_tiles=True)
+    names = ("xhat1", "mean1", "rstd1", "qkv", "a", "lse", "x1", "xhat2", "mean2", "rstd2", "h")
+    assert torch.equal(x2h, x2x), "half tiles: x2"
+    assert torch.equal(x2c_h.view(torch.int16), x2c.view(torch.int16)), "half tiles: x2 bf16"
+    for name, got, want in zip(names, saved_h, (xh1, m1x, r1x, qkvx, ax, lsex, x1x, xh2, m2x, r2x, hx)):
+        assert torch.equal(got, want), "half tiles: " + name
 
 
 # ------------------------------------------------------------------------------------ d_model 512 (csrc/block_d512.hip)
