@@ -509,17 +509,19 @@ class _route:
     (one document per CU or not), so at oracle-sized batches the route bench.py times would never meet the oracle:
     "timed" = what 256 documents per GPU run (attn_block_bwd_kernel, 128-row workgroups everywhere), "three" = the
     attention half's input gradients as three launches with 128-row dgrad workgroups, "half" = three launches with
-    the half-size dgrad workgroups of c4's per-GPU shape (the default at B < #CUs)."""
-    ROUTES = {"timed": ("1", "0"), "three": ("0", "0"), "half": ("0", "1"), "default": ("", None)}
+    the half-size dgrad workgroups AND the half-document tiles of the block forward (mfp_block_fwd_xhat_half), c4's per-GPU
+    shape (the default at 2 B <= #CUs)."""
+    ROUTES = {"timed": ("1", "0", "0"), "three": ("0", "0", "0"), "half": ("0", "1", "1"), "default": ("", None, "")}
 
     def __init__(self, name):
-        self.bwd, self.half = self.ROUTES[name]
+        self.bwd, self.half, self.fwd_half = self.ROUTES[name]
 
     def __enter__(self):
         import os
         from mfp.hip import functions
-        self.old = (functions.ATTN_BLOCK_BWD, os.environ.get("MFP_FUSED_HALF"))
+        self.old = (functions.ATTN_BLOCK_BWD, os.environ.get("MFP_FUSED_HALF"), functions.BLOCK_HALF)
         functions.ATTN_BLOCK_BWD = self.bwd
+        functions.BLOCK_HALF = self.fwd_half
         if self.half is None:
             os.environ.pop("MFP_FUSED_HALF", None)
         else:
@@ -529,6 +531,7 @@ class _route:
         import os
         from mfp.hip import functions
         functions.ATTN_BLOCK_BWD = self.old[0]
+        functions.BLOCK_HALF = self.old[2]
         if self.old[1] is None:
             os.environ.pop("MFP_FUSED_HALF", None)
         else:
@@ -557,7 +560,7 @@ def _kernel_names(fn):
     return names
 
 
-@pytest.mark.parametrize("dtype,route", [("fp32", "default"), ("bf16", "default"), ("bf16", "timed"), ("bf16", "three")])
+@pytest.mark.parametrize("dtype,route", [("fp32", "default"), ("bf16", "default"), ("bf16", "timed"), ("bf16", "three"), ("bf16", "half")])
 @pytest.mark.parametrize("mix,B", [("c2", 4), ("c3", 5)])
 def test_timed_shape_parity_vs_oracle(dtype, route, mix, B):
     S, D, L = 128, 256, 4
@@ -757,6 +760,39 @@ def test_train_step_timed_route_vs_oracle():
     import re
     bare = lambda names: sorted(set(re.sub(r"<.*$", "", n) for n in names))
     assert bare(eager_names) == bare(got_names), (bare(eager_names), bare(got_names))
+
+
+def test_half_document_tiles_train_step_equals_full_tiles():
+    """The one-launch block forward on HALF-document tiles (mfp_block_fwd_xhat_half: two workgroups per document, BASELINE
+    config 4's per-GPU shape, chosen when 2 B <= #CUs) inside ``MFP.train_step``: the kernel produces every saved tensor bit
+    for bit as the one-workgroup form (tests/test_gpu_kernels.py::test_block_fwd), so three whole train steps -- dropout 0.1,
+    masking, Adam -- must leave bit-identical parameters on both routes; the kernel names show each route ran its form.
+    (What meets the f64 oracle on this route: test_timed_shape_parity_vs_oracle[... bf16-half].)"""
+    import re
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.hip import functions
+    from mfp.models.mfp import MFP
+    S, D, L, B = 128, 256, 2, 9
+    ic = make_input_columns("crello")
+    dbatch = {k: v.to(DEV) for k, v in synthetic_batch(ic, B, S, seed=41, ragged=True).items()}
+    half_name = re.compile(r"attn_block_fwd_kernel<\w+, true, true, 128, true, true>")
+    out = {}
+    old = functions.BLOCK_HALF
+    try:
+        for flag in ("0", "1"):
+            functions.BLOCK_HALF = flag
+            model = MFP(ic, num_blocks=L, latent_dim=D, dropout=0.1, l2=1e-2, masking_method="random", dtype="bf16", device=DEV, seed=5)
+            model.compile(learning_rate=1e-3)
+            model.train_step(dbatch)
+            model.train_step(dbatch)
+            names = set(_kernel_names(lambda: model.train_step(dbatch)))
+            assert any(half_name.match(n) for n in names) == (flag == "1"), sorted(names)
+            torch.cuda.synchronize()
+            out[flag] = {k: v.clone() for k, v in model.model.store.state_dict().items()}
+    finally:
+        functions.BLOCK_HALF = old
+    for k in out["0"]:
+        assert torch.equal(out["0"][k], out["1"][k]), k
 
 
 # Total-loss deviation of the bf16 replay from the f64 oracle's trajectory.  Each engine steps its OWN parameters, so from
