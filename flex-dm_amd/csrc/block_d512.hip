@@ -368,7 +368,13 @@ constexpr int O5_VEC_OFF = 3 * O5_STAGE;            // bias of this column half 
 constexpr int O5_LDS = O5_VEC_OFF + O5_COLS * 4;    // 148 480 B
 constexpr int O5_EROW = O5_COLS * 4 + 16;           // f32 result image: 1 KB rows + 16 B (the accumulator layout's writes then spread over all banks)
 
-enum { O5_EPI_RES = 0, O5_EPI_BF16 = 1 };
+// O5_EPI_LNB (round 5): the product is the gradient of a LayerNorm OUTPUT (dy2 = dh W1, dy1 = dqkv Wqkv) and the LayerNorm
+// backward runs on the f32 result image -- dy never reaches HBM and the stand-alone ln_bwd launch behind it is gone.  A tile owns
+// HALF of a row's 512 columns, so the two row statistics (mean_c(dy gamma), mean_c(dy gamma xhat)) are exchanged between the
+// two workgroups of a row tile: 128 x 2 partial sums each way through a global scratch (write-through stores, drained, then a
+// relaxed agent-scope flag; the reader spins on the partner's flag, does one agent acquire and resets it -- the hand-off form of
+// gemm_wgg.h).  The pair sits 8 apart in a group of 16 consecutive workgroups (same XCD, adjacent in dispatch order).
+enum { O5_EPI_RES = 0, O5_EPI_BF16 = 1, O5_EPI_LNB = 2 };
 
 struct Os512Params {
   const unsigned short* A; int lda; int K;          // bf16 [T][lda], K columns used (a multiple of 64)
@@ -376,6 +382,11 @@ struct Os512Params {
   const float* bias;                                // [512] or nullptr
   const float* res; float* out; unsigned short* outc;      // O5_EPI_RES: out = res + Dropout(acc + bias) f32 [T][512] (+ bf16 copy or nullptr)
   unsigned short* outb;                             // O5_EPI_BF16: bf16 [T][512]
+  // O5_EPI_LNB: x-hat form of the LayerNorm backward on the result (ln_bwd_tile.h states the arithmetic), bf16 residual-gradient stream
+  const unsigned short* xhat; const float* gamma; const float* rstd;      // bf16 [T][512] = (x - mean) rstd, f32 [512], f32 [T]
+  const unsigned short* dres; unsigned short* dx; unsigned short* ddrop;  // bf16 [T][512]: residual gradient in, dx out, masked copy out (or nullptr)
+  float* part;                                      // f32 [T / 128][3][512]: per-tile sums of dy xhat | dy | ddrop
+  float* exch; int* flags;                          // f32 [T / 128][2][128][2] scratch; int [T / 128][2], zero between launches
   int T;
   float dropout_p; unsigned long long seed, offset; const int* step_ptr;
   unsigned long long* trace;                        // D5_TRACE builds
@@ -390,7 +401,12 @@ __global__ __launch_bounds__(512) void os512_kernel(Os512Params p) {
   // wave (rp, nh) owns 64 rows x 64 columns (4 x 4 MFMA tiles): 8 fragment reads per 16 products -- at 32 x 128 (10 reads) the
   // stage was bound by the LDS port (208 KB of reads + LDS-DMA writes per stage = 0.78 us against 0.62 us of products)
   const int rp = wave & 1, nh = wave >> 1;
-  const int row0 = blockIdx.x * O5_ROWS, n0 = blockIdx.y * O5_COLS;
+  // (O5_EPI_LNB: the two column halves of a row tile are workgroups b and b + 8 of a group of 16 in dispatch order)
+  const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const bool paired = EPI == O5_EPI_LNB && (gridDim.x & 7) == 0;
+  const int tile = EPI != O5_EPI_LNB ? (int)blockIdx.x : paired ? (lin >> 4) * 8 + (lin & 7) : lin >> 1;
+  const int half = EPI != O5_EPI_LNB ? (int)blockIdx.y : paired ? (lin >> 3) & 1 : lin & 1;
+  const int row0 = tile * O5_ROWS, n0 = half * O5_COLS;
   const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
   const unsigned int kb2 = (unsigned int)p.K * 2u;
   constexpr unsigned int OOB = 0x40000000u;
@@ -511,6 +527,106 @@ __global__ __launch_bounds__(512) void os512_kernel(Os512Params p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (unsigned int)row * (O5_N * 4) + n * 4, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_oc, (unsigned int)row * (O5_N * 2) + n * 2, 0, 0);
       }
+    }
+  } else if constexpr (EPI == O5_EPI_LNB) {
+    // wave w owns rows 16 w .. + 15 of the tile, a lane 4 consecutive columns of this half (ln_bwd_tile's walk on 512-byte row halves)
+    const unsigned int hb = (unsigned int)p.T * (O5_N * 2);
+    const __amdgpu_buffer_rsrc_t rs_xh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xhat), 0, hb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dres), 0, hb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc(p.dx, 0, hb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc(p.ddrop ? p.ddrop : p.dx, 0, p.ddrop ? hb : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ex = __builtin_amdgcn_make_buffer_rsrc(p.exch, 0, (unsigned int)(p.T / O5_ROWS) * (2 * O5_ROWS * 8), 0x00020000);
+    const int r0 = wave * 16;
+    const unsigned int cb = (unsigned int)(n0 + lane * 4) * 2u;
+    u32x2 xv[16], rv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      xv[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xh, (unsigned int)(row0 + r0 + i) * (O5_N * 2) + cb, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      rv[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dr, (unsigned int)(row0 + r0 + i) * (O5_N * 2) + cb, 0, 0));
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(p.gamma + n0 + lane * 4);
+    const float rs_l = lane < 16 ? p.rstd[row0 + r0 + lane] : 0.f;
+    // ---- pass 1: this half's share of the two row sums (f32 dy straight from the result image), parameter-gradient sums
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
+    float my1 = 0.f, my2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(E + (r0 + i) * O5_EROW + lane * 16);
+      const float xh[4] = {__uint_as_float(xv[i][0] << 16), __uint_as_float(xv[i][0] & 0xFFFF0000u), __uint_as_float(xv[i][1] << 16),
+                           __uint_as_float(xv[i][1] & 0xFFFF0000u)};
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dg[e] += d[e] * xh[e];
+        db[e] += d[e];
+        const float gy = d[e] * gam[e];
+        s1 += gy;
+        s2 += gy * xh[e];
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == i) { my1 = s1; my2 = s2; }
+    }
+    // ---- exchange with the other column half of the row tile
+    const unsigned int exo = (unsigned int)(((tile * 2 + half) * O5_ROWS + r0 + lane) * 8);
+    const unsigned int exp_ = (unsigned int)(((tile * 2 + (half ^ 1)) * O5_ROWS + r0 + lane) * 8);
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(my1), __float_as_uint(my2)}, rs_ex, lane < 16 ? exo : OOB, 0, 16 /* sc1 */);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(&p.flags[tile * 2 + half], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(&p.flags[tile * 2 + (half ^ 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(&p.flags[tile * 2 + (half ^ 1)], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+    }
+    __syncthreads();
+    const u32x2 ov = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ex, lane < 16 ? exp_ : OOB, 0, 0));
+    const float t1 = (my1 + __uint_as_float(ov[0])) * (1.0f / O5_N), t2 = (my2 + __uint_as_float(ov[1])) * (1.0f / O5_N);
+    // ---- pass 2: dx = dres + rstd (gy - mean(gy) - xhat mean(gy xhat)), its dropout-masked copy
+    const unsigned long long rng_off = p.offset + (p.step_ptr ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+    const float inv_keep = p.dropout_p > 0.f ? 1.f / (1.f - p.dropout_p) : 1.f;
+    const unsigned int dkey = drop_key(p.seed, rng_off), dthr = drop_thr16(p.dropout_p);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = row0 + r0 + i;
+      const float rs = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rs_l), i));
+      const float s1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t1), i));
+      const float s2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t2), i));
+      const f32x4 d = *reinterpret_cast<const f32x4*>(E + (r0 + i) * O5_EROW + lane * 16);
+      const float xh[4] = {__uint_as_float(xv[i][0] << 16), __uint_as_float(xv[i][0] & 0xFFFF0000u), __uint_as_float(xv[i][1] << 16),
+                           __uint_as_float(xv[i][1] & 0xFFFF0000u)};
+      const float res[4] = {__uint_as_float(rv[i][0] << 16), __uint_as_float(rv[i][0] & 0xFFFF0000u), __uint_as_float(rv[i][1] << 16),
+                            __uint_as_float(rv[i][1] & 0xFFFF0000u)};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rs * (d[e] * gam[e] - s1 - xh[e] * s2) + res[e];
+      __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_dx, (unsigned int)row * (O5_N * 2) + cb, 0, 0);
+      if (p.ddrop != nullptr) {
+        if (p.dropout_p > 0.f) {
+          bool keep[4];
+          drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)(n0 + lane * 4), dthr, keep);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = keep[e] ? o[e] * inv_keep : 0.f;
+        }
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs_dd, (unsigned int)row * (O5_N * 2) + cb, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dc[e] += o[e];
+      }
+    }
+    // ---- the tile's parameter-gradient sums: eight waves through LDS (the result image is dead), one [3][256] slice of the
+    // tile's partial row for the batched reduction at the end of the backward pass
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<f32x4*>(red + (wave * 3 + 0) * O5_COLS + lane * 4) = (f32x4){dg[0], dg[1], dg[2], dg[3]};
+    *reinterpret_cast<f32x4*>(red + (wave * 3 + 1) * O5_COLS + lane * 4) = (f32x4){db[0], db[1], db[2], db[3]};
+    *reinterpret_cast<f32x4*>(red + (wave * 3 + 2) * O5_COLS + lane * 4) = (f32x4){dc[0], dc[1], dc[2], dc[3]};
+    __syncthreads();
+    for (int c = tid; c < 3 * O5_COLS; c += 512) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[w * 3 * O5_COLS + c];
+      p.part[(size_t)tile * (3 * O5_N) + (c / O5_COLS) * O5_N + n0 + (c % O5_COLS)] = a;
     }
   } else {
     // bf16 rows: a lane packs 8 consecutive columns, a wave instruction covers two rows of this column half (2 x 512 B)
@@ -686,6 +802,31 @@ extern "C" int mfp_dense_n512_lda(const void* A, int32_t lda, const void* W, voi
   p.outb = reinterpret_cast<unsigned short*>(out);
   p.T = T;
   if (int rc = launch_os512<O5_EPI_BF16, false>(p, reinterpret_cast<hipStream_t>(stream))) return rc;
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+// mfp_dense_n512 followed by the x-hat form of mfp_layernorm_bwd_xhat on its result, in one launch (O5_EPI_LNB): A bf16 [T][K]
+// is the gradient of the Dense behind a LayerNorm (dh, dqkv), W bf16 [512][K] that Dense's transposed kernel, so A W^T = dy.
+//   dx = dres + rstd (dy gamma - mean_c(dy gamma) - xhat mean_c(dy gamma xhat)),  ddrop = Dropout-mask(dx) / keep (or nullptr),
+//   part[T / 128][3][512] = per-tile sums of dy xhat | dy | ddrop (dgamma, dbeta, the consuming Dense's bias gradient: the caller
+//   reduces them, mfp_reduce_partials[_batch] with P = T / 128, pstride = 1536).
+// exch: f32 [T / 128][2][128][2] scratch; flags: int32 [T / 128][2], ZERO on entry and zero again on exit.  T % 128 == 0.
+extern "C" int mfp_dense_n512_lnb(const void* A, const void* W, const void* xhat, const float* gamma, const float* rstd, const void* dres,
+                                  void* dx, void* ddrop, float* part, float* exch, int32_t* flags, int32_t T, int32_t K, float dropout_p,
+                                  uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(A && W && xhat && gamma && rstd && dres && dx && part && exch && flags);
+  MFP_CHECK_ARG(T > 0 && T <= (1 << 19) && T % O5_ROWS == 0 && K >= 128 && K % 64 == 0 && K <= 8192 && (long long)T * K * 2 < 0x40000000LL);
+  MFP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f);
+  MFP_CHECK_ARG(al16(A) && al16(W) && al16(xhat) && al16(gamma) && al16(dres) && al16(dx) && al16(ddrop) && al16(part) && al16(exch));
+  Os512Params p = {};
+  p.A = reinterpret_cast<const unsigned short*>(A); p.lda = K; p.K = K;
+  p.W = reinterpret_cast<const unsigned short*>(W);
+  p.xhat = reinterpret_cast<const unsigned short*>(xhat); p.gamma = gamma; p.rstd = rstd;
+  p.dres = reinterpret_cast<const unsigned short*>(dres); p.dx = reinterpret_cast<unsigned short*>(dx);
+  p.ddrop = reinterpret_cast<unsigned short*>(ddrop); p.part = part; p.exch = exch; p.flags = flags;
+  p.T = T; p.dropout_p = dropout_p; p.seed = seed; p.offset = offset; p.step_ptr = step_ptr;
+  if (int rc = launch_os512<O5_EPI_LNB, false>(p, reinterpret_cast<hipStream_t>(stream))) return rc;
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mfp_dense_relumask_d512": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_void_p]),
     "mfp_dense_n512_res": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_dense_n512": (c_int32, [c_void_p] * 3 + [c_int32, c_int32, c_void_p]),
+    "mfp_dense_n512_lnb": (c_int32, [c_void_p] * 11 + [c_int32, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_dense_n512_lda": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "mfp_attn_block_bwd": (c_int32, [c_void_p] * 9 + [c_int32] * 4 + [c_void_p]),
     "mfp_attn_block_bwd_ln": (c_int32, [c_void_p] * 17 + [c_size_t] + [c_int32] * 4 + [c_float, c_uint64, c_uint64, c_void_p, c_void_p]),

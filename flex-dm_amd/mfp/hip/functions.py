@@ -116,6 +116,10 @@ def _fused_ok(ctx, D) -> bool:
 # output (attention output projection, FFN2, the three input gradients) on the row-owning kernel (csrc/block_d512.hip);
 # 0 = ln_fwd + the generic weight-stationary / LDS-tiled products
 D512_FUSE = os.environ.get("MFP_D512_FUSE", "1") == "1"
+# ... and the LayerNorm backward in the epilogue of the products that form a LayerNorm output's gradient (dy2 = dh W1, dy1 = dqkv
+# Wqkv: mfp_dense_n512_lnb -- dy never reaches HBM, no stand-alone ln_bwd launch; x-hat stash + bf16 residual-gradient stream);
+# 0 = mfp_dense_n512 + mfp_layernorm_bwd_xhat (A/B switch)
+D512_LN_BWD = os.environ.get("MFP_D512_LN_BWD", "1") == "1"
 
 
 # fp8 mode, d_model 512, MEASUREMENT switches (tests/test_gpu_model.py::test_c5_fp8_deviation_and_training):
@@ -621,7 +625,14 @@ class BlockFn(torch.autograd.Function):
                      colsum=st.grad(p + "mlp/dense_0/bias"), splitk=sk(T, 2 * D, D))
         if not grouped:
             ctx.on_side(wgrads_mlp, d_o2, h, dh, y2)
-        if f512:
+        if f512 and D512_LN_BWD and xh2 is not None and T % 128 == 0:
+            # LN2 backward (+ the masked gradient of the attention dropout) in the epilogue of dy2 = dh W1 (csrc/block_d512.hip)
+            dx1, d_o1 = ops.dense_n512_lnb(dh, wt0, xh2, st.weight(p + "norm2/gamma"), rstd2, dx2,
+                                           st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
+                                           drop=(st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1, ctx.step_ptr),
+                                           jobs=ctx.ln_jobs)
+            ln_fused = True
+        elif f512:
             dy2 = ops.dense_n512(dh, wt0)
         elif not fused_bwd:
             dy2 = ops.gemm(dh, wt0 if wt0 is not None else st.cw(p + "mlp/dense_0/kernel"), T, D, 2 * D, a_kmajor=True,
@@ -686,6 +697,14 @@ class BlockFn(torch.autograd.Function):
             pass
         elif _fused_ok(ctx, D) and wtq is not None:
             dy1 = ops.dgrad_qkv(dqkv, wtq)       # activation-stationary (csrc/block_fused.hip)
+        elif _fused512_ok(ctx, D) and wtq is not None and D512_LN_BWD and xh1 is not None and T % 128 == 0:
+            # LN1 backward (+ the masked gradient block i - 1's MLP half starts from) in the epilogue of dy1 = dqkv Wqkv
+            drop1 = ((st.grad("blocks/seq2seq_%d/mlp/dense_1/bias" % (i - 1)), ctx.p, ctx.seed, 2 * (i - 1) + 2, ctx.step_ptr)
+                     if i > 0 else None)
+            r_ = ops.dense_n512_lnb(dqkv, wtq, xh1, st.weight(p + "norm1/gamma"), rstd1, dx1,
+                                    st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), drop=drop1, jobs=ctx.ln_jobs)
+            dx, nxt = r_ if i > 0 else (r_, None)
+            ln1_fused = True
         elif _fused512_ok(ctx, D) and wtq is not None:
             dy1 = ops.dense_n512(dqkv, wtq)      # row-owning (csrc/block_d512.hip)
         else:

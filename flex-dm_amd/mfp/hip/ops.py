@@ -523,6 +523,41 @@ def dense_n512_lda(A, W):
     return out
 
 
+_LNB_WS = {}
+
+
+def dense_n512_lnb(A, W, xhat, gamma, rstd, dres, dgamma, dbeta, drop=None, jobs: Optional[list] = None):
+    """``layernorm_bwd(dense_n512(A, W), ..., xhat=xhat)`` in ONE launch (see mfp_dense_n512_lnb): dy = A W^T never reaches HBM.
+    Returns (dx, ddrop) with ``drop`` = (colsum_out [512], p, seed, offset, step_ptr), else dx.  The exchange scratch and its
+    flags (zero between launches) are per device and token count, allocated once outside any graph capture's pool."""
+    lib = load()
+    T, K = A.shape
+    assert A.dtype == torch.bfloat16 and A.is_contiguous() and T % 128 == 0 and xhat.dtype == torch.bfloat16 and dres.dtype == torch.bfloat16
+    dev = A.device
+    key = (dev.index, T)
+    if key not in _LNB_WS:
+        assert not torch.cuda.is_current_stream_capturing(), "dense_n512_lnb: first call inside a graph capture"
+        _LNB_WS[key] = (torch.empty((T // 128, 2, 128, 2), dtype=torch.float32, device=dev),
+                        torch.zeros((T // 128, 2), dtype=torch.int32, device=dev))
+    exch, flags = _LNB_WS[key]
+    dx = torch.empty((T, 512), dtype=torch.bfloat16, device=dev)
+    ddrop = torch.empty((T, 512), dtype=torch.bfloat16, device=dev) if drop is not None else None
+    colsum, p_, seed_, off_, sp_ = drop if drop is not None else (None, 0.0, 0, 0, None)
+    P = T // 128
+    part = torch.empty((P, 3 * 512), dtype=torch.float32, device=dev)
+    with _timed("os512_kernel", 2 * T * K * 512, T * (K * 2 + 512 * 2 * (3 + (1 if drop is not None else 0))) + 512 * K * 2):
+        check(lib.mfp_dense_n512_lnb(_ptr(A), _ptr(W), _ptr(xhat), _ptr(gamma), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part),
+                                     _ptr(exch), _ptr(flags), T, K, float(p_), int(seed_), int(off_), _ptr(sp_), _stream()),
+              "mfp_dense_n512_lnb")
+    n = 3 * 512 if drop is not None else 2 * 512
+    if jobs is not None:
+        jobs.append(dict(part=part, out0=dgamma, out1=dbeta, out2=colsum, split1=512, split2=1024, P=P, N=n, pstride=3 * 512))
+    else:
+        check(lib.mfp_reduce_partials(part.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(colsum), 512, 1024, P, n, 3 * 512, _stream()),
+              "mfp_reduce_partials")
+    return (dx, ddrop) if drop is not None else dx
+
+
 def block_infer(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1, W2, b2, B: int, S: int, H: int):
     """A whole DeepSVG block forward in ONE launch with nothing saved for a backward pass (see mfp_block_infer): the
     inference callers' form (``MFP.__call__(training=False)``, ``iterative_decode``, eval.py).  Returns x2."""

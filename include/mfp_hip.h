@@ -254,6 +254,18 @@ int mfp_dense_n512(const void* A, const void* W, void* out, int32_t T, int32_t K
 /* mfp_dense_n512 for an A with row stride lda in (K - 128, K]: its columns lda .. K - 1 do not exist, W's columns >= lda must be
  * zero.  The decoder heads' input gradient at d_model 512 (A = d(logits) [T][U], W = the transposed heads zero-padded to K). */
 int mfp_dense_n512_lda(const void* A, int32_t lda, const void* W, void* out, int32_t T, int32_t K, mfp_stream_t stream);
+/* mfp_dense_n512 followed by mfp_layernorm_bwd_xhat on its result, in ONE launch (the Keras autodiff of
+ * Dense(LayerNormalization(x)) down to x: transformer.py:216-217 / 222-223): A bf16 [T,K] is the gradient of the Dense's output
+ * (dh, dqkv), W bf16 [512][K] its transposed kernel, so dy = A W^T -- which never reaches HBM:
+ *   dx = dres + rstd (dy gamma - mean_c(dy gamma) - xhat mean_c(dy gamma xhat))   (bf16 residual-gradient stream),
+ *   ddrop = Dropout-mask(dx) / keep for (dropout_p, seed, offset, *step_ptr), or NULL: none,
+ *   part f32 [T/128][3][512] = per-128-row-tile sums of dy xhat | dy | ddrop (dgamma, dbeta, the consuming Dense's bias gradient):
+ *   the caller reduces them (mfp_reduce_partials / _batch with P = T / 128, pstride = 1536).
+ * A workgroup owns 128 rows x 256 columns; the two row sums are exchanged between the two workgroups of a row tile through
+ * `exch` (f32 [T/128][2][128][2]) and `flags` (int32 [T/128][2]: ZERO on entry, zero again on exit).  T % 128 == 0. */
+int mfp_dense_n512_lnb(const void* A, const void* W, const void* xhat, const float* gamma, const float* rstd, const void* dres,
+                       void* dx, void* ddrop, float* part, float* exch, int32_t* flags, int32_t T, int32_t K, float dropout_p,
+                       uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
 /* Inference form of mfp_block_fwd (what MFP.__call__(training=False), iterative_decode and eval.py run: reference
  * models/mfp.py:141-207, eval.py:35-118): the same single launch with nothing saved for a backward pass -- y1, qkv, a, lse,

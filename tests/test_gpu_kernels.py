@@ -1588,6 +1588,54 @@ def test_dense_n512(T, K):
     assert_close(out, A.double() @ W.double().t(), 2e-2, 8e-3, "out vs double")
 
 
+@pytest.mark.parametrize("T,K,p", [(1024, 1024, 0.1), (384, 1536, 0.0), (16384, 1536, 0.1), (2048, 1024, None)])
+def test_dense_n512_lnb(T, K, p):
+    """mfp_dense_n512_lnb: dy = A W^T (the gradient of a LayerNorm output at d_model 512: dy2 = dh W1, dy1 = dqkv Wqkv) with the
+    x-hat LayerNorm backward on the f32 result in the same launch -- the two workgroups of a row tile exchange their halves of the
+    row sums through global memory.  Against a double restatement from the double product (dy is never rounded to bf16 here), and
+    against the launch pair it replaces (mfp_dense_n512 + mfp_layernorm_bwd_xhat, whose dy IS bf16) within that rounding; three
+    launches back to back on the same flags (they must be zero again after every launch); T = 384: three row tiles, i.e. the
+    unpaired workgroup mapping; p = None: no masked copy (block 0)."""
+    ops = _ops()
+    D = 512
+    g = torch.Generator().manual_seed(820 + T + K)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    A, W = bf16_round(rn(T, K)), bf16_round(rn(D, K) * 0.04)
+    xh = bf16_round(rn(T, D))
+    gamma, rstd = (torch.rand(D, generator=g) + 0.5), (torch.rand(T, generator=g) + 0.5)
+    dres = bf16_round(rn(T, D))
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d = lambda t, dt=None: t.to(DEV, dt) if dt else t.to(DEV)
+    bf = torch.bfloat16
+    Ad, Wd, xhd, gd, rd, drd = d(A, bf), d(W, bf), d(xh, bf), d(gamma), d(rstd), d(dres, bf)
+    outs = []
+    for rep in range(3):
+        dg, db, cs = (torch.full((D,), 7.0, device=DEV) for _ in range(3))
+        drop = (cs, p, 7, 3, step) if p is not None else None
+        r = ops.dense_n512_lnb(Ad, Wd, xhd, gd, rd, drd, dg, db, drop=drop)
+        dx, dd = r if p is not None else (r, None)
+        outs.append((dx.clone(), None if dd is None else dd.clone(), dg.clone(), db.clone(), cs.clone()))
+    torch.cuda.synchronize()
+    _, flags = ops._LNB_WS[(torch.device(DEV).index if torch.device(DEV).index is not None else torch.cuda.current_device(), T)]
+    assert int(flags.abs().sum().item()) == 0
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert (a is None and b is None) or torch.equal(a, b)
+    dx, dd, dg, db, cs = outs[0]
+    dy64 = A.double() @ W.double().t()
+    _check_ln_from_xhat(dy64, xh, gamma, rstd, dres, dx, dd, dg, db, cs, p if p is not None else 0.0)
+    # the launch pair it replaces
+    dy = ops.dense_n512(Ad, Wd)
+    dg2, db2, cs2 = (torch.empty(D, device=DEV) for _ in range(3))
+    r2 = ops.layernorm_bwd(dy, None, gd, None, rd, drd, dg2, db2, drop=(cs2, p, 7, 3, step) if p is not None else None, xhat=xhd)
+    dx2, dd2 = r2 if p is not None else (r2, None)
+    assert_close(dx, dx2.double().cpu(), 6e-2, 2e-2, "dx vs dense_n512 + layernorm_bwd_xhat")
+    if dd is not None:
+        assert torch.equal(dd == 0, dd2 == 0) or ((dd == 0) != (dd2 == 0)).float().mean().item() < 1e-4      # (the same dropout mask)
+    assert_close(dg, dg2.double().cpu(), 2e-2 * float(dg2.abs().max()), 1e-3, "dgamma vs the pair")
+    assert_close(db, db2.double().cpu(), 2e-2 * float(db2.abs().max()), 1e-3, "dbeta vs the pair")
+
+
 @pytest.mark.parametrize("T,U", [(384, 1384), (16384, 1384), (200, 1400)])
 def test_dense_n512_lda(T, U):
     """mfp_dense_n512_lda: the decoder heads' input gradient at d_model 512 -- A = d(logits) [T][U] with NO padding columns, W = the
