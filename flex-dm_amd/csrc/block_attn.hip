@@ -101,12 +101,20 @@ __device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
 // by the same instruction sequence on the same operands as in the one-workgroup form: results are bit-identical to it
 // (tests/test_gpu_kernels.py::test_block_fwd_half).  Per-wave op counts that the counted waits rest on: a weight chunk is 8
 // LDS-DMA pieces per wave instead of 4 (LD); every store loop covers half the rows with half the threads, i.e. the same count.
-template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128, bool XHAT = false, bool HALF = false>
-__global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBlockParams p) {
+// HALF == 2: the same two workgroups per document with EIGHT waves each -- a wave owns ONE 16-row tile (wave = (rp, nh, rtw): the
+// two waves of a SIMD hold the two row tiles of a row pair and share every weight fragment's column range), one (query tile,
+// head) per wave in the attention: two waves per SIMD overlap each other's chunk overheads, which one wave per SIMD could not.
+// Same arithmetic per row as the other forms: bit-identical.  Per-thread store counts halve (64 rows on 512 threads).
+template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128, bool XHAT = false, int HALF = 0>
+__global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(AttnBlockParams p) {
   static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
   static_assert(!HALF || (SDOC == 128 && MLP && XHAT && STASH), "half-document tiles: the x-hat training form at S = 128");
-  constexpr int NT = HALF ? 256 : 512;                 // threads
-  constexpr int LD = HALF ? 8 : 4;                     // 1 KB LDS-DMA pieces per wave and weight chunk
+  constexpr bool H8 = HALF == 2;
+  constexpr int NT = HALF == 1 ? 256 : 512;            // threads
+  constexpr int LD = HALF == 1 ? 8 : 4;                // 1 KB LDS-DMA pieces per wave and weight chunk
+  constexpr int RT = H8 ? 1 : 2;                       // 16-row tiles per wave
+  constexpr int SI = (HALF ? 64 : 128) * 8 / NT;       // 16-byte pieces per thread of an image's own rows (stash)
+  constexpr int HI = (HALF ? 64 : 128) * 16 / NT;      // ... of an h quarter's
   constexpr int NCH = MLP ? 2 * AB_CHUNKS : AB_CHUNKS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Im = smem;                      // Im + t * AB_IMG, t = 0 (q, then a), 1 (k), 2 (v)
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
   float* const Mb = reinterpret_cast<float*>(smem + AB_VEC_OFF + (768 + 3 * 256) * 4);
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rp = HALF ? (wave & 1) : (wave & 3), nh = HALF ? (wave >> 1) : (wave >> 2);
+  const int rp = HALF ? (wave & 1) : (wave & 3), nh = HALF ? ((wave >> 1) & 1) : (wave >> 2), rtw = H8 ? (wave >> 2) : 0;
   // HALF: the two halves of a document are workgroups b and b + 8 of a group of 16 -- the same XCD (workgroups go round the
   // eight XCDs), so the second fetch of the document's x rows and of the weights is a hit in that XCD's L2; a trailing partial
   // group pairs neighbours
@@ -126,14 +134,14 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
   const int doc = !HALF ? bi : bi < bfull ? (bi >> 4) * 8 + (bi & 7) : (bfull >> 1) + ((bi - bfull) >> 1);
   const int row0 = doc * AB_ROWS;
   const int rb = !HALF ? 0 : (bi < bfull ? (bi >> 3) & 1 : (bi - bfull) & 1) * 64;      // first own row of the document (image rows are document rows)
-  const int rbase = rb + rp * 32;                            // this wave's two row tiles: document rows rbase + 16 rt + li
+  const int rbase = rb + rp * 32 + rtw * 16;                 // this wave's row tile(s): document rows rbase + 16 rt + li, rt < RT
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   // (the step counter and the document's length are read first: their loads must not sit between the counted waits)
   const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
   const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[SDOC == 128 ? doc : 2 * doc]);
   const int nv1 = SDOC == 128 ? 0 : __builtin_amdgcn_readfirstlane(p.nvalid[2 * doc + 1]);
 
-  const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(blockIdx.x * (HALF ? 4 : 8) + wave) * 64;
+  const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(blockIdx.x * (HALF == 1 ? 4 : 8) + wave) * 64;
   AB_TR(0);
   const unsigned int xbytes = (unsigned int)p.T * (AB_D * 4);
   // inference form: the saved tensors are zero-sized buffers -- their stores are issued all the same (the counted waits
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
   // ---- weight chunk c = 4 p + t.  t = 0, 1, 2 (q, k, v): Wqkv rows t * 256 + 64 p .. + 63, all 256 k -> image [64][512 B],
   // slot ^ (row & 15) (2 rows per 1 KB piece).  t = 3 (o): Wo rows 0 .. 255, k = 64 p .. + 63 -> image [256][128 B],
   // slot ^ ((row >> 1) & 7) (8 rows per piece).  Four pieces per wave and chunk.
-  const unsigned int w1off = HALF ? (unsigned int)((wave * 16 + (lane >> 5)) * 512 + (((lane & 31) ^ (lane >> 5)) << 4))
+  const unsigned int w1off = HALF == 1 ? (unsigned int)((wave * 16 + (lane >> 5)) * 512 + (((lane & 31) ^ (lane >> 5)) << 4))
                                   : (unsigned int)((wave * 8 + (lane >> 5)) * 512 + (((lane & 31) ^ ((wave & 1) * 8 + (lane >> 5))) << 4));
   auto wload = [&](int c) {
     const int pr = c >> 2, t = c & 3;
@@ -217,12 +225,16 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
   bf16x8 xf[2][8];
   bf16x8 xo[HALF ? 2 : 1][8];      // HALF: LN1 of the other half's rows rbase ^ 64 + 16 rt + li, operands of the k / v chunks
   {
-    constexpr int NP = HALF ? 2 : 1;
+    constexpr int NP = HALF == 1 ? 2 : 1;      // (HALF == 2: eight waves cover the document's 128 rows in one pass, as the one-workgroup form)
+    // HALF == 2: the rows of the OTHER half (waves whose 16 rows are not in [rb, rb + 64)) leave no x-hat: their stores are issued
+    // out of range (the counted waits assume the same ten prologue stores in every wave); their statistics are stored twice, by
+    // both workgroups of the document, with identical values
+    const bool own8 = !H8 || ((wave >> 2) == (rb >> 6));
     float v[NP][8][8];
     float s[NP];
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
-      const int row = row0 + (HALF ? (rb ^ (ps * 64)) : 0) + wave * 16 + li;
+      const int row = row0 + (HALF == 1 ? (rb ^ (ps * 64)) : 0) + wave * 16 + li;
       s[ps] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
     AB_TR(1);
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
-      const int lrow = (HALF ? (rb ^ (ps * 64)) : 0) + wave * 16 + li, row = row0 + lrow;
+      const int lrow = (HALF == 1 ? (rb ^ (ps * 64)) : 0) + wave * 16 + li, row = row0 + lrow;
       float sm_ = s[ps];
       sm_ += lane_xor16(sm_);
       sm_ += lane_xor32(sm_);
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
           // contiguous bytes), the SAME eight stores per lane as the y rows below issue -- the counted waits see no difference
           if (ps == 0) {
             const u32x4 px = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-            __builtin_amdgcn_raw_buffer_store_b128(px, rs_y, (unsigned int)row * (AB_D * 2) + ks * 64 + g * 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(px, rs_y, own8 ? (unsigned int)row * (AB_D * 2) + ks * 64 + g * 16 : 0xFFFFFFF0u, 0, 0);
           }
         }
 #pragma unroll
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
     }
   }
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rbase + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
   auto stash = [&](int pr, int t) {
     const unsigned char* img = Im + (t == 3 ? 0 : t) * AB_IMG;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < SI; ++i) {
       const int idx = tid + NT * i, r = rb + (idx >> 3), c16 = idx & 7;      // (HALF: the own 64 rows)
       const u32x4 v = *reinterpret_cast<const u32x4*>(img + r * 128 + ((c16 ^ isw(r)) << 4));
       if (t < 3) __builtin_amdgcn_raw_buffer_store_b128(v, rs_q, (unsigned int)(row0 + r) * (768 * 2) + t * 512 + pr * 128 + c16 * 16, 0, 0);
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
+          for (int rt = 0; rt < RT; ++rt) {
             const int row = row0 + rbase + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
             resa[hf2][q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
           }
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
+          for (int rt = 0; rt < RT; ++rt) {
             acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
             if constexpr (both) acco[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], xo[rt][ks], acco[nt][rt], 0, 0, 0);
           }
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
       for (int nt = 0; nt < 2; ++nt) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(Bq + t * 256 + pr * 64 + (nh * 2 + nt) * 16 + 4 * g);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           const int row = rbase + rt * 16 + li;
           const u32x2 pk = {pack_bf16x2(acc[nt][rt][0] + bb[0], acc[nt][rt][1] + bb[1]), pack_bf16x2(acc[nt][rt][2] + bb[2], acc[nt][rt][3] + bb[3])};
           *reinterpret_cast<u32x2*>(img + row * 128 + ((((nh * 2 + nt) * 2 + (g >> 1)) ^ isw(row)) << 4) + (g & 1) * 8) = pk;
@@ -409,7 +421,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 hf[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           const int row = rbase + rt * 16 + li;
           hf[rt] = *reinterpret_cast<const bf16x8*>(ai + row * 128 + (((ks * 4 + g) ^ isw(row)) << 4));
         }
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
           if constexpr (HALF) wf = wo[ks][ct];
           else wf = *reinterpret_cast<const bf16x8*>(wb + wrow * 128 + (((ks * 4 + g) ^ isw(wrow)) << 4));
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
             acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf[rt], (pr == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[ct][rt], 0, 0, 0);
         }
       }
@@ -431,11 +443,12 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
     // the 10 stores of the prologue (chunk 1 landed there: every x load issued after it has been consumed)
     if (c + 1 < NCH) {
       constexpr int tp = (c - 1) & 3;
-      constexpr int st_prev = c == 0 ? 0 : (tp == 1 || tp == 2) ? 2 : tp == 3 ? 4 : 0;
-      constexpr int at_prev = (c >= 1 && tp == 2) ? 2 : 0;
-      constexpr int st_this = (t == 1 || t == 2) ? 2 : t == 3 ? 4 : 0;
+      // (SI stores per image and thread; one lse store per head a wave walks: two, HALF == 2: one)
+      constexpr int st_prev = c == 0 ? 0 : (tp == 1 || tp == 2) ? SI : tp == 3 ? 2 * SI : 0;
+      constexpr int at_prev = (c >= 1 && tp == 2) ? (H8 ? 1 : 2) : 0;
+      constexpr int st_this = (t == 1 || t == 2) ? SI : t == 3 ? 2 * SI : 0;
       // (HALF: the sixteen residual loads at the head of chunk AB_RES_AT are younger than the loads this chunk and the next wait for)
-      constexpr int allowed = c == 0 ? 10 + LD : st_prev + at_prev + (c + 2 < NCH ? LD : 0) + st_this + ((HALF && (c == AB_RES_AT || c == AB_RES_AT + 1)) ? 16 : 0);
+      constexpr int allowed = c == 0 ? 10 + LD : st_prev + at_prev + (c + 2 < NCH ? LD : 0) + st_this + ((HALF && (c == AB_RES_AT || c == AB_RES_AT + 1)) ? 8 * RT : 0);
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
       const unsigned char* qi = Im;
       const unsigned char* ki = Im + AB_IMG;
       const unsigned char* vi = Im + 2 * AB_IMG;
-      const int qrow = rb + 16 * wave + li;
+      const int qrow = rb + 16 * (H8 ? (wave & 3) : wave) + li;
       constexpr int NKT = SDOC / 16;                                    // key tiles a query sees
       const int kb = SDOC == 128 ? 0 : (wave >> 2) * 64;                // first key row of this wave's queries' document
       const unsigned char* const kid = ki + kb * 128;                   // ((row >> 1) & 7, the slot swizzle, is the same for row + 64)
@@ -458,9 +471,12 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
         // LDS reads per head on a port this phase keeps > 50 % busy) and both heads of the pair in the same loops (two
         // independent dependency chains per wave).  Per head the same operations on the same values in the same order as the
         // two-pass form below: bit-identical.
+        // (HALF == 2: ONE head per wave -- head hh0 of the pair for query tile wave & 3)
+        constexpr int NHH = H8 ? 1 : 2;
+        const int hh0 = H8 ? (wave >> 2) : 0;
         bf16x8 bq[2];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) bq[hh] = *reinterpret_cast<const bf16x8*>(qi + qrow * 128 + (((hh * 4 + g) ^ isw(qrow)) << 4));
+        for (int hx = 0; hx < NHH; ++hx) bq[hx] = *reinterpret_cast<const bf16x8*>(qi + qrow * 128 + ((((hh0 + hx) * 4 + g) ^ isw(qrow)) << 4));
         f32x4 sc[2][NKT];
         float m[2] = {-INFINITY, -INFINITY};
 #pragma unroll
@@ -468,8 +484,8 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
           const int krow = kt * 16 + li;
           const f32x4 mb4 = *reinterpret_cast<const f32x4*>(Mbq + kt * 16 + 4 * g);
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + (((hh * 4 + g) ^ isw(krow)) << 4));
+          for (int hh = 0; hh < NHH; ++hh) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kid + krow * 128 + ((((hh0 + hh) * 4 + g) ^ isw(krow)) << 4));
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, bq[hh], z, 0, 0, 0);
 #pragma unroll
@@ -480,18 +496,18 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
           }
         }
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < NHH; ++hh) {
           m[hh] = fmaxf(m[hh], lane_xor16(m[hh]));
           m[hh] = fmaxf(m[hh], lane_xor32(m[hh]));
         }
         float l[2] = {0.f, 0.f};
         f32x4 oo[2][2];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) oo[hh][0] = oo[hh][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int hh = 0; hh < NHH; ++hh) oo[hh][0] = oo[hh][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NKT / 2; ++u)
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
+          for (int hh = 0; hh < NHH; ++hh) {
             f32x4 pe[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
               const int vrow = 32 * u + 4 * g + (li >> 2);
-              const int P = hh * 8 + dt * 4 + (li & 3);
+              const int P = (hh0 + hh) * 8 + dt * 4 + (li & 3);
               const unsigned char* ptr = vid + vrow * 128 + ((((P >> 1) ^ isw(vrow)) << 4) | ((P & 1) << 3));
               const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)ptr);
               const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 128));
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
             }
           }
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < NHH; ++hh) {
           float lt = l[hh];
           lt += lane_xor16(lt);
           lt += lane_xor32(lt);
@@ -521,11 +537,11 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
             const u32x2 pk = {pack_bf16x2(oo[hh][dt][0] * inv, oo[hh][dt][1] * inv), pack_bf16x2(oo[hh][dt][2] * inv, oo[hh][dt][3] * inv)};
-            *reinterpret_cast<u32x2*>(ai + qrow * 128 + (((hh * 4 + dt * 2 + (g >> 1)) ^ isw(qrow)) << 4) + (g & 1) * 8) = pk;
+            *reinterpret_cast<u32x2*>(ai + qrow * 128 + ((((hh0 + hh) * 4 + dt * 2 + (g >> 1)) ^ isw(qrow)) << 4) + (g & 1) * 8) = pk;
           }
           const float lv = (m[hh] + __builtin_amdgcn_logf(lt)) * LN2;      // natural-log lse
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, lv), rs_l,
-                                                g != 0 ? 0xFFFFFFF0u : (unsigned int)(((doc * p.H + 2 * pr + hh) * AB_ROWS + qrow) * 4), 0, 0);
+                                                g != 0 ? 0xFFFFFFF0u : (unsigned int)(((doc * p.H + 2 * pr + hh0 + hh) * AB_ROWS + qrow) * 4), 0, 0);
         }
       } else {
 #pragma unroll
@@ -615,7 +631,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
       for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           const int row = row0 + rbase + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
           if constexpr (HALF) res[q4][rt] = resa[hf2][q4][rt];
           else res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
       for (int q4 = 0; q4 < 2; ++q4)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           const int ct = (hf2 >> 1) * 4 + (hf2 & 1) * 2 + q4;
           const int row = row0 + rbase + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
           const f32x4 bb = *reinterpret_cast<const f32x4*>(Bo + n);
@@ -644,6 +660,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
     // = scratch accesses on the in-order memory counter).
     int li_m = li, g_m = g, tid_m = tid;
     asm volatile("" : "+v"(li_m), "+v"(g_m), "+v"(tid_m));
+    const int lb = rp * 32 + rtw * 16;      // first LOCAL row (of the workgroup's own rows) of this wave's row tile(s)
     int xs_m[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) xs_m[ks] = ((ks * 4 + g_m) ^ li_m) << 4;
@@ -665,7 +682,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         float sacc = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
@@ -676,12 +693,12 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
           }
         sacc += lane_xor16(sacc);
         sacc += lane_xor32(sacc);
-        if (g_m == 0) St[nh * 128 + rp * 32 + rt * 16 + li_m] = sacc;
+        if (g_m == 0) St[nh * 128 + lb + rt * 16 + li_m] = sacc;
       }
       __syncthreads();
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int lrow = rp * 32 + rt * 16 + li_m;
+      for (int rt = 0; rt < RT; ++rt) {
+        const int lrow = lb + rt * 16 + li_m;
         const float tot = (St[lrow] + St[128 + lrow]) * (1.0f / AB_D);
         if (pass == 0) mu[rt] = tot;
         else rs2[rt] = rsqrtf(tot + p.eps);
@@ -692,8 +709,8 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
     // y2 (bf16) -> the [128][512 B] image (slot ^ (row & 15)); rows >= 96 sit behind ring buffer 0 (which holds a
     // prefetched weight chunk): + 32 KB.  (HALF: the MLP stage's images are indexed by the LOCAL row 32 rp + 16 rt + li < 64)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const int lrow = rp * 32 + rt * 16 + li_m;
+    for (int rt = 0; rt < RT; ++rt) {
+      const int lrow = lb + rt * 16 + li_m;
       unsigned char* irow = smem + lrow * 512 + (lrow >= 96 ? 32768 : 0);
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) {
@@ -729,10 +746,10 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
       }
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const int lrow = rp * 32 + rt * 16 + li_m;
+        const int lrow = lb + rt * 16 + li_m;
         xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + lrow * 512 + (lrow >= 96 ? 32768 : 0) + (((ks * 4 + g_m) ^ li_m) << 4));
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -758,7 +775,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
+          for (int rt = 0; rt < RT; ++rt) {
             const int row = row0 + rbase + rt * 16 + li_e;
             res[nt][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 rs_x1, (unsigned int)row * (AB_D * 4) + (nh * 4 * 16 + 4 * g_e) * 4 + (j * 8 + nt) * 64, 0, 0));
@@ -791,17 +808,17 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
               acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const f32x4 bb = *reinterpret_cast<const f32x4*>(B1s + q * 128 + j * 64 + (nh * 2 + nt) * 16 + 4 * g_m);
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
+          for (int rt = 0; rt < RT; ++rt) {
             const u32x2 pk = {pack_bf16x2(fmaxf(acc[nt][rt][0] + bb[0], 0.f), fmaxf(acc[nt][rt][1] + bb[1], 0.f)),
                               pack_bf16x2(fmaxf(acc[nt][rt][2] + bb[2], 0.f), fmaxf(acc[nt][rt][3] + bb[3], 0.f))};
-            *reinterpret_cast<u32x2*>(Hs + (rp * 32 + rt * 16 + li_m) * 256 + (((j * 8 + (nh * 2 + nt) * 2 + (g_m >> 1)) ^ li_m) << 4) + (g_m & 1) * 8) = pk;
+            *reinterpret_cast<u32x2*>(Hs + (lb + rt * 16 + li_m) * 256 + (((j * 8 + (nh * 2 + nt) * 2 + (g_m >> 1)) ^ li_m) << 4) + (g_m & 1) * 8) = pk;
           }
         }
       } else {
@@ -827,13 +844,13 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
               acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks % WFD][nt], hf[rt][ks],
                                                                            (q == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
         }
         if (last) {
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
+          for (int rt = 0; rt < RT; ++rt) {
             const int row = row0 + rbase + rt * 16 + li_e;
             const unsigned int rowh = drop_row(dkey2, (unsigned int)row);
 #pragma unroll
@@ -857,11 +874,13 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
         // counted wait (mlp_fused_kernel's): h stores of the previous chunk's tail (4, behind the barrier of chunks 1, 5,
         // 9, 13), the 4 loads of chunk c + 2, this chunk's stores; first MLP chunk: the 4 image stores at the head of the
         // last o chunk and the 28 stores of the x1 / LN2 stage (16 + 8 + 4) are younger than the loads of chunk c + 1
-        constexpr int st_prev = (cm & 3) == 2 ? 4 : 0;
-        constexpr int st_this = cm == 0 ? 32 : cm == 14 ? 24 : 0;
+        // (in units of this form's per-thread counts: HI h stores, 2 SI image stores, 8 RT x1 stores, 4 RT + 4 RT y rows, 2 RT
+        //  statistics, 4 RT residual loads + 8 RT x2 stores: 4 | 32 | 24 in the two-row-tile forms)
+        constexpr int st_prev = (cm & 3) == 2 ? HI : 0;
+        constexpr int st_this = cm == 0 ? 2 * SI + 8 * RT + 4 * RT + 2 * RT : cm == 14 ? 12 * RT : 0;
         constexpr int allowed = st_prev + (c + 2 < NCH ? LD : 0) + st_this;
         if (c + 1 < NCH) {
-          if (cm == 0 && XHAT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed + 8) : "memory");      // (16 x-hat stores, not 8 y rows)
+          if (cm == 0 && XHAT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed + 4 * RT) : "memory");      // (8 RT x-hat stores, not 4 RT y rows)
           else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
           __builtin_amdgcn_s_barrier();
         }
@@ -870,16 +889,16 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void attn_block_fwd_kernel(AttnBl
         int tid_h = tid_m;      // (opaque per quarter: the four store addresses are not kept across the quarters)
         asm volatile("" : "+v"(tid_h));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < HI; ++i) {
           const int idx = tid_h + NT * i, r = idx >> 4, c16 = idx & 15;
           __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(Hs + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_h,
                                                  (unsigned int)(row0 + rb + r) * (AB_F * 2) + c16 * 16 + q * 256, 0, 0);
         }
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks)
-            hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (rp * 32 + rt * 16 + li_m) * 256 + xs_m[ks]);
+            hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (lb + rt * 16 + li_m) * 256 + xs_m[ks]);
       }
       AB_TR(22 + cm);
     };
@@ -910,8 +929,10 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 64, true>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 64, true>, AB_LDS_MLP);
-    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 128, true, true>, AB_LDS_MLP);
-    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true, true>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 128, true, 1>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true, 1>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 128, true, 2>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true, 2>, AB_LDS_MLP);
     if (e != hipSuccess) {
       mfp_set_error("mfp_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS_MLP, hipGetErrorString(e));
       return MFP_ELAUNCH;
@@ -922,10 +943,15 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
   const dim3 grid(tiles), blk(512);
   if (p.xhat) {       // (mfp_block_fwd_xhat: the whole-block training forms)
     if (!mlp || !p.stash) { mfp_set_error("mfp_block_fwd_xhat: whole-block training form only"); return MFP_EINVAL; }
-    if (p.xhat == 2) {      // mfp_block_fwd_xhat_half: two four-wave workgroups per document
+    if (p.xhat == 2 || p.xhat == 3) {      // mfp_block_fwd_xhat_half: two workgroups per document (four waves | eight waves, one row tile each)
       if (S != AB_ROWS) { mfp_set_error("mfp_block_fwd_xhat_half: documents of 128 positions"); return MFP_EINVAL; }
-      if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 128, true, true>), dim3(2 * tiles), dim3(256), AB_LDS_MLP, st, p);
-      else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 128, true, true>), dim3(2 * tiles), dim3(256), AB_LDS_MLP, st, p);
+      if (p.xhat == 3) {
+        if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 128, true, 2>), dim3(2 * tiles), dim3(512), AB_LDS_MLP, st, p);
+        else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 128, true, 2>), dim3(2 * tiles), dim3(512), AB_LDS_MLP, st, p);
+      } else {
+        if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 128, true, 1>), dim3(2 * tiles), dim3(256), AB_LDS_MLP, st, p);
+        else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 128, true, 1>), dim3(2 * tiles), dim3(256), AB_LDS_MLP, st, p);
+      }
       return MFP_OK;
     }
     if (S == 64) {
@@ -1041,18 +1067,19 @@ extern "C" int mfp_block_fwd_xhat(const float* x, const float* gamma, const floa
                         xhat2, mean2, rstd2, h, x2, x2_bf16, B, S, D, H, eps, dropout_p, seed, offset_attn, offset_mlp, step_ptr, stream);
 }
 
-// mfp_block_fwd_xhat on HALF-document tiles: two four-wave workgroups per document (64 query rows each, the other half's K / V
-// recomputed), for batches with fewer documents than CUs (BASELINE config c4: 128 documents per GPU).  S = 128 only; results
-// are bit-identical to mfp_block_fwd_xhat.
+// mfp_block_fwd_xhat on HALF-document tiles: two workgroups per document (64 query rows each, the other half's K / V
+// recomputed), for batches with fewer documents than CUs (BASELINE config c4: 128 documents per GPU).  `waves` = 4 (a wave owns two
+// row tiles, one wave per SIMD) or 8 (one row tile per wave, two waves per SIMD).  S = 128 only; results are bit-identical to
+// mfp_block_fwd_xhat.
 extern "C" int mfp_block_fwd_xhat_half(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
                                        const void* Wo, const float* bo, const int32_t* nvalid, void* xhat1, float* mean, float* rstd,
                                        void* qkv, void* a, float* lse, float* x1, const float* gamma2, const float* beta2,
                                        const void* W1, const float* b1, const void* W2, const float* b2, void* xhat2, float* mean2,
                                        float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
                                        float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
-                                       const int32_t* step_ptr, mfp_stream_t stream) {
-  MFP_CHECK_ARG(S == AB_ROWS);
-  return block_fwd_impl(2, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, xhat1, mean, rstd, qkv, a, lse, x1, gamma2, beta2, W1, b1, W2, b2,
+                                       const int32_t* step_ptr, int32_t waves, mfp_stream_t stream) {
+  MFP_CHECK_ARG(S == AB_ROWS && (waves == 4 || waves == 8));
+  return block_fwd_impl(waves == 8 ? 3 : 2, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, xhat1, mean, rstd, qkv, a, lse, x1, gamma2, beta2, W1, b1, W2, b2,
                         xhat2, mean2, rstd2, h, x2, x2_bf16, B, S, D, H, eps, dropout_p, seed, offset_attn, offset_mlp, step_ptr, stream);
 }
 

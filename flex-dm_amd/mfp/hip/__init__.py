@@ -101,7 +101,7 @@ SIGNATURES = {
     "mfp_attn_block_fwd": (c_int32, [c_void_p] * 15 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_block_fwd": (c_int32, [c_void_p] * 27 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_block_fwd_xhat": (c_int32, [c_void_p] * 27 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
-    "mfp_block_fwd_xhat_half": (c_int32, [c_void_p] * 27 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "mfp_block_fwd_xhat_half": (c_int32, [c_void_p] * 27 + [c_int32] * 4 + [c_float, c_float, c_uint64, c_uint64, c_uint64, c_void_p, c_int32, c_void_p]),
     "mfp_block_infer": (c_int32, [c_void_p] * 17 + [c_int32] * 4 + [c_float, c_void_p]),
     "mfp_ln_dense_d512": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_float, c_void_p]),
     "mfp_ln_dense_d512_xhat": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_float, c_void_p]),

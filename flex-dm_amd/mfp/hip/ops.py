@@ -427,13 +427,18 @@ def attn_block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, B: int, S: int, H
     return x1, y1, mean, rstd, qkv, a, lse
 
 
+# waves per half-document workgroup of mfp_block_fwd_xhat_half (4: two row tiles per wave; 8: one) -- A/B switch
+HALF_WAVES = int(os.environ.get("MFP_BLOCK_HALF_WAVES", "8"))
+
+
 def block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1, W2, b2, B: int, S: int, H: int,
               p: float, seed: int, off_attn: int, off_mlp: int, step_ptr=None, x2_c=None, xhat_stash: bool = False,
               half_tiles: bool = False):
     """A whole DeepSVG block forward in ONE launch (see mfp_block_fwd): returns
     (x2, (y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)) -- the tensors the separate launches save.
     ``xhat_stash``: y1 / y2 hold x-hat = (x - mean) rstd instead of the LayerNorm outputs (mfp_block_fwd_xhat);
-    ``half_tiles`` (with xhat_stash, S = 128): two workgroups per document (mfp_block_fwd_xhat_half), bit-identical results."""
+    ``half_tiles`` (with xhat_stash, S = 128): two workgroups per document (mfp_block_fwd_xhat_half), bit-identical results;
+    True = MFP_BLOCK_HALF_WAVES waves per workgroup, 4 / 8 = that many."""
     assert not half_tiles or (xhat_stash and S == 128)
     lib = load()
     T, D = x.shape
@@ -448,11 +453,15 @@ def block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1,
     flops = 2 * T * D * 3 * D + 4 * B * S * S * D + 2 * T * D * D + 2 * 2 * T * D * 2 * D
     nbytes = T * (D * 4 * 5 + D * 2 * 3 + 3 * D * 2 + 2 * D * 2) + 8 * D * D * 2
     with _timed("block_fwd_kernel", flops, nbytes):
-        check((lib.mfp_block_fwd_xhat_half if half_tiles else lib.mfp_block_fwd_xhat if xhat_stash else lib.mfp_block_fwd)(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(Wqkv), _ptr(bqkv), _ptr(Wo), _ptr(bo), _ptr(nvalid),
-                                _ptr(y1), _ptr(mean1), _ptr(rstd1), _ptr(qkv), _ptr(a), _ptr(lse), _ptr(x1), _ptr(gamma2), _ptr(beta2),
-                                _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(y2), _ptr(mean2), _ptr(rstd2), _ptr(h), _ptr(x2), _ptr(x2_c),
-                                B, S, D, H, LN_EPS, float(p), int(seed), int(off_attn), int(off_mlp),
-                                _ptr(step_ptr) if step_ptr is not None else None, _stream()), "mfp_block_fwd")
+        args = (_ptr(x), _ptr(gamma), _ptr(beta), _ptr(Wqkv), _ptr(bqkv), _ptr(Wo), _ptr(bo), _ptr(nvalid),
+                _ptr(y1), _ptr(mean1), _ptr(rstd1), _ptr(qkv), _ptr(a), _ptr(lse), _ptr(x1), _ptr(gamma2), _ptr(beta2),
+                _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(y2), _ptr(mean2), _ptr(rstd2), _ptr(h), _ptr(x2), _ptr(x2_c),
+                B, S, D, H, LN_EPS, float(p), int(seed), int(off_attn), int(off_mlp),
+                _ptr(step_ptr) if step_ptr is not None else None)
+        if half_tiles:
+            check(lib.mfp_block_fwd_xhat_half(*args, int(half_tiles) if int(half_tiles) in (4, 8) else HALF_WAVES, _stream()), "mfp_block_fwd_xhat_half")
+        else:
+            check((lib.mfp_block_fwd_xhat if xhat_stash else lib.mfp_block_fwd)(*args, _stream()), "mfp_block_fwd")
     return x2, (y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
 
 

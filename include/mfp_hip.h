@@ -216,7 +216,8 @@ int mfp_block_fwd_xhat(const float* x, const float* gamma, const float* beta, co
                   const int32_t* step_ptr, mfp_stream_t stream);
 /* mfp_block_fwd_xhat on HALF-document tiles: two four-wave workgroups per document (64 query rows each; the other half's K / V
  * are recomputed in the workgroup, nothing is exchanged), for batches with fewer documents than the device has CUs (BASELINE
- * config 4's per-GPU share: 128 documents).  S = 128 only.  Same arguments, same saved tensors, results bit-identical to
+ * config 4's per-GPU share: 128 documents).  S = 128 only.  `waves`: 4 (a wave owns two 16-row tiles, one wave per SIMD) or 8 (one
+ * row tile per wave, two waves per SIMD).  Otherwise the same arguments, same saved tensors, results bit-identical to
  * mfp_block_fwd_xhat. */
 int mfp_block_fwd_xhat_half(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
                   const void* Wo, const float* bo, const int32_t* nvalid, void* xhat1, float* mean, float* rstd,
@@ -224,7 +225,7 @@ int mfp_block_fwd_xhat_half(const float* x, const float* gamma, const float* bet
                   const void* W1, const float* b1, const void* W2, const float* b2, void* xhat2, float* mean2,
                   float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
                   float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
-                  const int32_t* step_ptr, mfp_stream_t stream);
+                  const int32_t* step_ptr, int32_t waves, mfp_stream_t stream);
 
 /* --------------------------------------------------------------------------- Dense layers of a block at d_model 512
  * (csrc/block_d512.hip; BASELINE config 5 = Crello Ours-EXP-FT: reference args.py:29-38 --latent_dim 512 --num_blocks 8;

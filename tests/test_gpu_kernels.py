@@ -1491,14 +1491,16 @@ def test_block_fwd(B, p):
         assert (xh != want.to(DEV, torch.float32).to(bf)).float().mean().item() < 2e-3, what
     # mfp_block_fwd_xhat_half: two four-wave workgroups per document (the other half's K / V recomputed) -- every output of the
     # x-hat form bit for bit (the same instruction sequence on the same operands produces every value)
-    x2c_h = torch.zeros(T, D, dtype=bf, device=DEV)
-    x2h, saved_h = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H, p, 7, 3, 4, step, x2_c=x2c_h,
-                                 xhat_stash=True, half_tiles=True)
-    names = ("xhat1", "mean1", "rstd1", "qkv", "a", "lse", "x1", "xhat2", "mean2", "rstd2", "h")
-    assert torch.equal(x2h, x2x), "half tiles: x2"
-    assert torch.equal(x2c_h.view(torch.int16), x2c.view(torch.int16)), "half tiles: x2 bf16"
-    for name, got, want in zip(names, saved_h, (xh1, m1x, r1x, qkvx, ax, lsex, x1x, xh2, m2x, r2x, hx)):
-        assert torch.equal(got, want), "half tiles: " + name
+    # (4 waves: two row tiles per wave, one wave per SIMD; 8 waves: one row tile per wave, one (query tile, head) per wave)
+    for waves in (4, 8):
+        x2c_h = torch.zeros(T, D, dtype=bf, device=DEV)
+        x2h, saved_h = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H, p, 7, 3, 4, step, x2_c=x2c_h,
+                                     xhat_stash=True, half_tiles=waves)
+        names = ("xhat1", "mean1", "rstd1", "qkv", "a", "lse", "x1", "xhat2", "mean2", "rstd2", "h")
+        assert torch.equal(x2h, x2x), "half tiles (%d waves): x2" % waves
+        assert torch.equal(x2c_h.view(torch.int16), x2c.view(torch.int16)), "half tiles (%d waves): x2 bf16" % waves
+        for name, got, want in zip(names, saved_h, (xh1, m1x, r1x, qkvx, ax, lsex, x1x, xh2, m2x, r2x, hx)):
+            assert torch.equal(got, want), "half tiles (%d waves): %s" % (waves, name)
 
 
 # ------------------------------------------------------------------------------------ d_model 512 (csrc/block_d512.hip)

@@ -67,8 +67,9 @@ if "block" in which:
     timeit("block_fwd_xhat", lambda: ops.block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8, 0.1, 5, 3, 4, step, xhat_stash=True),
            T * (256 * 4 * 5 + 256 * 2 * 3 + 768 * 2 + 512 * 2))
     # two four-wave workgroups per document (fewer documents than CUs: T=16384 is config c4's per-GPU share)
-    timeit("block_fwd_xhat_half", lambda: ops.block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8, 0.1, 5, 3, 4, step, xhat_stash=True, half_tiles=True),
-           T * (256 * 4 * 5 + 256 * 2 * 3 + 768 * 2 + 512 * 2))
+    for wv in (4, 8):
+        timeit("block_fwd_xhat_half (%d waves)" % wv, lambda: ops.block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8, 0.1, 5, 3, 4, step, xhat_stash=True, half_tiles=wv),
+               T * (256 * 4 * 5 + 256 * 2 * 3 + 768 * 2 + 512 * 2))
     # the inference form (nothing saved): what the in-CU pipeline does when only x1 / x2 cross HBM
     timeit("block_infer (1 launch)", lambda: ops.block_infer(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8),
            T * 256 * 4 * 5)

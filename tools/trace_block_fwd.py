@@ -6,7 +6,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "flex-dm_amd")]
 import torch
 from mfp.hip import ops
 T, D = int(os.environ.get("T", 32768)), 256; B = T // 128; dev = "cuda"
-HALF = os.environ.get("HALF", "0") == "1"      # mfp_block_fwd_xhat_half: two four-wave workgroups per document
+HALF = int(os.environ.get("HALF", "0"))      # mfp_block_fwd_xhat_half: two workgroups per document, HALF = 4 / 8 waves each (1 = 4)
+HALF = 4 if HALF == 1 else HALF
 rnd = lambda *s: torch.randn(*s, device=dev).to(torch.bfloat16)
 x = torch.randn(T, D, device=dev)
 gam, bet = torch.rand(D, device=dev) + 0.5, torch.randn(D, device=dev)
@@ -21,7 +22,7 @@ for _ in range(3):
     ops.block_fwd(x, gam, bet, Wq, bq, Wo, bo, nvalid, g2, be2, W1, b1, W2, b2, B, 128, 8, 0.1, 5, 3, 4, step, x2_c=x2c,
                   xhat_stash=True, half_tiles=HALF)
 torch.cuda.synchronize()
-tr = x2c.view(torch.int64).view(-1)[:B * 512].view((2 * B, 4, 64) if HALF else (B, 8, 64)).cpu().double()
+tr = x2c.view(torch.int64).view(-1)[:B * 512 * (2 if HALF == 8 else 1)].view((2 * B, HALF, 64) if HALF else (B, 8, 64)).cpu().double()
 rel = tr - tr[:, :, :1].min(dim=1, keepdim=True).values
 names = {0: "start", 1: "x landed", 2: "LN1 done, y1 out"}
 for c in range(16):
