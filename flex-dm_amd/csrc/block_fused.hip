@@ -549,15 +549,26 @@ struct MlpBwdParams {
 };
 
 // LNB: 0 = dy2 leaves as bf16 rows; 1 = LN2 backward in the epilogue from x1 (f32); 2 = from the x-hat stash (bf16)
-template <int LNB>
+// HT (round 5): HALF tiles -- two workgroups per 128-row tile, 64 rows each, a wave owns ONE 16-row tile (wave = (rp, nh, rtw): the
+// two waves of a SIMD hold the two row tiles of a row pair), for batches with fewer 128-row tiles than CUs (BASELINE config c4);
+// the same per-row arithmetic, per-thread store counts halved in the counted waits, the LayerNorm-backward epilogue walks 8 rows
+// per wave and leaves one partial row per HALF tile (the csrc/block_attn.hip HALF == 2 form of this machine)
+template <int LNB, bool HT = false>
 __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
+  static_assert(!HT || LNB == 2, "half tiles: the x-hat form");
+  constexpr int RT = HT ? 1 : 2;                 // row tiles per wave
+  constexpr int ROWS = HT ? 64 : MLP_ROWS;
+  constexpr int SI = ROWS * 16 / 512;            // 16-byte pieces per thread of a [ROWS][256 B] image
+  constexpr int HP = HT ? 4 : 8;                 // 1 KB pieces per h wave and quarter
+  constexpr int NR = ROWS / 8;                   // rows per wave in the LayerNorm-backward epilogue
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Hs = smem;
   unsigned char* const Ws = smem + MLP_HS_B;
   unsigned char* const Hm = smem + MLP_HS_B + 3 * MLP_WS_B;      // saved h of the quarter (ReLU mask), own 32 KB image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int rp = wave & 3, nh = wave >> 2;
-  const int row0 = blockIdx.x * MLP_ROWS;
+  const int rp = HT ? (wave & 1) : (wave & 3), nh = HT ? ((wave >> 1) & 1) : (wave >> 2);
+  const int lb = rp * 32 + (HT ? (wave >> 2) * 16 : 0);      // first local row of this wave's row tile(s)
+  const int row0 = blockIdx.x * ROWS;
   const unsigned int xbytes = (unsigned int)p.T * (MLP_D * 2), hbytes = (unsigned int)p.T * (MLP_F * 2);
   const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W2t), 0, MLP_F * MLP_D * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.W1t), 0, MLP_F * MLP_D * 2, 0x00020000);
@@ -593,12 +604,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
     }
   };
   // h quarter q -> image [128][256 B]: the row / slot pattern of a W "2" chunk, on the 1 KB rows of h
-  const unsigned int hoff = (unsigned int)((row0 + wl * 32 + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
+  const unsigned int hoff = (unsigned int)((row0 + wl * (HP * 4) + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
   auto hload = [&](int q) {
     if (wv < 4) return;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_u8*)(Hm + wl * 8192 + i * 1024), 16, hoff ^ ((i & 3) << 6), q * 256 + i * 4096, 0, 0);
+    for (int i = 0; i < HP; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_u8*)(Hm + wl * (HP * 1024) + i * 1024), 16, hoff ^ ((i & 3) << 6), q * 256 + i * 4096, 0, 0);
   };
   MLP_STAMP(0);
   wload(0);
@@ -606,16 +617,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   // operand fragments of d_o2: lane (li, g) holds row li of the tile, columns 32 ks + 8 g .. + 7
   bf16x8 xf[2][8];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
       xf[rt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-          rs_do, (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (MLP_D * 2) + g * 16 + ks * 64, 0, 0));
+          rs_do, (unsigned int)(row0 + lb + rt * 16 + li) * (MLP_D * 2) + g * 16 + ks * 64, 0, 0));
   // the first h quarter is needed at the END of chunk 0 (its epilogue) only: it stays in flight across this
   // barrier (first touched since the forward pass: HBM latency) and is waited for in front of that epilogue
   hload(0);
   MLP_STAMP(1);
-  if (wv < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // chunks 0, 1 landed (older than the 16 fragment loads)
+  if (wv < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * RT) : "memory");      // chunks 0, 1 landed (older than the 8 RT fragment loads)
   __builtin_amdgcn_s_barrier();
   MLP_STAMP(2);
 
@@ -627,9 +638,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 
   // LNB: the x1 rows of the LN2-backward epilogue (wave w: rows 16 w .. + 15, a lane 4 columns) are requested at the head of
   // chunk 14 -- the d_o2 fragments are dead by then, the 64 registers change hands -- and cross the last two chunks in flight
-  constexpr int LN_PF = LNB ? 16 : 0;
-  f32x4 xv[16];      // (dead registers in the other forms)
-  u32x2 xhv[16];
+  constexpr int LN_PF = LNB ? NR : 0;
+  f32x4 xv[NR];      // (dead registers in the other forms)
+  u32x2 xhv[NR];
   const __amdgpu_buffer_rsrc_t rs_x = LNB == 2 ? ln_tile_xh_rsrc(p.ln, p.T) : ln_tile_x_rsrc(p.ln, LNB ? p.T : 0);
   auto chunk = [&](auto cc_) {
     constexpr int c = decltype(cc_)::value;
@@ -660,7 +671,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
             acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], xf[rt][ks], acc[nt][rt], 0, 0, 0);
       }
       if (c == 0) {      // the first h quarter (waves 4-7 issued it in the prologue) must be in LDS now
@@ -670,8 +681,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const int slot = (rp * 32 + rt * 16 + li) * 256 + (((j * 8 + (nh * 2 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8;
+        for (int rt = 0; rt < RT; ++rt) {
+          const int slot = (lb + rt * 16 + li) * 256 + (((j * 8 + (nh * 2 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8;
           const u32x2 hv = *reinterpret_cast<const u32x2*>(Hm + slot);      // 4 bf16 of h: positive <=> nonzero, sign clear
           const bool m0 = (short)(hv[0] & 0xFFFFu) > 0, m1 = (int)hv[0] >= 0x10000;
           const bool m2 = (short)(hv[1] & 0xFFFFu) > 0, m3 = (int)hv[1] >= 0x10000;
@@ -693,7 +704,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
             acc2[j * 4 + nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nt], hf[rt][ks],
                                                                          (q == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc2[j * 4 + nt][rt], 0, 0, 0);
       }
@@ -705,16 +716,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           const u32x2 pk = {pack_bf16x2(acc2[j * 4 + nt][rt][0], acc2[j * 4 + nt][rt][1]), pack_bf16x2(acc2[j * 4 + nt][rt][2], acc2[j * 4 + nt][rt][3])};
-          *reinterpret_cast<u32x2*>(img + (rp * 32 + rt * 16 + li) * 256 + ((((nh * 4 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = pk;
+          *reinterpret_cast<u32x2*>(img + (lb + rt * 16 + li) * 256 + ((((nh * 4 + nt) * 2 + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = pk;
         }
     }
     // end of chunk.  Weight waves: chunk c + 1 has landed when at most the 8 loads of chunk c + 2 and the stores
     // issued behind the previous barrier (dh: 4, chunks 2, 6, 10, 14; dy2 of chunk 14: 4) are younger.  h waves: the
     // next h quarter must be there at the end of a quarter's last chunk; otherwise nothing to wait for
     {
-      constexpr int st_prev = ((c & 3) == 2 || (c == MLP_CHUNKS - 1 && !LNB)) ? 4 : 0;
+      constexpr int st_prev = ((c & 3) == 2 || (c == MLP_CHUNKS - 1 && !LNB)) ? SI : 0;
       constexpr int allowed_w = st_prev + (c + 2 < MLP_CHUNKS ? 8 : 0) + (c >= MLP_CHUNKS - 2 ? LN_PF : 0);
       constexpr bool h_due = (c & 3) == 3 && q < 3;
       if (wv < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
@@ -726,21 +737,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
     if (!ffn2 && j == 1) {
       // dh quarter complete in LDS: write it out in 256-byte row pieces and pick up this wave's operand fragments
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < SI; ++i) {
         const int idx = tid + 512 * i, r = idx >> 4, c16 = idx & 15;
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(Hs + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_dh,
                                                (unsigned int)(row0 + r) * (MLP_F * 2) + c16 * 16 + q * 256, 0, 0);
       }
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-          hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (rp * 32 + rt * 16 + li) * 256 + xs[ks]);
+          hf[rt][ks] = *reinterpret_cast<const bf16x8*>(Hs + (lb + rt * 16 + li) * 256 + xs[ks]);
     }
     if (c >= MLP_CHUNKS - 2 && !LNB) {
       const unsigned char* img = Ws + (c % 3) * MLP_WS_B;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < SI; ++i) {
         const int idx = tid + 512 * i, r = idx >> 4, c16 = idx & 15;
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(img + r * 256 + ((c16 ^ (r & 15)) << 4)), rs_dy,
                                                (unsigned int)(row0 + r) * (MLP_D * 2) + c16 * 16 + j * 256, 0, 0);
@@ -1420,6 +1431,50 @@ extern "C" int mfp_mlp_bwd_ln(const void* d_o2, const void* h, const void* W2t, 
   }
   if (xhat != nullptr) hipLaunchKernelGGL(mlp_bwd_kernel<2>, dim3(T / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(mlp_bwd_kernel<1>, dim3(T / MLP_ROWS), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+// mfp_mlp_bwd_ln (x-hat form) on HALF tiles: two workgroups per 128-row tile (64 rows each, one 16-row tile per wave), for
+// batches with fewer 128-row tiles than CUs (BASELINE config c4).  `part` holds T / 64 rows of [3][256].  dh bit-identical to
+// mfp_mlp_bwd_ln, dx / ddrop too; the partial rows sum to the same parameter gradients in another grouping.
+extern "C" int mfp_mlp_bwd_ln_half(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, const void* xhat,
+                                   const float* gamma, const float* rstd, const void* dres, void* dx, void* ddrop, float* part,
+                                   size_t part_bytes, int32_t T, int32_t D, float drop_p, uint64_t seed, uint64_t offset,
+                                   const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(d_o2 && h && W2t && W1t && dh && xhat && gamma && rstd && dres && dx && ddrop && part);
+  MFP_CHECK_ARG(T > 0 && T % MLP_ROWS == 0 && T <= (1 << 21) && D == MLP_D && drop_p >= 0.f && drop_p < 1.f);
+  MFP_CHECK_ARG(((uintptr_t)d_o2 % 16) == 0 && ((uintptr_t)h % 16) == 0 && ((uintptr_t)W2t % 16) == 0 && ((uintptr_t)W1t % 16) == 0 &&
+                ((uintptr_t)dh % 16) == 0 && ((uintptr_t)xhat % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)dres % 16) == 0 &&
+                ((uintptr_t)dx % 16) == 0 && ((uintptr_t)ddrop % 16) == 0);
+  if (part_bytes < (size_t)(T / 64) * 3 * MLP_D * sizeof(float)) {
+    mfp_set_error("mfp_mlp_bwd_ln_half: partial-sum buffer too small");
+    return MFP_EWORKSPACE;
+  }
+  MlpBwdParams p = {};
+  p.d_o2 = reinterpret_cast<const unsigned short*>(d_o2); p.h = reinterpret_cast<const unsigned short*>(h);
+  p.W2t = reinterpret_cast<const unsigned short*>(W2t); p.W1t = reinterpret_cast<const unsigned short*>(W1t);
+  p.dh = reinterpret_cast<unsigned short*>(dh); p.dy2 = nullptr;
+  p.T = T;
+#ifdef MFP_GEMM_TRACE
+  p.trace = g_mlp_trace;
+#endif
+  p.ln.x = nullptr; p.ln.xhat = reinterpret_cast<const unsigned short*>(xhat); p.ln.gamma = gamma; p.ln.mean = nullptr; p.ln.rstd = rstd;
+  p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
+  p.ln.dx = reinterpret_cast<unsigned short*>(dx); p.ln.ddrop = reinterpret_cast<unsigned short*>(ddrop); p.ln.part = part;
+  p.ln.drop_p = drop_p; p.ln.seed = seed; p.ln.offset = offset; p.ln.step_ptr = step_ptr;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  constexpr int lds = 2 * MLP_HS_B + 3 * MLP_WS_B;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_mlp_bwd_ln_half: cannot raise dynamic LDS to %d: %s", lds, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((mlp_bwd_kernel<2, true>), dim3(T / 64), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -31,46 +31,49 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ln_tile_x_rsrc(const LnTileArg
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ln_tile_xh_rsrc(const LnTileArgs& q, int T) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(q.xhat), 0, (unsigned int)T * 512u, 0x00020000);
 }
-__device__ __forceinline__ void ln_tile_load_xh(const __amdgpu_buffer_rsrc_t rs_xh, int row0, int wv, int lane, u32x2 (&xv)[16]) {
+template <int NR>
+__device__ __forceinline__ void ln_tile_load_xh(const __amdgpu_buffer_rsrc_t rs_xh, int row0, int wv, int lane, u32x2 (&xv)[NR]) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    xv[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xh, (unsigned int)(row0 + wv * 16 + i) * 512u + lane * 8, 0, 0));
+  for (int i = 0; i < NR; ++i)
+    xv[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xh, (unsigned int)(row0 + wv * NR + i) * 512u + lane * 8, 0, 0));
 }
 
 // the x rows of wave `wv` (may be issued early by the caller: 64 registers in flight)
-__device__ __forceinline__ void ln_tile_load_x(const __amdgpu_buffer_rsrc_t rs_x, int row0, int wv, int lane, f32x4 (&xv)[16]) {
+template <int NR>
+__device__ __forceinline__ void ln_tile_load_x(const __amdgpu_buffer_rsrc_t rs_x, int row0, int wv, int lane, f32x4 (&xv)[NR]) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)(row0 + wv * 16 + i) * 1024u + lane * 16, 0, 0));
+  for (int i = 0; i < NR; ++i)
+    xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)(row0 + wv * NR + i) * 1024u + lane * 16, 0, 0));
 }
 
 // dy_of(r) = the 4 bf16 values (u32x2) of tile row r at this lane's columns 4 lane .. + 3; red = 24 KB of free LDS; every wave
 // of the 512-thread workgroup calls it (one __syncthreads inside)
-// XT = f32x4 (x rows) or u32x2 (x-hat rows, bf16)
-template <typename XT, typename DyOf>
+// XT = f32x4 (x rows) or u32x2 (x-hat rows, bf16); NR = rows per wave: 16 (a 128-row tile) or 8 (a 64-row half tile: `tile`
+// then counts half tiles and `part` holds T / 64 rows)
+template <typename XT, typename DyOf, int NR>
 __device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0, int tile, int wv, int lane, int tid,
-                                            const XT (&xv)[16], DyOf dy_of, float* red) {
+                                            const XT (&xv)[NR], DyOf dy_of, float* red) {
   constexpr bool XH = sizeof(XT) == 8;
   constexpr int D = 256;
   const unsigned int rbytes = (unsigned int)T * (D * 2);
   const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(q.dres), 0, rbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc(q.dx, 0, rbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc(q.ddrop ? q.ddrop : q.dx, 0, q.ddrop ? rbytes : 0u, 0x00020000);
-  const int r0 = wv * 16;
-  u32x2 rv[16];
+  const int r0 = wv * NR;
+  u32x2 rv[NR];
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < NR; ++i)
     rv[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dr, (unsigned int)(row0 + r0 + i) * (D * 2) + lane * 8, 0, 0));
   const f32x4 gam = *reinterpret_cast<const f32x4*>(q.gamma + lane * 4);
   // the 16 rows' statistics in lanes 0..15, broadcast per row by v_readlane
   float mu_l = 0.f, rs_l = 0.f;
-  if (lane < 16 && row0 + r0 + lane < T) { mu_l = XH ? 0.f : q.mean[row0 + r0 + lane]; rs_l = q.rstd[row0 + r0 + lane]; }
+  if (lane < NR && row0 + r0 + lane < T) { mu_l = XH ? 0.f : q.mean[row0 + r0 + lane]; rs_l = q.rstd[row0 + r0 + lane]; }
   const unsigned long long rng_off = q.offset + (q.step_ptr ? (unsigned long long)(*q.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
   const float inv_keep = q.drop_p > 0.f ? 1.f / (1.f - q.drop_p) : 1.f;
   const unsigned int dkey = drop_key(q.seed, rng_off), dthr = drop_thr16(q.drop_p);
   float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < NR; ++i) {
     const int r = r0 + i, row = row0 + r;
     const bool live = row < T;
     const float mu = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mu_l), i));

@@ -92,6 +92,16 @@ FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 3
 BLOCK_HALF = os.environ.get("MFP_BLOCK_HALF", "")
 
 
+# ... and the MLP half's input-gradient launch (+ LN2 backward) on half tiles (mfp_mlp_bwd_ln_half); unset: as above
+MLP_BWD_HALF = os.environ.get("MFP_MLP_BWD_HALF", "")
+
+
+def _mlp_bwd_half_on(ctx, T: int) -> bool:
+    if MLP_BWD_HALF != "":
+        return MLP_BWD_HALF == "1"
+    return 2 * (T // 128) <= ops.cu_count(ctx.store.w.device)
+
+
 def _block_half_on(ctx, B: int, S: int) -> bool:
     if S != 128:
         return False
@@ -608,7 +618,7 @@ class BlockFn(torch.autograd.Function):
             dh, dx1, d_o1 = ops.mlp_bwd_ln(d_o2, h, wt, wt0, x1, st.weight(p + "norm2/gamma"), mean2, rstd2, dx2,
                                            st.grad(p + "norm2/gamma"), st.grad(p + "norm2/beta"),
                                            (st.grad(p + "attn/combine_heads/bias"), ctx.p, ctx.seed, 2 * i + 1, ctx.step_ptr),
-                                           jobs=ctx.ln_jobs, xhat=xh2)
+                                           jobs=ctx.ln_jobs, xhat=xh2, half_tiles=xh2 is not None and _mlp_bwd_half_on(ctx, T))
             ln_fused = True
         elif fused_bwd:      # both input-gradient products of the half in one launch (csrc/block_fused.hip)
             dh, dy2 = ops.mlp_fused_bwd(d_o2, h, wt, wt0)

@@ -701,12 +701,14 @@ def mlp_fused_bwd(d_o2, h, W2t, W1t):
     return dh, dy2
 
 
-def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, drop, jobs: Optional[list] = None, xhat=None):
+def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, drop, jobs: Optional[list] = None, xhat=None,
+               half_tiles: bool = False):
     """:func:`mlp_fused_bwd` with the backward of LN2 in its epilogue (``mfp_mlp_bwd_ln``; bf16 residual-gradient stream):
     returns (dh, dx, ddrop) -- what ``mlp_fused_bwd`` + ``layernorm_bwd(dy2, x, ..., dres, drop=drop)`` return, dy2 never
     written.  ``drop`` = (colsum_out [D], p, seed, offset, step_ptr); ``jobs``: the parameter-gradient partials (one row per
     128-row tile) join the batched reduction at the end of the backward pass, else they are reduced here.  ``xhat``: the bf16
-    stash (x - mean) rstd of ``block_fwd(xhat_stash=True)`` -- x and mean are then not read."""
+    stash (x - mean) rstd of ``block_fwd(xhat_stash=True)`` -- x and mean are then not read.  ``half_tiles`` (x-hat form):
+    two workgroups per 128-row tile (mfp_mlp_bwd_ln_half), one partial row per half tile."""
     lib = load()
     T, D = d_o2.shape
     dev = d_o2.device
@@ -714,10 +716,16 @@ def mlp_bwd_ln(d_o2, h, W2t, W1t, x, gamma, mean, rstd, dres, dgamma, dbeta, dro
     dx = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
     ddrop = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
     colsum, p_, seed_, off_, sp_ = drop
-    P = T // 128
+    assert not half_tiles or xhat is not None
+    P = T // 64 if half_tiles else T // 128
     part = torch.empty((P, 3 * D), dtype=torch.float32, device=dev)
     with _timed("mlp_bwd_kernel", 2 * 2 * T * D * 2 * D, T * (D * 2 + 2 * D * 2 * 2 + D * (4 + 2 + 2 + 2)) + 2 * D * 2 * D * 2):
-        check(lib.mfp_mlp_bwd_ln(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(x), _ptr(xhat), _ptr(gamma), _ptr(mean),
+        if half_tiles:
+            check(lib.mfp_mlp_bwd_ln_half(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(xhat), _ptr(gamma), _ptr(rstd),
+                                          _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part), part.numel() * 4, T, D, float(p_),
+                                          int(seed_), int(off_), _ptr(sp_), _stream()), "mfp_mlp_bwd_ln_half")
+        else:
+          check(lib.mfp_mlp_bwd_ln(_ptr(d_o2), _ptr(h), _ptr(W2t), _ptr(W1t), _ptr(dh), _ptr(x), _ptr(xhat), _ptr(gamma), _ptr(mean),
                                  _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop), _ptr(part), part.numel() * 4, T, D, float(p_),
                                  int(seed_), int(off_), _ptr(sp_), _stream()), "mfp_mlp_bwd_ln")
     if jobs is not None:

@@ -318,6 +318,13 @@ int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void* qkv, const
                        const int32_t* nvalid, const void* Wqkvt, void* dqkv, void* dy1, int32_t B, int32_t S,
                        int32_t D, int32_t H, mfp_stream_t stream);
 
+/* mfp_mlp_bwd_ln (x-hat form) on HALF tiles: two workgroups per 128-row tile, 64 rows each, one 16-row tile per wave -- for
+ * batches with fewer 128-row tiles than the device has CUs (BASELINE config 4's per-GPU share).  `part`: T / 64 rows of [3][256].
+ * dh, dx, ddrop bit-identical to mfp_mlp_bwd_ln; the partial rows sum to the same parameter gradients in another grouping. */
+int mfp_mlp_bwd_ln_half(const void* d_o2, const void* h, const void* W2t, const void* W1t, void* dh, const void* xhat,
+                        const float* gamma, const float* rstd, const void* dres, void* dx, void* ddrop, float* part,
+                        size_t part_bytes, int32_t T, int32_t D, float drop_p, uint64_t seed, uint64_t offset,
+                        const int32_t* step_ptr, mfp_stream_t stream);
 /* The same launch with the backward of LN1 in its epilogue (round 5; the arguments of mfp_mlp_bwd_ln): dx = dres + d(LN1)(dy1),
  * ddrop = its dropout-masked copy or nullptr (block 0: nothing consumes one), part[T / 128][3][256].  Replaces
  * mfp_attn_block_bwd + mfp_layernorm_bwd_res16. */

@@ -1038,6 +1038,18 @@ def test_mlp_bwd_ln(T, p):
     dh2, dx2, do2 = ops.mlp_bwd_ln(dd, hd, W2t, W1t, None, gamma, None, rstd, dres, dg2, db2, (cs2, p, 11, 5, step), xhat=xh)
     assert torch.equal(dh2, dh0)
     _check_ln_from_xhat(dy2, xh, gamma, rstd, dres, dx2, do2, dg2, db2, cs2, p)
+    # ... on HALF tiles (mfp_mlp_bwd_ln_half: two workgroups per 128-row tile, one row tile per wave): dh, dx and the masked copy
+    # bit for bit, the parameter-gradient sums in another grouping; both reduction routes
+    for batched in (False, True):
+        dg3, db3, cs3 = new()
+        jobs = [] if batched else None
+        dh3, dx3, do3 = ops.mlp_bwd_ln(dd, hd, W2t, W1t, None, gamma, None, rstd, dres, dg3, db3, (cs3, p, 11, 5, step), jobs=jobs, xhat=xh,
+                                       half_tiles=True)
+        if batched:
+            ops.reduce_partials_batch(jobs)
+        assert torch.equal(dh3, dh0) and torch.equal(dx3, dx2) and torch.equal(do3, do2)
+        for a, b, what in ((dg3, dg2, "dgamma"), (db3, db2, "dbeta"), (cs3, cs2, "colsum")):
+            assert_close(a, b.cpu().double(), 1e-4 * float(b.abs().max()), 1e-5, "half tiles: " + what)
 
 
 @pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
