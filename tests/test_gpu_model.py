@@ -932,7 +932,7 @@ def test_grouped_wgrad_equals_per_product_path():
 @pytest.mark.parametrize("B,S,D,L", [(64, 128, 256, 4), (16, 256, 512, 2)])
 def test_bf16_residual_gradient_stream_vs_f32(B, S, D, L):
     """(d_model 512, round 5: the heads' input-gradient product writes bf16 and mfp_dropout_bwd_res16 masks it for the last block;
-    the kernel list of the step must show the bf16 LayerNorm backward.)
+    the kernel list of the step must show the bf16 LayerNorm backward -- inside os512_kernel<2> since mfp_dense_n512_lnb.)
     bf16 train step: the gradient of the residual stream carried in bf16 between the LayerNorm backward kernels
     (MFP_RES_GRAD_BF16, mfp_layernorm_bwd_res16; autograd sees placeholders) against the same step with the f32 stream --
     same batch, masks and dropout streams.  The f32 stream's own distance to the oracle is what the budgets of
@@ -957,7 +957,10 @@ def test_bf16_residual_gradient_stream_vs_f32(B, S, D, L):
             torch.cuda.synchronize()
             ln = [n for n in names if n.startswith("ln_bwd_kernel")]
             import re
-            assert ln and all((re.search(r", (unsigned short|float), \d+(, (true|false))?>$", n).group(1) == "unsigned short") == r16 for n in ln), (r16, ln)
+            if D == 512 and r16:      # (the bf16 stream's LayerNorm backward rides in the input-gradient products: mfp_dense_n512_lnb)
+                assert not ln and any(n.startswith("os512_kernel<2") for n in names), sorted(set(names))
+            else:
+                assert ln and all((re.search(r", (unsigned short|float), \d+(, (true|false))?>$", n).group(1) == "unsigned short") == r16 for n in ln), (r16, ln)
             grads.append((model.model.store.grads_state_dict(), holder["sums"].clone()))
     finally:
         functions.RES_GRAD_BF16 = old
