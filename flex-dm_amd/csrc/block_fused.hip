@@ -791,6 +791,7 @@ struct DgradParams {
   const unsigned short* Wt;    // [256][768] bf16: Wt[c][n] = W[n][c]
   unsigned short* C;           // [T][256] bf16
   int T;
+  LnTileArgs ln;               // dgrad_half_kernel<768, true> (mfp_dgrad_qkv_ln_half): the backward of LN1 on the result tile
 };
 // (DG_K = 768: the fused Q | K | V; DG_K = 256: the attention output projection, da = d_o1 Wo)
 template <int DG_K>
@@ -926,7 +927,9 @@ constexpr int H_AS_B = H_ROWS * 256;     // one [64][256 B] activation piece
 constexpr int H_WS_B = 16384;            // one weight chunk
 constexpr int H_LDS = 2 * H_AS_B + 3 * H_WS_B;      // 80 KB
 
-template <int DG_K>
+// LNB (round 5): the x-hat LayerNorm backward on the 64 x 256 result tile (whole rows: no exchange), ln_bwd_tile with four waves
+// of 16 rows -- dy1 never reaches HBM and the stand-alone ln_bwd launch of the three-launch attention route is gone
+template <int DG_K, bool LNB = false>
 __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
   constexpr int DG_KQ = DG_K / 128, DG_CHUNKS = 4 * DG_KQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -967,6 +970,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
 
   f32x4 acc2[4][2][2];
   bf16x8 hf[2][4];
+  u32x2 xhv[16];      // (LNB: the tile's x-hat rows, wave w rows 16 w .. + 15)
   int xs[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
@@ -988,7 +992,8 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
     constexpr int kq = c >> 2, j = c & 3;
     constexpr bool lastq = kq == DG_KQ - 1;
     if (c + 2 < DG_CHUNKS) wload(c + 2);
-    if (lastq && j == 2) out_store(0);        // behind the barrier that ended (last, 1); AFTER the weight loads (counted waits)
+    if (!LNB && lastq && j == 2) out_store(0);        // behind the barrier that ended (last, 1); AFTER the weight loads (counted waits)
+    if constexpr (LNB && c == DG_CHUNKS - 1) ln_tile_load_xh(ln_tile_xh_rsrc(p.ln, p.T), row0, wv, lane, xhv);      // 16 loads cross the last chunk
     if (j == 0 && kq >= 1 && kq + 1 < DG_KQ) aload(kq + 1);
     if (j == 0) {
 #pragma unroll
@@ -1029,7 +1034,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
     {
       // weight waves: chunk c + 1 landed when at most the 8 loads of chunk c + 2 (and the 4 stores of result half 0,
       // issued at the head of (last, 2)) are younger; activation waves: piece kq + 1 is due at the end of (kq, 3)
-      constexpr int allowed_w = (c + 2 < DG_CHUNKS ? 8 : 0) + ((lastq && j == 2) ? 4 : 0);
+      constexpr int allowed_w = (c + 2 < DG_CHUNKS ? 8 : 0) + ((!LNB && lastq && j == 2) ? 4 : 0) + ((LNB && c == DG_CHUNKS - 1) ? 16 : 0);
       if (wv < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
       else if (j == 3 && kq + 1 < DG_KQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1037,7 +1042,15 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
     }
   };
   wgg_free_static_for<0, DG_CHUNKS>(chunk);
-  out_store(1);
+  if constexpr (LNB) {
+    // dy sits in the two activation buffers as bf16 images of its column halves; the partial sums go through the weight ring
+    const unsigned char* img = As + ((DG_KQ + (lane >> 5)) & 1) * H_AS_B;      // this lane's column half
+    const int c16 = (lane & 31) >> 1, sub = (lane & 1) * 8;
+    auto dy_of = [&](int r) { return *reinterpret_cast<const u32x2*>(img + r * 256 + ((c16 ^ (r & 15)) << 4) + sub); };
+    ln_bwd_tile<4>(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xhv, dy_of, reinterpret_cast<float*>(Ws));
+  } else {
+    out_store(1);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1553,6 +1566,42 @@ extern "C" int mfp_dgrad_qkv(const void* dqkv, const void* Wt, void* dy, int32_t
   p.C = reinterpret_cast<unsigned short*>(dy); p.T = T;
   const int rc = launch_dgrad_k<768>(p, reinterpret_cast<hipStream_t>(stream));
   if (rc != MFP_OK) return rc;
+  MFP_CHECK_LAUNCH();
+  return MFP_OK;
+}
+
+// mfp_dgrad_qkv on 64-row tiles with the x-hat backward of LN1 on its result (dgrad_half_kernel<768, true>): what
+// mfp_dgrad_qkv + mfp_layernorm_bwd_xhat compute for batches with fewer 128-row tiles than CUs (BASELINE config c4: the
+// three-launch attention route), dy1 never written.  ddrop may be NULL (block 0); part: T / 64 rows of [3][256].  T % 64 == 0.
+extern "C" int mfp_dgrad_qkv_ln_half(const void* dqkv, const void* Wt, const void* xhat, const float* gamma, const float* rstd,
+                                     const void* dres, void* dx, void* ddrop, float* part, size_t part_bytes, int32_t T, int32_t D,
+                                     float drop_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  MFP_CHECK_ARG(dqkv && Wt && xhat && gamma && rstd && dres && dx && part && T > 0 && T <= (1 << 20) && T % H_ROWS == 0 && D == MLP_D);
+  MFP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  MFP_CHECK_ARG(((uintptr_t)dqkv % 16) == 0 && ((uintptr_t)Wt % 16) == 0 && ((uintptr_t)xhat % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                ((uintptr_t)dres % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)ddrop % 16) == 0);
+  if (part_bytes < (size_t)(T / H_ROWS) * 3 * MLP_D * sizeof(float)) {
+    mfp_set_error("mfp_dgrad_qkv_ln_half: partial-sum buffer too small");
+    return MFP_EWORKSPACE;
+  }
+  DgradParams p = {};
+  p.A = reinterpret_cast<const unsigned short*>(dqkv); p.Wt = reinterpret_cast<const unsigned short*>(Wt);
+  p.C = nullptr; p.T = T;
+  p.ln.x = nullptr; p.ln.xhat = reinterpret_cast<const unsigned short*>(xhat); p.ln.gamma = gamma; p.ln.mean = nullptr; p.ln.rstd = rstd;
+  p.ln.dres = reinterpret_cast<const unsigned short*>(dres);
+  p.ln.dx = reinterpret_cast<unsigned short*>(dx); p.ln.ddrop = reinterpret_cast<unsigned short*>(ddrop); p.ln.part = part;
+  p.ln.drop_p = drop_p; p.ln.seed = seed; p.ln.offset = offset; p.ln.step_ptr = step_ptr;
+  static bool attr_done[MFP_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[mfp_device_slot()];
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_half_kernel<768, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS);
+    if (e != hipSuccess) {
+      mfp_set_error("mfp_dgrad_qkv_ln_half: cannot raise dynamic LDS to %d: %s", H_LDS, hipGetErrorString(e));
+      return MFP_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dgrad_half_kernel<768, true>), dim3(T / H_ROWS), dim3(256), H_LDS, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

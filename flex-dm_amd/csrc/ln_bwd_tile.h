@@ -50,7 +50,8 @@ __device__ __forceinline__ void ln_tile_load_x(const __amdgpu_buffer_rsrc_t rs_x
 // of the 512-thread workgroup calls it (one __syncthreads inside)
 // XT = f32x4 (x rows) or u32x2 (x-hat rows, bf16); NR = rows per wave: 16 (a 128-row tile) or 8 (a 64-row half tile: `tile`
 // then counts half tiles and `part` holds T / 64 rows)
-template <typename XT, typename DyOf, int NR>
+// NWV = waves of the workgroup (8; 4: dgrad_half_kernel's 64-row tiles, 16 rows per wave)
+template <int NWV = 8, typename XT, typename DyOf, int NR>
 __device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0, int tile, int wv, int lane, int tid,
                                             const XT (&xv)[NR], DyOf dy_of, float* red) {
   constexpr bool XH = sizeof(XT) == 8;
@@ -121,10 +122,10 @@ __device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0
   *reinterpret_cast<f32x4*>(red + (wv * 3 + 1) * D + lane * 4) = (f32x4){db[0], db[1], db[2], db[3]};
   *reinterpret_cast<f32x4*>(red + (wv * 3 + 2) * D + lane * 4) = (f32x4){dc[0], dc[1], dc[2], dc[3]};
   __syncthreads();
-  for (int c = tid; c < 3 * D; c += 512) {
+  for (int c = tid; c < 3 * D; c += NWV * 64) {
     float a = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) a += red[w * 3 * D + c];
+    for (int w = 0; w < NWV; ++w) a += red[w * 3 * D + c];
     q.part[(size_t)tile * (3 * D) + c] = a;
   }
 }

@@ -119,6 +119,7 @@ SIGNATURES = {
     "mfp_dgrad_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                  c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_mlp_fused_bwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
+    "mfp_dgrad_qkv_ln_half": (c_int32, [c_void_p] * 9 + [c_size_t, c_int32, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_mlp_bwd_ln_half": (c_int32, [c_void_p] * 12 + [c_size_t, c_int32, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_mlp_bwd_ln": (c_int32, [c_void_p] * 14 + [c_size_t, c_int32, c_int32, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_layernorm_fwd": (c_int32, [c_void_p] * 6 + [c_int32, c_int32, c_float, c_int32, c_void_p]),

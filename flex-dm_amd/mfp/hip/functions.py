@@ -92,6 +92,9 @@ FUSE_MAX_T = 1 << 20     # the activation-stationary kernels address rows with 3
 BLOCK_HALF = os.environ.get("MFP_BLOCK_HALF", "")
 
 
+# the three-launch attention route of batches with fewer 128-row tiles than CUs: LN1 backward in the epilogue of dy1 = dqkv Wqkv
+# on 64-row tiles (mfp_dgrad_qkv_ln_half); 0 = mfp_dgrad_qkv + mfp_layernorm_bwd_xhat (A/B switch)
+DGRAD_LN_HALF = os.environ.get("MFP_DGRAD_LN_HALF", "1") == "1"
 # ... and the MLP half's input-gradient launch (+ LN2 backward) on half tiles (mfp_mlp_bwd_ln_half); unset: as above
 MLP_BWD_HALF = os.environ.get("MFP_MLP_BWD_HALF", "")
 
@@ -705,6 +708,15 @@ class BlockFn(torch.autograd.Function):
             ctx.on_side(wgrads_attn, d_o1, a, dqkv, y1)
         if dy1 is not None or ln1_fused:
             pass
+        elif (_fused_ok(ctx, D) and wtq is not None and DGRAD_LN_HALF and xh1 is not None and T % 64 == 0
+              and ops.fused_half_mode(T)):
+            # fewer 128-row tiles than CUs (c4): dy1 = dqkv Wqkv on 64-row tiles with the backward of LN1 on its result
+            drop1 = ((st.grad("blocks/seq2seq_%d/mlp/dense_1/bias" % (i - 1)), ctx.p, ctx.seed, 2 * (i - 1) + 2, ctx.step_ptr)
+                     if i > 0 else None)
+            r_ = ops.dgrad_qkv_ln_half(dqkv, wtq, xh1, st.weight(p + "norm1/gamma"), rstd1, dx1,
+                                       st.grad(p + "norm1/gamma"), st.grad(p + "norm1/beta"), drop=drop1, jobs=ctx.ln_jobs)
+            dx, nxt = r_ if i > 0 else (r_, None)
+            ln1_fused = True
         elif _fused_ok(ctx, D) and wtq is not None:
             dy1 = ops.dgrad_qkv(dqkv, wtq)       # activation-stationary (csrc/block_fused.hip)
         elif _fused512_ok(ctx, D) and wtq is not None and D512_LN_BWD and xh1 is not None and T % 128 == 0:

@@ -216,6 +216,15 @@ def cu_count(device=None) -> int:
     return _cu_count[dev]
 
 
+def fused_half_mode(T: int) -> bool:
+    """What csrc/block_fused.hip's half_mode() decides for the activation-stationary launches of T rows: the half-size (64-row)
+    workgroups when MFP_FUSED_HALF says so, else when the 128-row grid would leave CUs idle."""
+    env = os.environ.get("MFP_FUSED_HALF", "")
+    if env != "":
+        return int(env) != 0
+    return (T + 127) // 128 < cu_count()
+
+
 def wgrad_splitk(T: int, M: int, N: int) -> int:
     """Split the token contraction so that the 128x128 output tiles x splits give about one
     persistent workgroup per CU (the streaming wgrad kernel keeps 8 waves and ~80 KB of LDS per
@@ -607,6 +616,32 @@ def dgrad_qkv(dqkv: torch.Tensor, Wt: torch.Tensor) -> torch.Tensor:
     with _timed("dgrad_qkv_kernel", 2 * T * K * D, T * (K + D) * 2 + K * D * 2):
         check(lib.mfp_dgrad_qkv(_ptr(dqkv), _ptr(Wt), _ptr(dy), T, D, _stream()), "mfp_dgrad_qkv")
     return dy
+
+
+def dgrad_qkv_ln_half(dqkv, Wt, xhat, gamma, rstd, dres, dgamma, dbeta, drop=None, jobs: Optional[list] = None):
+    """``layernorm_bwd(dgrad_qkv(dqkv, Wt), ..., xhat=xhat)`` in ONE launch on 64-row tiles (see mfp_dgrad_qkv_ln_half): dy1 never
+    reaches HBM.  Returns (dx, ddrop) with ``drop`` = (colsum_out [256], p, seed, offset, step_ptr), else dx."""
+    lib = load()
+    T, K = dqkv.shape
+    D = K // 3
+    assert T % 64 == 0 and xhat.dtype == torch.bfloat16 and dres.dtype == torch.bfloat16
+    dev = dqkv.device
+    dx = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    ddrop = torch.empty((T, D), dtype=torch.bfloat16, device=dev) if drop is not None else None
+    colsum, p_, seed_, off_, sp_ = drop if drop is not None else (None, 0.0, 0, 0, None)
+    P = T // 64
+    part = torch.empty((P, 3 * D), dtype=torch.float32, device=dev)
+    with _timed("dgrad_qkv_kernel", 2 * T * K * D, T * (K * 2 + D * 2 * (3 + (1 if drop is not None else 0))) + K * D * 2):
+        check(lib.mfp_dgrad_qkv_ln_half(_ptr(dqkv), _ptr(Wt), _ptr(xhat), _ptr(gamma), _ptr(rstd), _ptr(dres), _ptr(dx), _ptr(ddrop),
+                                        _ptr(part), part.numel() * 4, T, D, float(p_), int(seed_), int(off_), _ptr(sp_), _stream()),
+              "mfp_dgrad_qkv_ln_half")
+    n = 3 * D if drop is not None else 2 * D
+    if jobs is not None:
+        jobs.append(dict(part=part, out0=dgamma, out1=dbeta, out2=colsum, split1=D, split2=2 * D, P=P, N=n, pstride=3 * D))
+    else:
+        check(lib.mfp_reduce_partials(part.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(colsum), D, 2 * D, P, n, 3 * D, _stream()),
+              "mfp_reduce_partials")
+    return (dx, ddrop) if drop is not None else dx
 
 
 def attn_block_bwd(d_o1, Wot, qkv, a, lse, nvalid, Wqkvt, B: int, S: int, H: int):

@@ -318,6 +318,12 @@ int mfp_attn_block_bwd(const void* d_o1, const void* Wot, const void* qkv, const
                        const int32_t* nvalid, const void* Wqkvt, void* dqkv, void* dy1, int32_t B, int32_t S,
                        int32_t D, int32_t H, mfp_stream_t stream);
 
+/* mfp_dgrad_qkv (dy1 = dqkv Wqkv) on 64-row tiles with the x-hat backward of LN1 on its result in the same launch: what
+ * mfp_dgrad_qkv + mfp_layernorm_bwd_xhat compute, dy1 never written -- the three-launch attention route of batches with fewer
+ * 128-row tiles than CUs (BASELINE config 4).  ddrop may be NULL (block 0); part: T / 64 rows of [3][256].  T % 64 == 0. */
+int mfp_dgrad_qkv_ln_half(const void* dqkv, const void* Wt, const void* xhat, const float* gamma, const float* rstd,
+                          const void* dres, void* dx, void* ddrop, float* part, size_t part_bytes, int32_t T, int32_t D,
+                          float drop_p, uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 /* mfp_mlp_bwd_ln (x-hat form) on HALF tiles: two workgroups per 128-row tile, 64 rows each, one 16-row tile per wave -- for
  * batches with fewer 128-row tiles than the device has CUs (BASELINE config 4's per-GPU share).  `part`: T / 64 rows of [3][256].
  * dh, dx, ddrop bit-identical to mfp_mlp_bwd_ln; the partial rows sum to the same parameter gradients in another grouping. */

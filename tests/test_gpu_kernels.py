@@ -1077,6 +1077,52 @@ def test_qkv_fused_fwd(T):
     assert_close(qkv, want, 2e-2, 1e-2, "qkv vs double")
 
 
+@pytest.mark.parametrize("T,p", [(4096, 0.1), (64 * 5, 0.0), (16384, 0.1), (1024, None)])
+def test_dgrad_qkv_ln_half(T, p):
+    """mfp_dgrad_qkv_ln_half: dy1 = dqkv Wqkv on 64-row tiles with the x-hat backward of LN1 on the tile, against the launch pair
+    it replaces (mfp_dgrad_qkv on the half-size workgroups + mfp_layernorm_bwd_xhat) -- dx and the masked copy up to an occasional
+    bf16 step, the parameter-gradient sums to summation-order noise -- and a double restatement from the pair's own dy1;
+    p = None: no masked copy (block 0); both reduction routes."""
+    import os
+    ops = _ops()
+    D, K = 256, 768
+    g = torch.Generator().manual_seed(T + 31)
+    dq = (torch.randn(T, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
+    Wt = (torch.randn(D, K, generator=g) * 0.05).to(DEV, torch.bfloat16)
+    xh = torch.randn(T, D, generator=g).to(DEV, torch.bfloat16)
+    gamma, rstd = (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.rand(T, generator=g) + 0.5).to(DEV)
+    dres = torch.randn(T, D, generator=g).to(DEV, torch.bfloat16)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    new = lambda: tuple(torch.full((D,), 3.0, device=DEV) for _ in range(3))
+    old = os.environ.get("MFP_FUSED_HALF")
+    os.environ["MFP_FUSED_HALF"] = "1"
+    try:
+        dy1 = ops.dgrad_qkv(dq, Wt)
+    finally:
+        if old is None:
+            os.environ.pop("MFP_FUSED_HALF", None)
+        else:
+            os.environ["MFP_FUSED_HALF"] = old
+    dg0, db0, cs0 = new()
+    r0 = ops.layernorm_bwd(dy1, None, gamma, None, rstd, dres, dg0, db0, drop=(cs0, p, 11, 5, step) if p is not None else None, xhat=xh)
+    dx0, do0 = r0 if p is not None else (r0, None)
+    for batched in (False, True):
+        dg1, db1, cs1 = new()
+        jobs = [] if batched else None
+        r1 = ops.dgrad_qkv_ln_half(dq, Wt, xh, gamma, rstd, dres, dg1, db1, drop=(cs1, p, 11, 5, step) if p is not None else None, jobs=jobs)
+        if batched:
+            ops.reduce_partials_batch(jobs)
+        dx1, do1 = r1 if p is not None else (r1, None)
+        assert (dx1 != dx0).float().mean().item() < 1e-4
+        assert_close(dx1, dx0.float().cpu().double(), 2e-2, 1e-2, "dx")
+        if p is not None:
+            assert (do1 != do0).float().mean().item() < 1e-4 and torch.equal(do1 == 0, do0 == 0)
+        for a, b, what in ((dg1, dg0, "dgamma"), (db1, db0, "dbeta")) + (((cs1, cs0, "colsum"),) if p is not None else ()):
+            assert torch.isfinite(a).all(), what
+            assert_close(a, b.cpu().double(), 2e-3 * float(b.abs().max()), 1e-4, what)
+    _check_ln_from_xhat(dy1, xh, gamma, rstd, dres, dx1, do1, dg1, db1, cs1, p if p is not None else 0.0)
+
+
 @pytest.mark.parametrize("T", [4096, 1000, 33, 128 * 3 + 5])
 def test_dgrad_qkv(T):
     """mfp_dgrad_qkv: dy1 = dqkv Wqkv (K = 768) in the activation-stationary kernel against the product it
