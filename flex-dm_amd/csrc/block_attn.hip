@@ -108,7 +108,11 @@ __device__ __forceinline__ bf16x8 ab_pack(const f32x4& a, const f32x4& b) {
 template <bool DROPOUT, bool MLP, bool STASH = true, int SDOC = 128, bool XHAT = false, int HALF = 0>
 __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(AttnBlockParams p) {
   static_assert(SDOC == 128 || SDOC == 64, "documents of 128 or 64 positions");
-  static_assert(!HALF || (SDOC == 128 && MLP && XHAT && STASH), "half-document tiles: the x-hat training form at S = 128");
+  static_assert(!HALF || (MLP && XHAT && STASH && (SDOC == 128 || HALF == 2)), "half tiles: the x-hat training form");
+  // HD: HALF == 2 at S = 64 -- a half tile IS one document of 64 positions (the datasets' shape at the reference's default batch
+  // of 256: 128 two-document tiles on 256 CUs): nothing of another workgroup's rows is needed, no K / V recomputed; LN1 on waves
+  // 0-3 (waves 4-7 repeat their rows: identical LDS writes, their stores out of range)
+  constexpr bool HD = HALF == 2 && SDOC == 64;
   constexpr bool H8 = HALF == 2;
   constexpr int NT = HALF == 1 ? 256 : 512;            // threads
   constexpr int LD = HALF == 1 ? 8 : 4;                // 1 KB LDS-DMA pieces per wave and weight chunk
@@ -131,15 +135,15 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
   // eight XCDs), so the second fetch of the document's x rows and of the weights is a hit in that XCD's L2; a trailing partial
   // group pairs neighbours
   const int bi = (int)blockIdx.x, bfull = (int)(gridDim.x >> 4) << 4;
-  const int doc = !HALF ? bi : bi < bfull ? (bi >> 4) * 8 + (bi & 7) : (bfull >> 1) + ((bi - bfull) >> 1);
-  const int row0 = doc * AB_ROWS;
-  const int rb = !HALF ? 0 : (bi < bfull ? (bi >> 3) & 1 : (bi - bfull) & 1) * 64;      // first own row of the document (image rows are document rows)
+  const int doc = (!HALF || HD) ? bi : bi < bfull ? (bi >> 4) * 8 + (bi & 7) : (bfull >> 1) + ((bi - bfull) >> 1);
+  const int row0 = doc * (HD ? 64 : AB_ROWS);
+  const int rb = (!HALF || HD) ? 0 : (bi < bfull ? (bi >> 3) & 1 : (bi - bfull) & 1) * 64;      // first own row of the document (image rows are document rows)
   const int rbase = rb + rp * 32 + rtw * 16;                 // this wave's row tile(s): document rows rbase + 16 rt + li, rt < RT
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   // (the step counter and the document's length are read first: their loads must not sit between the counted waits)
   const int step_now = (DROPOUT && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
-  const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[SDOC == 128 ? doc : 2 * doc]);
-  const int nv1 = SDOC == 128 ? 0 : __builtin_amdgcn_readfirstlane(p.nvalid[2 * doc + 1]);
+  const int nv = __builtin_amdgcn_readfirstlane(p.nvalid[(SDOC == 128 || HD) ? doc : 2 * doc]);
+  const int nv1 = (SDOC == 128 || HD) ? 0 : __builtin_amdgcn_readfirstlane(p.nvalid[2 * doc + 1]);
 
   const unsigned long long* trbase = reinterpret_cast<const unsigned long long*>(p.x2c) + (size_t)(blockIdx.x * (HALF == 1 ? 4 : 8) + wave) * 64;
   AB_TR(0);
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
   }
   // additive key term (exp2 domain); no row past S.  SDOC = 64: key's validity inside ITS document (a wave only visits the
   // 64 keys of its queries' document)
-  if (tid < 128) Mb[tid] = (SDOC == 128 ? tid < nv : (tid & 63) < (tid >> 6 ? nv1 : nv)) ? 0.f : -1e9f * LOG2E;
+  if (tid < 128) Mb[tid] = ((SDOC == 128 || HD) ? tid < nv : (tid & 63) < (tid >> 6 ? nv1 : nv)) ? 0.f : -1e9f * LOG2E;
 
   // ---- LN1 (as qkv_fused_kernel): wave w normalises rows 16 w .. + 15 in the MFMA operand layout.  HALF: two passes of 16
   // rows per wave -- the own half's (statistics and x-hat leave for HBM) and the other half's (K / V operands only); every load
@@ -229,12 +233,12 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
     // HALF == 2: the rows of the OTHER half (waves whose 16 rows are not in [rb, rb + 64)) leave no x-hat: their stores are issued
     // out of range (the counted waits assume the same ten prologue stores in every wave); their statistics are stored twice, by
     // both workgroups of the document, with identical values
-    const bool own8 = !H8 || ((wave >> 2) == (rb >> 6));
+    const bool own8 = !H8 || (HD ? wave < 4 : (wave >> 2) == (rb >> 6));
     float v[NP][8][8];
     float s[NP];
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
-      const int row = row0 + (HALF == 1 ? (rb ^ (ps * 64)) : 0) + wave * 16 + li;
+      const int row = row0 + (HALF == 1 ? (rb ^ (ps * 64)) : 0) + (HD ? wave & 3 : wave) * 16 + li;
       s[ps] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
     AB_TR(1);
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
-      const int lrow = (HALF == 1 ? (rb ^ (ps * 64)) : 0) + wave * 16 + li, row = row0 + lrow;
+      const int lrow = (HALF == 1 ? (rb ^ (ps * 64)) : 0) + (HD ? wave & 3 : wave) * 16 + li, row = row0 + lrow;
       float sm_ = s[ps];
       sm_ += lane_xor16(sm_);
       sm_ += lane_xor32(sm_);
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       xf[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + (rbase + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
-      if constexpr (HALF)
+      if constexpr (HALF && !HD)
         xo[rt][ks] = *reinterpret_cast<const bf16x8*>(smem + ((rbase ^ 64) + rt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
     if (t < 3) {
       // 64 columns of q / k / v: acc[nt][rt], wave (rp, nh) owns column tiles 2 nh + nt of the chunk
       const unsigned char* wa = wb + ((nh * 2) * 16 + li) * 512;
-      constexpr bool both = HALF && t != 0;      // k / v of the other half's rows too (acco: same products on xo)
+      constexpr bool both = HALF && !HD && t != 0;      // k / v of the other half's rows too (acco: same products on xo)
       f32x4 acc[2][2], acco[both ? 2 : 1][2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
       const unsigned char* vi = Im + 2 * AB_IMG;
       const int qrow = rb + 16 * (H8 ? (wave & 3) : wave) + li;
       constexpr int NKT = SDOC / 16;                                    // key tiles a query sees
-      const int kb = SDOC == 128 ? 0 : (wave >> 2) * 64;                // first key row of this wave's queries' document
+      const int kb = (SDOC == 128 || HD) ? 0 : (wave >> 2) * 64;        // first key row of this wave's queries' document
       const unsigned char* const kid = ki + kb * 128;                   // ((row >> 1) & 7, the slot swizzle, is the same for row + 64)
       const unsigned char* const vid = vi + kb * 128;
       const float* const Mbq = Mb + kb;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
           }
           const float lv = (m[hh] + __builtin_amdgcn_logf(lt)) * LN2;      // natural-log lse
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, lv), rs_l,
-                                                g != 0 ? 0xFFFFFFF0u : (unsigned int)(((doc * p.H + 2 * pr + hh0 + hh) * AB_ROWS + qrow) * 4), 0, 0);
+                                                g != 0 ? 0xFFFFFFF0u : (unsigned int)(((doc * p.H + 2 * pr + hh0 + hh) * SDOC + qrow) * 4), 0, 0);
         }
       } else {
 #pragma unroll
@@ -933,6 +937,8 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true, 1>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 128, true, 2>, AB_LDS_MLP);
     if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 128, true, 2>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<true, true, true, 64, true, 2>, AB_LDS_MLP);
+    if (e == hipSuccess) e = ab_set_lds(attn_block_fwd_kernel<false, true, true, 64, true, 2>, AB_LDS_MLP);
     if (e != hipSuccess) {
       mfp_set_error("mfp_block_fwd: cannot raise dynamic LDS to %d: %s", AB_LDS_MLP, hipGetErrorString(e));
       return MFP_ELAUNCH;
@@ -944,8 +950,11 @@ static int launch_block(AttnBlockParams& p, bool mlp, int tiles, int S, hipStrea
   if (p.xhat) {       // (mfp_block_fwd_xhat: the whole-block training forms)
     if (!mlp || !p.stash) { mfp_set_error("mfp_block_fwd_xhat: whole-block training form only"); return MFP_EINVAL; }
     if (p.xhat == 2 || p.xhat == 3) {      // mfp_block_fwd_xhat_half: two workgroups per document (four waves | eight waves, one row tile each)
-      if (S != AB_ROWS) { mfp_set_error("mfp_block_fwd_xhat_half: documents of 128 positions"); return MFP_EINVAL; }
-      if (p.xhat == 3) {
+      if (S != AB_ROWS && !(S == 64 && p.xhat == 3)) { mfp_set_error("mfp_block_fwd_xhat_half: documents of 128 positions (64: eight waves only)"); return MFP_EINVAL; }
+      if (p.xhat == 3 && S == 64) {      // (a half tile is one document)
+        if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 64, true, 2>), dim3(2 * tiles), dim3(512), AB_LDS_MLP, st, p);
+        else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 64, true, 2>), dim3(2 * tiles), dim3(512), AB_LDS_MLP, st, p);
+      } else if (p.xhat == 3) {
         if (drop) hipLaunchKernelGGL((attn_block_fwd_kernel<true, true, true, 128, true, 2>), dim3(2 * tiles), dim3(512), AB_LDS_MLP, st, p);
         else hipLaunchKernelGGL((attn_block_fwd_kernel<false, true, true, 128, true, 2>), dim3(2 * tiles), dim3(512), AB_LDS_MLP, st, p);
       } else {
@@ -1069,7 +1078,8 @@ extern "C" int mfp_block_fwd_xhat(const float* x, const float* gamma, const floa
 
 // mfp_block_fwd_xhat on HALF-document tiles: two workgroups per document (64 query rows each, the other half's K / V
 // recomputed), for batches with fewer documents than CUs (BASELINE config c4: 128 documents per GPU).  `waves` = 4 (a wave owns two
-// row tiles, one wave per SIMD) or 8 (one row tile per wave, two waves per SIMD).  S = 128 only; results are bit-identical to
+// row tiles, one wave per SIMD) or 8 (one row tile per wave, two waves per SIMD).  S = 128, or S = 64 with 8 waves (a half tile is
+// then ONE document: the datasets' shape at the reference's default batch of 256 documents); results are bit-identical to
 // mfp_block_fwd_xhat.
 extern "C" int mfp_block_fwd_xhat_half(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
                                        const void* Wo, const float* bo, const int32_t* nvalid, void* xhat1, float* mean, float* rstd,
@@ -1078,7 +1088,7 @@ extern "C" int mfp_block_fwd_xhat_half(const float* x, const float* gamma, const
                                        float* rstd2, void* h, float* x2, void* x2_bf16, int32_t B, int32_t S, int32_t D, int32_t H,
                                        float eps, float dropout_p, uint64_t seed, uint64_t offset_attn, uint64_t offset_mlp,
                                        const int32_t* step_ptr, int32_t waves, mfp_stream_t stream) {
-  MFP_CHECK_ARG(S == AB_ROWS && (waves == 4 || waves == 8));
+  MFP_CHECK_ARG((waves == 4 || waves == 8) && (S == AB_ROWS || (S == 64 && waves == 8)));
   return block_fwd_impl(waves == 8 ? 3 : 2, x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, xhat1, mean, rstd, qkv, a, lse, x1, gamma2, beta2, W1, b1, W2, b2,
                         xhat2, mean2, rstd2, h, x2, x2_bf16, B, S, D, H, eps, dropout_p, seed, offset_attn, offset_mlp, step_ptr, stream);
 }

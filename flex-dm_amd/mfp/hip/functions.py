@@ -106,11 +106,13 @@ def _mlp_bwd_half_on(ctx, T: int) -> bool:
 
 
 def _block_half_on(ctx, B: int, S: int) -> bool:
-    if S != 128:
+    """Half tiles: half a document at S = 128, ONE document at S = 64 (two documents per 128-row tile: the datasets' shape --
+    at the reference's default batch of 256 documents that is 128 tiles on 256 CUs)."""
+    if S not in (64, 128):
         return False
     if BLOCK_HALF != "":
         return BLOCK_HALF == "1"
-    return 2 * B <= ops.cu_count(ctx.store.w.device)
+    return 2 * (B * S // 128) <= ops.cu_count(ctx.store.w.device)
 
 
 def _doc_tile_ok(B: int, S: int, T: int) -> bool:

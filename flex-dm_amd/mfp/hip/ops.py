@@ -448,7 +448,9 @@ def block_fwd(x, gamma, beta, Wqkv, bqkv, Wo, bo, nvalid, gamma2, beta2, W1, b1,
     ``xhat_stash``: y1 / y2 hold x-hat = (x - mean) rstd instead of the LayerNorm outputs (mfp_block_fwd_xhat);
     ``half_tiles`` (with xhat_stash, S = 128): two workgroups per document (mfp_block_fwd_xhat_half), bit-identical results;
     True = MFP_BLOCK_HALF_WAVES waves per workgroup, 4 / 8 = that many."""
-    assert not half_tiles or (xhat_stash and S == 128)
+    if half_tiles and S == 64:
+        half_tiles = 8      # (a half tile is one document of 64 positions: the eight-wave form only)
+    assert not half_tiles or (xhat_stash and S in (64, 128))
     lib = load()
     T, D = x.shape
     dev = x.device

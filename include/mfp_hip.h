@@ -216,7 +216,8 @@ int mfp_block_fwd_xhat(const float* x, const float* gamma, const float* beta, co
                   const int32_t* step_ptr, mfp_stream_t stream);
 /* mfp_block_fwd_xhat on HALF-document tiles: two four-wave workgroups per document (64 query rows each; the other half's K / V
  * are recomputed in the workgroup, nothing is exchanged), for batches with fewer documents than the device has CUs (BASELINE
- * config 4's per-GPU share: 128 documents).  S = 128 only.  `waves`: 4 (a wave owns two 16-row tiles, one wave per SIMD) or 8 (one
+ * config 4's per-GPU share: 128 documents).  S = 128, or S = 64 with `waves` = 8 (a half tile is then one document: the datasets'
+ * shape at the reference's default batch of 256).  `waves`: 4 (a wave owns two 16-row tiles, one wave per SIMD) or 8 (one
  * row tile per wave, two waves per SIMD).  Otherwise the same arguments, same saved tensors, results bit-identical to
  * mfp_block_fwd_xhat. */
 int mfp_block_fwd_xhat_half(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,

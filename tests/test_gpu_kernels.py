@@ -1757,3 +1757,11 @@ def test_block_fwd_two_documents_per_tile(B, p):
     if p == 0.0:
         x2i = ops.block_infer(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H)
         assert torch.equal(x2i, x2)
+    # x-hat form, and the same on HALF tiles -- at S = 64 a half tile is ONE document (eight waves, one row tile each; nothing
+    # recomputed): every output bit for bit
+    x2x, saved_x = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H, p, 7, 3, 4, step, xhat_stash=True)
+    x2h, saved_h = ops.block_fwd(*args, d(g2), d(b2_), d(W1, bf), d(c1), d(W2, bf), d(c2), B, S, H, p, 7, 3, 4, step, xhat_stash=True,
+                                 half_tiles=True)
+    assert torch.equal(x2x, x2) and torch.equal(x2h, x2)
+    for name, got, want in zip(("xhat1", "mean1", "rstd1", "qkv", "a", "lse", "x1", "xhat2", "mean2", "rstd2", "h"), saved_h, saved_x):
+        assert torch.equal(got, want), "half tiles at S = 64: " + name
