@@ -59,8 +59,126 @@ __device__ __forceinline__ int decide(const mfp_mask_col& col, int k, int t, int
   return code;
 }
 
+// Round 5 (second half): SIXTEEN tokens per workgroup.  Phase 1: thread (token, column) decides its pair (one Philox), writes the
+// mask bit, handles a categorical column's features, leaves the numerical columns' codes in LDS.  Phase 2: all 256 threads stream
+// the workgroup's numerical rows (16 tokens x W floats per column), every load of a thread (eight float4 at W = 512) requested
+// before its first store.  The wave-per-token form below walked a token's columns one after the other -- a chain of ~12
+// dependent load -> store round trips with 32 tokens in flight per CU: 55 us at c2 for 45 MB read + 70 MB written.  Same draws
+// (Philox is keyed by (seed, token, column / feature / float4 index, step)): outputs bit-identical to the wave-per-token form.
+constexpr int MK_TOK = 16;
+#ifndef MK_ABL
+#define MK_ABL 0      // timing experiment for tools/bench_mask.py ONLY (the numerical rows stay stale): 1 = no numerical rows
+#endif
 template <typename TX>
 __global__ __launch_bounds__(256) void mask_kernel(MaskCols cols, int* __restrict__ idx_all, int NCOL,
+                                                   const int* __restrict__ nvalid, const int* __restrict__ tasks,
+                                                   int T, int S, unsigned long long seed,
+                                                   unsigned long long offset0, const int* __restrict__ step_ptr) {
+  __shared__ unsigned char s_code[MK_TOK][MFP_MAX_MASK_COLS];
+  const int tid = threadIdx.x;
+  const unsigned long long off = offset0 + (step_ptr ? (unsigned long long)(*step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  {
+    const int tok = tid >> 4, k = tid & 15, t = blockIdx.x * MK_TOK + tok;
+    if (t < T && k < cols.n) {
+      const int b = t / S, s = t % S;
+      const int nv = nvalid[b], task = tasks[b];
+      int sel = -1;
+      if (task == 1) {  // select_single_element (masking.py:98-113): floor(U * length)
+        unsigned int r[4];
+        philox4x32(seed, (unsigned int)b, 0xE1E0E1E0u, off, r);
+        sel = min((int)(u01(r[0]) * (float)nv), nv - 1);
+      }
+      const mfp_mask_col& col = cols.c[k];
+      bool mfp;
+      unsigned int extra;
+      const int code = decide(col, k, t, s, nv, task, sel, seed, off, &mfp, &extra);
+      col.mask_out[t] = mfp ? 1 : 0;
+      s_code[tok][k] = (unsigned char)code;
+      if (!col.is_numerical) {
+        const int* src = reinterpret_cast<const int*>(col.src) + (long long)t * col.n_feat;
+        int* dst = idx_all + (long long)t * NCOL + col.idx_col;
+        for (int f = 0; f < col.n_feat; ++f) {
+          int v = src[f];
+          if (code == 2) v = col.input_dim + 1;
+          else if (code == 1) v = col.input_dim;
+          else if (code == 3) {
+            unsigned int r[4];
+            philox4x32(seed, (unsigned int)t, (unsigned int)(k + 64 * (f + 1)), off, r);
+            v = (int)(((unsigned long long)r[0] * (unsigned long long)col.input_dim) >> 32);
+          }
+          dst[f] = v;
+        }
+      } else {
+        col.rowcode[t] = (unsigned char)((code == 1 || code == 2) ? code : 0);
+        idx_all[(long long)t * NCOL + col.idx_col] = code == 1 ? 0 : (code == 2 ? 1 : -1);
+      }
+    }
+  }
+  __syncthreads();
+  const int t0 = blockIdx.x * MK_TOK;
+  if (MK_ABL == 1) return;
+  for (int k = 0; k < cols.n; ++k) {
+    const mfp_mask_col& col = cols.c[k];
+    if (!col.is_numerical) continue;
+    const int W = col.n_feat, q = W >> 3;                 // 8-float units per row (W % 8 == 0: host check)
+    const int total = MK_TOK * q;                          // units of the workgroup's rows of this column
+    const float* srcb = reinterpret_cast<const float*>(col.src);
+    TX* dstb = reinterpret_cast<TX*>(col.x_out);
+    // a thread's unit = 8 consecutive floats: two 16-byte loads, ONE 16-byte bf16 store (8-byte-per-lane stores run at about half
+    // the rate of 16-byte ones: MI355X_MICROARCH.md)
+    for (int base = 0; base < total; base += 256 * 4) {    // four units per thread and round (W = 512: one round)
+      float4 v[4][2];
+      int code[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = base + tid + 256 * i;
+        const int tok = idx / q, t = t0 + tok;
+        code[i] = (idx < total && t < T) ? (int)s_code[tok][k] : -1;
+        if (code[i] == 0) {
+          const float* sp = srcb + (long long)t * W + (idx - tok * q) * 8;
+          v[i][0] = *reinterpret_cast<const float4*>(sp);
+          v[i][1] = *reinterpret_cast<const float4*>(sp + 4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (code[i] < 0) continue;
+        const int idx = base + tid + 256 * i;
+        const int tok = idx / q, t = t0 + tok, c = (idx - tok * q) * 8;
+        float4 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (code[i] == 0) {
+            o[h] = v[i][h];
+          } else if (code[i] == 1) {
+            o[h] = make_float4(10.f, 10.f, 10.f, 10.f);     // MASK_VALUE (masking.py:8)
+          } else if (code[i] == 2) {
+            o[h] = make_float4(0.f, 0.f, 0.f, 0.f);         // NULL_VALUE (masking.py:9)
+          } else {  // tf.random.normal(stddev=0.1): Box-Muller on 4 Philox uniforms per float4
+            unsigned int r[4];
+            philox4x32(seed, (unsigned int)t, (unsigned int)(k + 64 * (1 + (c + 4 * h) / 4)), off ^ 0x5bd1e995ull, r);
+            const float u0 = fmaxf(u01(r[0]), 1e-7f), u1 = u01(r[1]), u2 = fmaxf(u01(r[2]), 1e-7f), u3 = u01(r[3]);
+            const float ra = 0.1f * sqrtf(-2.f * logf(u0)), rb = 0.1f * sqrtf(-2.f * logf(u2));
+            o[h] = make_float4(ra * cosf(6.2831853f * u1), ra * sinf(6.2831853f * u1),
+                               rb * cosf(6.2831853f * u3), rb * sinf(6.2831853f * u3));
+          }
+        }
+        TX* dst = dstb + (long long)t * W + c;
+        if constexpr (sizeof(TX) == 4) {
+          *reinterpret_cast<float4*>(dst) = o[0];
+          *reinterpret_cast<float4*>(dst + 4) = o[1];
+        } else {
+          const u32x4 pk = {pack_bf16x2(o[0].x, o[0].y), pack_bf16x2(o[0].z, o[0].w), pack_bf16x2(o[1].x, o[1].y), pack_bf16x2(o[1].z, o[1].w)};
+          *reinterpret_cast<u32x4*>(dst) = pk;
+        }
+      }
+    }
+  }
+}
+
+// The wave-per-token form of rounds 1-5 (MFP_MASK_WAVE=1: A/B)
+template <typename TX>
+__global__ __launch_bounds__(256) void mask_wave_kernel(MaskCols cols, int* __restrict__ idx_all, int NCOL,
                                                    const int* __restrict__ nvalid, const int* __restrict__ tasks,
                                                    int T, int S, unsigned long long seed,
                                                    unsigned long long offset0, const int* __restrict__ step_ptr) {
@@ -222,18 +340,27 @@ extern "C" int mfp_mask_tokens(const mfp_mask_col* cols, int32_t ncols, int32_t*
   mc.n = ncols;
   for (int i = 0; i < ncols; ++i) {
     MFP_CHECK_ARG(cols[i].src && cols[i].mask_out);
-    if (cols[i].is_numerical) MFP_CHECK_ARG(cols[i].x_out && cols[i].rowcode && cols[i].n_feat % 4 == 0);
+    if (cols[i].is_numerical) MFP_CHECK_ARG(cols[i].x_out && cols[i].rowcode && cols[i].n_feat % 8 == 0 && ((uintptr_t)cols[i].x_out % 16) == 0);
     else MFP_CHECK_ARG(cols[i].n_feat >= 1 && cols[i].n_feat <= 64 && cols[i].input_dim > 0);
     mc.c[i] = cols[i];
   }
   const int T = B * S;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (x_dtype == MFP_F32)
-    hipLaunchKernelGGL(mask_kernel<float>, dim3((T + 3) / 4), dim3(256), 0, st, mc, idx_all, NCOL, nvalid, tasks, T, S,
+  const char* env = getenv("MFP_MASK_WAVE");
+  if (env != nullptr && env[0] == '1') {      // (A/B: the wave-per-token form)
+    if (x_dtype == MFP_F32)
+      hipLaunchKernelGGL(mask_wave_kernel<float>, dim3((T + 3) / 4), dim3(256), 0, st, mc, idx_all, NCOL, nvalid, tasks, T, S,
+                         seed, offset, step_ptr);
+    else
+      hipLaunchKernelGGL(mask_wave_kernel<unsigned short>, dim3((T + 3) / 4), dim3(256), 0, st, mc, idx_all, NCOL, nvalid,
+                         tasks, T, S, seed, offset, step_ptr);
+  } else if (x_dtype == MFP_F32) {
+    hipLaunchKernelGGL(mask_kernel<float>, dim3((T + MK_TOK - 1) / MK_TOK), dim3(256), 0, st, mc, idx_all, NCOL, nvalid, tasks, T, S,
                        seed, offset, step_ptr);
-  else
-    hipLaunchKernelGGL(mask_kernel<unsigned short>, dim3((T + 3) / 4), dim3(256), 0, st, mc, idx_all, NCOL, nvalid,
+  } else {
+    hipLaunchKernelGGL(mask_kernel<unsigned short>, dim3((T + MK_TOK - 1) / MK_TOK), dim3(256), 0, st, mc, idx_all, NCOL, nvalid,
                        tasks, T, S, seed, offset, step_ptr);
+  }
   MFP_CHECK_LAUNCH();
   return MFP_OK;
 }

@@ -584,7 +584,7 @@ int mfp_colsum(const void* X, float* colsum, void* workspace, size_t workspace_b
  */
 typedef struct mfp_mask_col {
   int32_t is_numerical;
-  int32_t n_feat;          /* categorical: N; numerical: width W (W % 4 == 0) */
+  int32_t n_feat;          /* categorical: N; numerical: width W (W % 8 == 0) */
   int32_t input_dim;       /* categorical C */
   int32_t group;           /* attribute-group id (task = group + 2) */
   const void* src;         /* int32 [T][N] or f32 [T][W] (unmasked batch column) */

@@ -109,6 +109,44 @@ def test_fused_masking_equals_oracle_on_inferred_draws(dataset, method):
             assert got_m[k][b].sum() == 1 and got_m[k][b].argmax() == sel[b] and sel[b] < length[b]
 
 
+@pytest.mark.parametrize("B,S,dtype", [(48, 40, "fp32"), (5, 13, "bf16"), (64, 128, "bf16")])
+def test_mask_kernel_forms_agree(B, S, dtype):
+    """mask_kernel (round 5: sixteen tokens per workgroup, numerical rows streamed with their loads up front) against the
+    wave-per-token form it replaces (MFP_MASK_WAVE=1): Philox is keyed by (seed, token, column / feature / float4 index, step), so
+    every output must be bit-identical -- every task type in the mix, ragged lengths, a token count that is not a multiple of 16."""
+    import os
+    from oracle import np_masking as om
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    method = "random_elem_type_pos_attr_img_txt"
+    batch = synthetic_batch(ic, B, S, seed=6, ragged=True, device=DEV)
+    model = MFP(ic, num_blocks=1, latent_dim=128, dropout=0.0, l2=1e-2, dtype=dtype, device=DEV, seed=13, masking_method=method)
+    probs = om.task_probs(om.get_task_names(_nd(ic)), method)
+    tasks = torch.from_numpy(om.sample_tasks(probs, np.random.default_rng(3).permutation(B) / B + 0.5 / B)).to(DEV)
+    ctx = model.model.make_ctx(batch, True)
+    outs = []
+    old = os.environ.get("MFP_MASK_WAVE")
+    try:
+        for flag in ("1", "0"):
+            os.environ["MFP_MASK_WAVE"] = flag
+            idx_all, codes, xs, masks = model._masker(batch, tasks, ctx.nvalid, B, S, None)
+            torch.cuda.synchronize()
+            outs.append((idx_all.clone(), [c.clone() for c in codes], [x.clone() for x in xs], {k: v.clone() for k, v in masks.items()}))
+    finally:
+        if old is None:
+            os.environ.pop("MFP_MASK_WAVE", None)
+        else:
+            os.environ["MFP_MASK_WAVE"] = old
+    (i0, c0, x0, m0), (i1, c1, x1, m1) = outs
+    assert torch.equal(i0, i1)
+    for a, b in zip(c0 + x0, c1 + x1):
+        assert torch.equal(a.view(torch.uint8) if a.dtype == torch.bfloat16 else a, b.view(torch.uint8) if b.dtype == torch.bfloat16 else b)
+    for k in m0:
+        assert torch.equal(m0[k], m1[k]), k
+    assert any(int((x == 10.0).all(-1).sum()) > 0 for x in x1)      # (something was masked)
+
+
 # ------------------------------------------------------------------ validation / test metric path
 def _oracle_metrics(ic, params, L, S, targets, modified, masks, sort_flag=None):
     from oracle import np_ref
