@@ -467,7 +467,12 @@ __global__ __launch_bounds__(512) void attn_block_bwd_kernel(AttnBwdBlockParams 
     // (dead: the barrier behind the last product)
     const int c16 = lane >> 1, sub = (lane & 1) * 8;
     auto dy_of = [&](int r) { return *reinterpret_cast<const u32x2*>(smem + r * 512 + ((c16 ^ (r & 15)) << 4) + sub); };
-    if constexpr (LNB == 2) {
+    if constexpr (LNB == 2 && SDOC == 128) {      // (16-byte accesses: 8 columns per lane, two rows per wave instruction; -6 us per c2 step)
+      u32x4 xhv[8];
+      ln_tile_load_xh16(ln_tile_xh_rsrc(p.ln, p.T), row0, wave, lane, xhv);
+      auto dy_of8 = [&](int r, int s5) { return *reinterpret_cast<const u32x4*>(smem + r * 512 + ((s5 ^ (r & 15)) << 4)); };
+      ln_bwd_tile16<8>(p.ln, p.T, row0, blockIdx.x, wave, lane, tid, xhv, dy_of8, reinterpret_cast<float*>(smem + BB_Q));
+    } else if constexpr (LNB == 2) {      // (S = 64: the 16-byte form cost this instance eight more spilled registers and 4 us per step)
       u32x2 xhv[16];
       ln_tile_load_xh(ln_tile_xh_rsrc(p.ln, p.T), row0, wave, lane, xhv);
       ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wave, lane, tid, xhv, dy_of, reinterpret_cast<float*>(smem + BB_Q));

@@ -638,15 +638,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
 
   // LNB: the x1 rows of the LN2-backward epilogue (wave w: rows 16 w .. + 15, a lane 4 columns) are requested at the head of
   // chunk 14 -- the d_o2 fragments are dead by then, the 64 registers change hands -- and cross the last two chunks in flight
-  constexpr int LN_PF = LNB ? NR : 0;
+  constexpr int LN_PF = LNB == 2 ? NR / 2 : LNB ? NR : 0;      // (x-hat form: 16-byte loads, two rows per wave instruction)
   f32x4 xv[NR];      // (dead registers in the other forms)
-  u32x2 xhv[NR];
+  u32x4 xhv[NR / 2];
   const __amdgpu_buffer_rsrc_t rs_x = LNB == 2 ? ln_tile_xh_rsrc(p.ln, p.T) : ln_tile_x_rsrc(p.ln, LNB ? p.T : 0);
   auto chunk = [&](auto cc_) {
     constexpr int c = decltype(cc_)::value;
     constexpr int q = c >> 2, ffn2 = (c >> 1) & 1, j = c & 1;
     if constexpr (LNB == 1 && c == MLP_CHUNKS - 2) ln_tile_load_x(rs_x, row0, wv, lane, xv);
-    if constexpr (LNB == 2 && c == MLP_CHUNKS - 2) ln_tile_load_xh(rs_x, row0, wv, lane, xhv);
+    if constexpr (LNB == 2 && c == MLP_CHUNKS - 2) ln_tile_load_xh16(rs_x, row0, wv, lane, xhv);
     // the next quarter's h goes into its image while the two dy2 chunks of this quarter run (the masks of this
     // quarter were read before the barrier that ended the previous chunk); waited for at the end of the next chunk
     if (ffn2 && j == 0 && q < 3) hload(q + 1);
@@ -774,7 +774,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
     const unsigned char* img = Ws + ((lane >> 5) ? 0 : 2) * MLP_WS_B;      // this lane's column half
     const int c16 = (lane & 31) >> 1, sub = (lane & 1) * 8;
     auto dy_of = [&](int r) { return *reinterpret_cast<const u32x2*>(img + r * 256 + ((c16 ^ (r & 15)) << 4) + sub); };
-    if constexpr (LNB == 2) ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xhv, dy_of, reinterpret_cast<float*>(Ws + 1 * MLP_WS_B));
+    // (x-hat form: 8 columns per lane -- the 16-byte slot s of tile row r: column half s >> 4 in its image)
+    auto dy_of8 = [&](int r, int s5) {
+      return *reinterpret_cast<const u32x4*>(Ws + ((s5 >> 4) ? 0 : 2) * MLP_WS_B + r * 256 + (((s5 & 15) ^ (r & 15)) << 4));
+    };
+    if constexpr (LNB == 2) ln_bwd_tile16<8>(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xhv, dy_of8, reinterpret_cast<float*>(Ws + 1 * MLP_WS_B));
     else ln_bwd_tile(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xv, dy_of, reinterpret_cast<float*>(Ws + 1 * MLP_WS_B));
   }
 }
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
 
   f32x4 acc2[4][2][2];
   bf16x8 hf[2][4];
-  u32x2 xhv[16];      // (LNB: the tile's x-hat rows, wave w rows 16 w .. + 15)
+  u32x4 xhv[8];       // (LNB: the tile's x-hat rows, wave w rows 16 w .. + 15, two rows per 16-byte-per-lane load)
   int xs[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
     constexpr bool lastq = kq == DG_KQ - 1;
     if (c + 2 < DG_CHUNKS) wload(c + 2);
     if (!LNB && lastq && j == 2) out_store(0);        // behind the barrier that ended (last, 1); AFTER the weight loads (counted waits)
-    if constexpr (LNB && c == DG_CHUNKS - 1) ln_tile_load_xh(ln_tile_xh_rsrc(p.ln, p.T), row0, wv, lane, xhv);      // 16 loads cross the last chunk
+    if constexpr (LNB && c == DG_CHUNKS - 1) ln_tile_load_xh16(ln_tile_xh_rsrc(p.ln, p.T), row0, wv, lane, xhv);      // 8 loads cross the last chunk
     if (j == 0 && kq >= 1 && kq + 1 < DG_KQ) aload(kq + 1);
     if (j == 0) {
 #pragma unroll
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
     {
       // weight waves: chunk c + 1 landed when at most the 8 loads of chunk c + 2 (and the 4 stores of result half 0,
       // issued at the head of (last, 2)) are younger; activation waves: piece kq + 1 is due at the end of (kq, 3)
-      constexpr int allowed_w = (c + 2 < DG_CHUNKS ? 8 : 0) + ((!LNB && lastq && j == 2) ? 4 : 0) + ((LNB && c == DG_CHUNKS - 1) ? 16 : 0);
+      constexpr int allowed_w = (c + 2 < DG_CHUNKS ? 8 : 0) + ((!LNB && lastq && j == 2) ? 4 : 0) + ((LNB && c == DG_CHUNKS - 1) ? 8 : 0);
       if (wv < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed_w) : "memory");
       else if (j == 3 && kq + 1 < DG_KQ) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1044,10 +1048,10 @@ __global__ __launch_bounds__(256, 2) void dgrad_half_kernel(DgradParams p) {
   wgg_free_static_for<0, DG_CHUNKS>(chunk);
   if constexpr (LNB) {
     // dy sits in the two activation buffers as bf16 images of its column halves; the partial sums go through the weight ring
-    const unsigned char* img = As + ((DG_KQ + (lane >> 5)) & 1) * H_AS_B;      // this lane's column half
-    const int c16 = (lane & 31) >> 1, sub = (lane & 1) * 8;
-    auto dy_of = [&](int r) { return *reinterpret_cast<const u32x2*>(img + r * 256 + ((c16 ^ (r & 15)) << 4) + sub); };
-    ln_bwd_tile<4>(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xhv, dy_of, reinterpret_cast<float*>(Ws));
+    auto dy_of8 = [&](int r, int s5) {      // the 16-byte slot s5 of tile row r: column half s5 >> 4 in its image
+      return *reinterpret_cast<const u32x4*>(As + ((DG_KQ + (s5 >> 4)) & 1) * H_AS_B + r * 256 + (((s5 & 15) ^ (r & 15)) << 4));
+    };
+    ln_bwd_tile16<4>(p.ln, p.T, row0, blockIdx.x, wv, lane, tid, xhv, dy_of8, reinterpret_cast<float*>(Ws));
   } else {
     out_store(1);
   }

@@ -129,3 +129,115 @@ __device__ __forceinline__ void ln_bwd_tile(const LnTileArgs& q, int T, int row0
     q.part[(size_t)tile * (3 * D) + c] = a;
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// ln_bwd_tile with 16-BYTE accesses (round 5, x-hat form only): a lane owns 8 consecutive columns, a wave instruction covers
+// TWO rows (lanes 0-31: row 2 i, lanes 32-63: row 2 i + 1) -- x-hat / dres loads and dx / masked-copy stores of 16 bytes per
+// lane instead of 8 (8-byte accesses run at 0.54-0.70 of the 16-byte rate: MI355X_MICROARCH.md; the epilogue is a pure memory
+// phase).  NH = row PAIRS per wave (8: a 128-row tile on eight waves or a 64-row tile on four; 4: a 64-row tile on eight waves).
+// dy_of8(r, s) = the 8 bf16 values (u32x4) of tile row r at columns 8 s .. + 7.  Row sums: four DPP steps inside each 16-lane
+// row, then the two rows of a half-wave through scalar registers.
+template <int NH>
+__device__ __forceinline__ void ln_tile_load_xh16(const __amdgpu_buffer_rsrc_t rs_xh, int row0, int wv, int lane, u32x4 (&xv)[NH]) {
+#pragma unroll
+  for (int i = 0; i < NH; ++i)
+    xv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_xh, (unsigned int)(row0 + wv * (2 * NH) + 2 * i + (lane >> 5)) * 512u + (lane & 31) * 16, 0, 0));
+}
+
+template <int NWV = 8, typename DyOf8, int NH>
+__device__ __forceinline__ void ln_bwd_tile16(const LnTileArgs& q, int T, int row0, int tile, int wv, int lane, int tid,
+                                              const u32x4 (&xv)[NH], DyOf8 dy_of8, float* red) {
+  constexpr int D = 256;
+  const unsigned int rbytes = (unsigned int)T * (D * 2);
+  const __amdgpu_buffer_rsrc_t rs_dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(q.dres), 0, rbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc(q.dx, 0, rbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc(q.ddrop ? q.ddrop : q.dx, 0, q.ddrop ? rbytes : 0u, 0x00020000);
+  const int r0 = wv * (2 * NH), half = lane >> 5, s5 = lane & 31;
+  u32x4 rv[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i)
+    rv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dr, (unsigned int)(row0 + r0 + 2 * i + half) * (D * 2) + s5 * 16, 0, 0));
+  const f32x4 gam0 = *reinterpret_cast<const f32x4*>(q.gamma + s5 * 8), gam1 = *reinterpret_cast<const f32x4*>(q.gamma + s5 * 8 + 4);
+  const float gam[8] = {gam0[0], gam0[1], gam0[2], gam0[3], gam1[0], gam1[1], gam1[2], gam1[3]};
+  // the 2 NH rows' rstd in lanes 0 .. 2 NH - 1, broadcast per row by v_readlane
+  float rs_l = 0.f;
+  if (lane < 2 * NH && row0 + r0 + lane < T) rs_l = q.rstd[row0 + r0 + lane];
+  const unsigned long long rng_off = q.offset + (q.step_ptr ? (unsigned long long)(*q.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);
+  const float inv_keep = q.drop_p > 0.f ? 1.f / (1.f - q.drop_p) : 1.f;
+  const unsigned int dkey = drop_key(q.seed, rng_off), dthr = drop_thr16(q.drop_p);
+  float dg[8], db[8], dc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dg[e] = db[e] = dc[e] = 0.f;
+  auto unpack8 = [](const u32x4& v, float (&o)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(v[j] << 16); o[2 * j + 1] = __uint_as_float(v[j] & 0xFFFF0000u); }
+  };
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int r = r0 + 2 * i + half, row = row0 + r;
+    const bool live = row < T;
+    const float rsa = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rs_l), 2 * i));
+    const float rsb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rs_l), 2 * i + 1));
+    const float rs = half ? rsb : rsa;
+    float d[8], xh[8], res[8], gy[8];
+    unpack8(dy_of8(r, s5), d);
+    unpack8(xv[i], xh);
+    unpack8(rv[i], res);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[e] += d[e] * xh[e];
+      db[e] += d[e];
+      gy[e] = d[e] * gam[e];
+      s1 += gy[e];
+      s2 += gy[e] * xh[e];
+    }
+    // sums over the 32 lanes of this lane's row: 16-lane rows by DPP, the two rows of a half-wave through scalar registers
+    s1 += mfp_dpp_f<0xB1>(s1); s1 += mfp_dpp_f<0x4E>(s1); s1 += mfp_dpp_f<0x141>(s1); s1 += mfp_dpp_f<0x140>(s1);
+    s2 += mfp_dpp_f<0xB1>(s2); s2 += mfp_dpp_f<0x4E>(s2); s2 += mfp_dpp_f<0x141>(s2); s2 += mfp_dpp_f<0x140>(s2);
+    const int v1 = __builtin_bit_cast(int, s1), v2 = __builtin_bit_cast(int, s2);
+    const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v1, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(v1, 16));
+    const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v1, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(v1, 48));
+    const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v2, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(v2, 16));
+    const float b2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v2, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(v2, 48));
+    const float m1 = (half ? b1 : a1) * (1.0f / D), m2 = (half ? b2 : a2) * (1.0f / D);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = rs * (gy[e] - m1 - xh[e] * m2) + res[e];
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])},
+                                           rs_dx, (unsigned int)row * (D * 2) + s5 * 16, 0, 0);
+    if (q.ddrop != nullptr) {
+      if (q.drop_p > 0.f) {
+        const unsigned int rowh = drop_row(dkey, (unsigned int)row);
+        bool k0[4], k1[4];
+        drop_keep4(rowh, (unsigned int)(s5 * 8), dthr, k0);
+        drop_keep4(rowh, (unsigned int)(s5 * 8 + 4), dthr, k1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = k0[e] ? o[e] * inv_keep : 0.f; o[4 + e] = k1[e] ? o[4 + e] * inv_keep : 0.f; }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])},
+                                             rs_dd, (unsigned int)row * (D * 2) + s5 * 16, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dc[e] += live ? o[e] : 0.f;
+    }
+  }
+  // the tile's partial sums: the two half-waves hold the same columns (even / odd rows) -> one exchange, then NWV waves through LDS
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dg[e] += lane_xor32(dg[e]); db[e] += lane_xor32(db[e]); dc[e] += lane_xor32(dc[e]); }
+  if (half == 0) {
+    *reinterpret_cast<f32x4*>(red + (wv * 3 + 0) * D + s5 * 8) = (f32x4){dg[0], dg[1], dg[2], dg[3]};
+    *reinterpret_cast<f32x4*>(red + (wv * 3 + 0) * D + s5 * 8 + 4) = (f32x4){dg[4], dg[5], dg[6], dg[7]};
+    *reinterpret_cast<f32x4*>(red + (wv * 3 + 1) * D + s5 * 8) = (f32x4){db[0], db[1], db[2], db[3]};
+    *reinterpret_cast<f32x4*>(red + (wv * 3 + 1) * D + s5 * 8 + 4) = (f32x4){db[4], db[5], db[6], db[7]};
+    *reinterpret_cast<f32x4*>(red + (wv * 3 + 2) * D + s5 * 8) = (f32x4){dc[0], dc[1], dc[2], dc[3]};
+    *reinterpret_cast<f32x4*>(red + (wv * 3 + 2) * D + s5 * 8 + 4) = (f32x4){dc[4], dc[5], dc[6], dc[7]};
+  }
+  __syncthreads();
+  for (int c = tid; c < 3 * D; c += NWV * 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) a += red[w * 3 * D + c];
+    q.part[(size_t)tile * (3 * D) + c] = a;
+  }
+}
