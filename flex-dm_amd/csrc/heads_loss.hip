@@ -15,8 +15,8 @@
 // is cut into 64-column chunks.  Per chunk c (32 KB of W = rows col0 .. col0 + 63 as a [64][512 B] LDS image, 3-buffer
 // LDS-DMA ring, counted waits):
 //   1. logits tile = W_c x^T (transposed product: a lane holds 4 consecutive columns of its row) + bias
-//   2. categorical: tile -> LDS (f32), one 16-lane group per ACTIVE (row, item) runs softmax / clipped CE / gradient in
-//      place (ce_tile_kernel's walk), 16-byte pieces of inactive items / padding are written as zeros -> bf16 dl image;
+//   2. categorical: tile -> LDS (f32), the dl image zeroed, one 16-lane group per ACTIVE (row, item) runs softmax / clipped CE /
+//      gradient (ce_tile_kernel's walk) and writes the item's d(logits) into the dl image as bf16 (inactive items / padding stay 0);
 //      numerical: in the accumulator layout -- targets (loaded one chunk ahead, only rows that carry a loss) ->
 //      2 (p - y) / B -> dl image; sum of squares / |y|^2 / |p|^2 / y.p per row carried in registers across the head's chunks
 //   3. dl image -> HBM (dlogits) and, as the B operand, dx += dl_c W_c with W_c read TRANSPOSED from the same LDS image
@@ -275,7 +275,14 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
     }
     HL_TR(4 * c + 1);
     if (kind == 0) {
-      // ---- 2a. categorical chunk: logits -> LDS, active (row, item) pairs compacted
+      // ---- 2a. categorical chunk: logits -> LDS, active (row, item) pairs compacted; the dl image starts as zeros (every wave is
+      // past B1, i.e. past the previous chunk's reads of it) -- the walk below writes the gradients of the ACTIVE items straight
+      // into it as bf16 (round 5: the f32 write-back + barrier + tile -> image conversion pass cost ~0.9 us per categorical chunk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid_c + 512 * i;
+        *reinterpret_cast<u32x4*>(Dli + (idx >> 3) * 128 + ((idx & 7) << 4)) = (u32x4){0u, 0u, 0u, 0u};
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -341,38 +348,21 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
           gp += gg[q] * zv[q];
         }
         gp = row16_sum(gp);
+        // d(logits) of the item's classes -> the dl image (bf16; column cc of the chunk sits in 16-byte slot (cc >> 3) ^ isw(row))
+        const int cc0 = Itab[16 + item] - col0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (l16 + 16 * q < C) z[l16 + 16 * q] = zv[q] * (gg[q] - gp) * p.inv_B;
+          if (l16 + 16 * q < C) {
+            const int cc = cc0 + l16 + 16 * q;
+            *reinterpret_cast<unsigned short*>(Dli + row * 128 + (((cc >> 3) ^ isw(row)) << 4) + (cc & 7) * 2) = f32_to_bf16(zv[q] * (gg[q] - gp) * p.inv_B);
+          }
         if (l16 == 0) {
           atomicAdd(&Red[kidx * 3 + 0], loss * p.inv_B);
           atomicAdd(&Red[kidx * 3 + 1], am == y ? 1.f : 0.f);
           atomicAdd(&Red[kidx * 3 + 2], 1.f);
         }
       }
-      if (c < 8) HL_TR(128 + 8 * c + 2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                                  // B3
-      if (c < 8) HL_TR(128 + 8 * c + 3);
-      if (tid_c == 0) *Nact = 0;
-      const unsigned long long pmap = (unsigned long long)(unsigned int)p.ch[c][3] | ((unsigned long long)(unsigned int)p.ch[c][4] << 32);
-      // tile -> dl image: a thread converts two 8-column pieces; pieces of inactive items / padding / other chunks' columns are 0
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid_c + 512 * i, row = idx >> 3, c8 = idx & 7;
-        const int item = (int)((pmap >> (8 * c8)) & 0xFFull);
-        u32x4 pk = {0u, 0u, 0u, 0u};
-        if (item != 0xFF && Wrow[Itab[item] * 128 + row]) {
-          const float* src = Tile + row * HL_TW + c8 * 8;
-          const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
-          const int lim = Itab[16 + item] + Itab[32 + item] - (col0 + c8 * 8);       // classes of the item left in this piece
-          float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e >= lim) v[e] = 0.f;
-          pk = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        }
-        *reinterpret_cast<u32x4*>(Dli + row * 128 + ((c8 ^ isw(row)) << 4)) = pk;
-      }
+      if (c < 8) { HL_TR(128 + 8 * c + 2); HL_TR(128 + 8 * c + 3); }
     } else {
       // ---- 2b. numerical chunk, in the accumulator layout
       const int k = ckey;
@@ -423,6 +413,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                    // B4: the dl image is complete
     HL_TR(4 * c + 2);
+    if (kind == 0 && tid_c == 0) *Nact = 0;      // (every thread read the count behind B2; the next compaction is behind B1)
     if (kind == 1 && clast && nh == 0) {
       const int k = ckey;
       float l0 = 0.f, l1 = 0.f, l2 = 0.f;
@@ -484,20 +475,36 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
     const float inv_keep = 1.0f / (1.0f - p.dropout_p);
     const unsigned int dthr = drop_thr16(p.dropout_p);
     const unsigned int dkey = drop_key(p.seed, p.offset + (unsigned long long)step_now * MFP_RNG_STEP_STRIDE);
+    // The two bf16 copies leave in 16-BYTE pieces (8-byte stores run at about half the rate: MI355X_MICROARCH.md): the lanes (li, g)
+    // and (li, g ^ 1) hold adjacent 4-column groups of the same two rows -- the even-g lane takes row tile 0 of both (its own four
+    // columns + its neighbour's), the odd-g lane row tile 1; one row swap (v_permlane16_swap) per dword on the way.
+    const bool odd = (g & 1) != 0;
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
+    for (int ct = 0; ct < 8; ++ct) {
+      const int n0c = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16;
+      u32x2 pb[2], pd[2];      // [rt]: unmasked / dropout-masked bf16 of this lane's 4 columns
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const int row = row0 + rp * 32 + rt * 16 + li, n = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16 + 4 * g;
+        const int row = row0 + rp * 32 + rt * 16 + li, n = n0c + 4 * g;
         const f32x4 v = acc2[ct][rt];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_c, (unsigned int)row * (HL_D * 4) + n * 4, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rs_cb, (unsigned int)row * (HL_D * 2) + n * 2, 0, 0);
+        pb[rt] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         bool keep[4] = {true, true, true, true};
         if (p.dropout_p > 0.f) drop_keep4(drop_row(dkey, (unsigned int)row), (unsigned int)n, dthr, keep);
-        const u32x2 pk = {pack_bf16x2(keep[0] ? v[0] * inv_keep : 0.f, keep[1] ? v[1] * inv_keep : 0.f),
-                          pack_bf16x2(keep[2] ? v[2] * inv_keep : 0.f, keep[3] ? v[3] * inv_keep : 0.f)};
-        __builtin_amdgcn_raw_buffer_store_b64(pk, rs_d, (unsigned int)row * (HL_D * 2) + n * 2, 0, 0);
+        pd[rt] = (u32x2){pack_bf16x2(keep[0] ? v[0] * inv_keep : 0.f, keep[1] ? v[1] * inv_keep : 0.f),
+                         pack_bf16x2(keep[2] ? v[2] * inv_keep : 0.f, keep[3] ? v[3] * inv_keep : 0.f)};
       }
+      // send the row tile this lane does NOT store, receive the neighbour's share of the one it does
+      const u32x2 sb = odd ? pb[0] : pb[1], sd = odd ? pd[0] : pd[1];
+      const u32x2 rb = {__float_as_uint(lane_xor16(__uint_as_float(sb[0]))), __float_as_uint(lane_xor16(__uint_as_float(sb[1])))};
+      const u32x2 rd = {__float_as_uint(lane_xor16(__uint_as_float(sd[0]))), __float_as_uint(lane_xor16(__uint_as_float(sd[1])))};
+      const u32x2 mb = odd ? pb[1] : pb[0], md = odd ? pd[1] : pd[0];
+      const int row = row0 + rp * 32 + (odd ? 16 : 0) + li, n8 = n0c + 8 * (g >> 1);
+      const u32x4 ob = odd ? (u32x4){rb[0], rb[1], mb[0], mb[1]} : (u32x4){mb[0], mb[1], rb[0], rb[1]};
+      const u32x4 od = odd ? (u32x4){rd[0], rd[1], md[0], md[1]} : (u32x4){md[0], md[1], rd[0], rd[1]};
+      __builtin_amdgcn_raw_buffer_store_b128(ob, rs_cb, (unsigned int)row * (HL_D * 2) + n8 * 2, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(od, rs_d, (unsigned int)row * (HL_D * 2) + n8 * 2, 0, 0);
+    }
   }
   __syncthreads();
   HL_TR(255);
