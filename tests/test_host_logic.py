@@ -180,3 +180,31 @@ def test_fused_path_hint():
     assert "--seq_len 64" in fused_path_hint("bf16", 256, None, 256)
     assert "even" in fused_path_hint("bf16", 256, 64, 3)
     assert "latent_dim 128" in fused_path_hint("bf16", 128, 32, 8)
+
+
+def test_half_tile_routing_predicates(monkeypatch):
+    """When the kernels run on HALF tiles (mfp/hip/functions.py): the one-launch block forward when two workgroups per 128-row tile
+    still fit the chip in one round -- half a document at S = 128, ONE document at S = 64 (the reference's default batch of 256
+    at --seq_len 64 = 128 tiles on 256 CUs) -- the MLP half's backward likewise, and the switches that force either way; the
+    64-row activation-stationary workgroups follow MFP_FUSED_HALF as csrc/block_fused.hip's half_mode() does."""
+    from types import SimpleNamespace
+    from mfp.hip import functions, ops
+    monkeypatch.setattr(ops, "cu_count", lambda device=None: 256)
+    ctx = SimpleNamespace(store=SimpleNamespace(w=SimpleNamespace(device=None)))
+    monkeypatch.setattr(functions, "BLOCK_HALF", "")
+    monkeypatch.setattr(functions, "MLP_BWD_HALF", "")
+    assert functions._block_half_on(ctx, 128, 128) and not functions._block_half_on(ctx, 129, 128)      # c4 | one document more
+    assert not functions._block_half_on(ctx, 256, 128)                                                   # c2: the chip is full
+    assert functions._block_half_on(ctx, 256, 64) and not functions._block_half_on(ctx, 512, 64)         # default batch | c2 at S = 64
+    assert not functions._block_half_on(ctx, 8, 32)                                                      # no document tile at S = 32
+    assert functions._mlp_bwd_half_on(ctx, 128 * 128) and not functions._mlp_bwd_half_on(ctx, 256 * 128)
+    monkeypatch.setattr(functions, "BLOCK_HALF", "0")
+    assert not functions._block_half_on(ctx, 4, 128)
+    monkeypatch.setattr(functions, "BLOCK_HALF", "1")
+    assert functions._block_half_on(ctx, 256, 128) and not functions._block_half_on(ctx, 8, 32)
+    monkeypatch.delenv("MFP_FUSED_HALF", raising=False)
+    assert ops.fused_half_mode(128 * 128) and not ops.fused_half_mode(256 * 128)
+    monkeypatch.setenv("MFP_FUSED_HALF", "0")
+    assert not ops.fused_half_mode(128)
+    monkeypatch.setenv("MFP_FUSED_HALF", "1")
+    assert ops.fused_half_mode(1 << 20)
