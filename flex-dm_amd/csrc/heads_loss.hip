@@ -97,8 +97,14 @@ __device__ __forceinline__ int row16_min(int v) {
 __device__ __forceinline__ int isw(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int dsw(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
 
-template <bool LOGITS>      // LOGITS: the f32 logits are written (4 more stores per thread and chunk in the counted schedule)
+// LOGITS: the f32 logits are written (2 RT more stores per thread and chunk in the counted schedule).
+// RT = 16-row tiles per wave: 2 = one workgroup per 128 rows; 1 (round 6) = per 64 rows, for batches with fewer 128-row tiles than
+// CUs (BASELINE config c4: 128 documents per GPU = 128 tiles on 256 CUs): the same eight waves, wave (rp, nh) owns rows 16 rp ..
+// + 15 -- every row walks the same instructions on the same operands as in the 128-row form: logits, d(logits) and dx are
+// bit-identical to it; the per-key sums are the same terms in twice as many partial rows.
+template <bool LOGITS, int RT = 2>
 __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
+  constexpr int RS = 64 * RT;      // rows of the workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Ws = smem;
   float* const Tile = reinterpret_cast<float*>(smem + HL_TILE);
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rp = wave & 3, nh = wave >> 2;
-  const int row0 = blockIdx.x * HL_ROWS;
+  const int row0 = blockIdx.x * RS;
   const int nch = p.nch;
   constexpr unsigned int OOB = 0xFFFFFFF0u;
   const int step_now = (p.dXd && p.step_ptr) ? __builtin_amdgcn_readfirstlane(*p.step_ptr) : 0;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   };
   unsigned int onm[2] = {0u, 0u};      // bit k: this lane's row (of row tile rt) carries a loss for key k (filled after the prologue)
   // ---- targets of a numerical chunk for this lane's (row tile, column tile) pairs: only rows that carry a loss
-  auto tload = [&](int c, f32x4 (&tg)[2][2]) {
+  auto tload = [&](int c, f32x4 (&tg)[2][RT]) {
     const int w1 = c < nch ? p.ch[c][1] : 0;
     const bool num = (w1 & 0xff) == 1;
     const int k = num ? ((w1 >> 8) & 0xff) : 0;
@@ -152,10 +158,10 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(key.target), 0, num ? (unsigned int)p.T * (unsigned int)key.n_class * 4u : 0u, 0x00020000);
     const int cb = num ? (p.ch[c < nch ? c : 0][0] & 0xffff) - key.col_off : 0;
     // (branch-free: offsets first, then the four loads back to back)
-    unsigned int off[2][2];
+    unsigned int off[2][RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const int row = rp * 32 + rt * 16 + li;
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = rp * (16 * RT) + rt * 16 + li;
       const bool on = num & (((onm[rt] >> k) & 1u) != 0u);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -164,43 +170,44 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
         tg[nt][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, off[nt][rt], 0, 0));
   };
 
   // ---- prologue: x fragments, chunks 0 and 1; per (key, row) weights, per (row, item) labels, bias -> LDS
-  bf16x8 xf[2][8];
+  bf16x8 xf[RT][8];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
       xf[rt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-          rs_x, (unsigned int)(row0 + rp * 32 + rt * 16 + li) * (HL_D * 2) + g * 16 + ks * 64, 0, 0));
+          rs_x, (unsigned int)(row0 + rp * (16 * RT) + rt * 16 + li) * (HL_D * 2) + g * 16 + ks * 64, 0, 0));
   wload(0);
   wload(1);
   {
-    // (four keys / four items per thread, all their loads issued before the first is used: one memory round trip each,
-    //  not a chain per key; the key index is wave-uniform, so the key records are scalar loads)
-    const int row = tid & 127, t = row0 + row;
-    const int kq = __builtin_amdgcn_readfirstlane(tid >> 7);
+    // (four keys / four items per thread (RT = 1: two), all their loads issued before the first is used: one memory round trip
+    //  each, not a chain per key; the key index is wave-uniform, so the key records are scalar loads)
+    constexpr int KG = 512 / RS, KI = 16 / KG;      // key groups of RS threads, keys per thread
+    const int row = tid & (RS - 1), t = row0 + row;
+    const int kq = __builtin_amdgcn_readfirstlane(tid / RS);
     const bool live = t < p.T;
     const int b = live ? t / p.S : 0, s = t - b * p.S;
     const int nv = p.nvalid[b];
-    unsigned char m[4]; int v[4]; int y[4];
+    unsigned char m[KI]; int v[KI]; int y[KI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = kq + 4 * i;
+    for (int i = 0; i < KI; ++i) {
+      const int k = kq + KG * i;
       const mfp_loss_key& key = p.key[k < p.nkeys ? k : 0];
       m[i] = (live && k < p.nkeys) ? key.mask[t] : 0;
       v[i] = (live && k < p.nkeys && key.cond_idx != nullptr) ? key.cond_idx[(long long)t * key.cond_stride] : 0;
-      const int it = kq + 4 * i;
+      const int it = kq + KG * i;
       const int itc = it < p.nitem ? it : 0;
       const mfp_loss_key& ikey = p.key[p.item_key[itc]];
       y[i] = (live && it < p.nitem) ? reinterpret_cast<const int*>(ikey.target)[(long long)t * ikey.n_feat + p.item_feat[itc]] : 0;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = kq + 4 * i;
+    for (int i = 0; i < KI; ++i) {
+      const int k = kq + KG * i;
       if (k < p.nkeys) {
         const mfp_loss_key& key = p.key[k];
         const bool cnd = key.cond_idx == nullptr || (v[i] >= 0 && v[i] < 32 && ((key.cond_bits >> v[i]) & 1u));
@@ -217,24 +224,27 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
   __builtin_amdgcn_s_barrier();
 
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-    for (int k = 0; k < p.nkeys; ++k) onm[rt] |= (unsigned int)(Wrow[k * 128 + rp * 32 + rt * 16 + li] != 0) << k;
+  for (int rt = 0; rt < RT; ++rt)
+    for (int k = 0; k < p.nkeys; ++k) onm[rt] |= (unsigned int)(Wrow[k * 128 + rp * (16 * RT) + rt * 16 + li] != 0) << k;
   int xs[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ dsw(li)) << 4;
-  f32x4 acc2[8][2];
+  f32x4 acc2[8][RT];
 #pragma unroll
-  for (int a = 0; a < 8; ++a) acc2[a][0] = acc2[a][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float ms[2][4];      // numerical head in flight: per row tile {sum d^2, sum y^2, sum p^2, sum y p} over this lane's columns
+  for (int a = 0; a < 8; ++a)
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) ms[rt][0] = ms[rt][1] = ms[rt][2] = ms[rt][3] = 0.f;
-  f32x4 tg[2][2];
+    for (int rt = 0; rt < RT; ++rt) acc2[a][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ms[RT][4];      // numerical head in flight: per row tile {sum d^2, sum y^2, sum p^2, sum y p} over this lane's columns
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) ms[rt][0] = ms[rt][1] = ms[rt][2] = ms[rt][3] = 0.f;
+  f32x4 tg[2][RT];
   tload(0, tg);
 
   for (int c = 0; c < nch; ++c) {
     // chunk c has landed: younger than its four loads are the 10 (6) other operations of iteration c - 2 and the 14 (10) of c - 1
-    if (LOGITS) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    // (per iteration: 4 weight loads, 2 RT logits stores, 2 RT target loads, RT d(logits) stores)
+    constexpr int PER_IT = 4 + (LOGITS ? 2 * RT : 0) + 2 * RT + RT;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_IT - 4) : "memory");
     __builtin_amdgcn_s_barrier();                                                    // B1
     HL_TR(4 * c);
     // (opaque copies per iteration: loop-invariant address arithmetic is not hoisted out of the loop and kept in registers)
@@ -246,18 +256,20 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
     wload(c + 2);                                                                    // 4 loads
     const unsigned char* wb = Ws + (c % 3) * HL_WS_B;
     // ---- 1. logits tile: acc[nt][rt] = rows 32 rp + 16 rt + li_c, columns col0 + (2 nh + nt) 16 + 4 g_c .. + 3
-    f32x4 acc[2][2];
+    f32x4 acc[2][RT];
     {
       const unsigned char* wa = wb + ((nh * 2) * 16 + li_c) * 512;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[nt][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wa + nt * 8192 + xs[ks & 3] + (ks >> 2) * 256);
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt) acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[rt][ks], acc[nt][rt], 0, 0, 0);
+          for (int rt = 0; rt < RT; ++rt) acc[nt][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[rt][ks], acc[nt][rt], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -265,9 +277,9 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         const int cc = (nh * 2 + nt) * 16 + 4 * g_c;
         const f32x4 bb = *reinterpret_cast<const f32x4*>(Bias + col0 + cc);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           acc[nt][rt] += bb;
-          const int row = rp * 32 + rt * 16 + li_c;
+          const int row = rp * (16 * RT) + rt * 16 + li_c;
           if (LOGITS) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[nt][rt]), rs_lg,
                                                  cc < ncols ? (unsigned int)(row0 + row) * ldb4 + (unsigned int)(col0 + cc) * 4u : OOB, 0, 0);   // 4 stores
         }
@@ -279,18 +291,18 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
       // past B1, i.e. past the previous chunk's reads of it) -- the walk below writes the gradients of the ACTIVE items straight
       // into it as bf16 (round 5: the f32 write-back + barrier + tile -> image conversion pass cost ~0.9 us per categorical chunk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < RT; ++i) {
         const int idx = tid_c + 512 * i;
         *reinterpret_cast<u32x4*>(Dli + (idx >> 3) * 128 + ((idx & 7) << 4)) = (u32x4){0u, 0u, 0u, 0u};
       }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-          *reinterpret_cast<f32x4*>(Tile + (rp * 32 + rt * 16 + li_c) * HL_TW + (nh * 2 + nt) * 16 + 4 * g_c) = acc[nt][rt];
+        for (int rt = 0; rt < RT; ++rt)
+          *reinterpret_cast<f32x4*>(Tile + (rp * (16 * RT) + rt * 16 + li_c) * HL_TW + (nh * 2 + nt) * 16 + 4 * g_c) = acc[nt][rt];
       const int item0 = cw2 & 0xff, ni = (cw2 >> 8) & 0xff;
-      for (int idx = tid_c; idx < 128 * ni; idx += 512) {      // (128 ni is a multiple of the wave size: whole waves)
-        const int row = idx & 127, j = idx >> 7;
+      for (int idx = tid_c; idx < RS * ni; idx += 512) {      // (RS ni is a multiple of the wave size: whole waves)
+        const int row = idx & (RS - 1), j = idx / RS;
         const bool on = Wrow[Itab[item0 + j] * 128 + row] != 0;
         // one LDS atomic per wave (per-item atomics on the one counter were most of this phase)
         const unsigned long long bm = __ballot(on);
@@ -368,11 +380,11 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
       const int k = ckey;
       if (cfirst) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) ms[rt][0] = ms[rt][1] = ms[rt][2] = ms[rt][3] = 0.f;
+        for (int rt = 0; rt < RT; ++rt) ms[rt][0] = ms[rt][1] = ms[rt][2] = ms[rt][3] = 0.f;
       }
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int row = rp * 32 + rt * 16 + li_c;
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = rp * (16 * RT) + rt * 16 + li_c;
         const bool on = ((onm[rt] >> k) & 1u) != 0u;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
       if (clast) {
         // row sums: over the 4 lanes of a row in this wave, then the two column halves (waves nh = 0, 1) through LDS
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             ms[rt][q] += lane_xor16(ms[rt][q]);
@@ -402,8 +414,8 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
           }
         if (nh == 1 && g_c == 0) {
 #pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-            *reinterpret_cast<f32x4*>(Tile + (rp * 32 + rt * 16 + li_c) * 4) = (f32x4){ms[rt][0], ms[rt][1], ms[rt][2], ms[rt][3]};
+          for (int rt = 0; rt < RT; ++rt)
+            *reinterpret_cast<f32x4*>(Tile + (rp * (16 * RT) + rt * 16 + li_c) * 4) = (f32x4){ms[rt][0], ms[rt][1], ms[rt][2], ms[rt][3]};
         }
       }
     }
@@ -419,8 +431,8 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
       float l0 = 0.f, l1 = 0.f, l2 = 0.f;
       if (g_c == 0) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const int row = rp * 32 + rt * 16 + li_c;
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = rp * (16 * RT) + rt * 16 + li_c;
           if (Wrow[k * 128 + row]) {
             const f32x4 o = *reinterpret_cast<const f32x4*>(Tile + row * 4);
             const float sd = ms[rt][0] + o[0], sy = ms[rt][1] + o[1], sp = ms[rt][2] + o[2], syp = ms[rt][3] + o[3];
@@ -434,17 +446,17 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
     }
     // ---- 3. dl image -> dlogits (16-byte pieces of the chunk's own columns), dx += dl_c W_c
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int idx = tid_c + 512 * i, row = idx >> 3, c8 = idx & 7;
       const u32x4 v = *reinterpret_cast<const u32x4*>(Dli + row * 128 + ((c8 ^ isw(row)) << 4));
       __builtin_amdgcn_raw_buffer_store_b128(v, rs_dl, c8 * 8 < ncols ? (unsigned int)(row0 + row) * ldb2 + (unsigned int)(col0 + c8 * 8) * 2u : OOB, 0, 0);   // 2 stores
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 hf[2];
+      bf16x8 hf[RT];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int row = rp * 32 + rt * 16 + li_c;
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = rp * (16 * RT) + rt * 16 + li_c;
         // (k order of a transposing read: lane group g holds u = 32 ks + 4 g + j and 32 ks + 16 + 4 g + j, j = 0..3 --
         //  the dl operand is picked up in the same order: two 8-byte pieces)
         const int p0 = 8 * ks + g_c, p1 = p0 + 4;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 MFP_LDS*)(ptr + 16 * 512));     // (row + 16: same swizzle)
         const bf16x8 wt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt, hf[rt], acc2[ct][rt], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt) acc2[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt, hf[rt], acc2[ct][rt], 0, 0, 0);
       }
     }
     HL_TR(4 * c + 3);
@@ -482,10 +494,10 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
       const int n0c = ((ct >> 2) * 8 + nh * 4 + (ct & 3)) * 16;
-      u32x2 pb[2], pd[2];      // [rt]: unmasked / dropout-masked bf16 of this lane's 4 columns
+      u32x2 pb[RT], pd[RT];      // [rt]: unmasked / dropout-masked bf16 of this lane's 4 columns
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int row = row0 + rp * 32 + rt * 16 + li, n = n0c + 4 * g;
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = row0 + rp * (16 * RT) + rt * 16 + li, n = n0c + 4 * g;
         const f32x4 v = acc2[ct][rt];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_c, (unsigned int)row * (HL_D * 4) + n * 4, 0, 0);
         pb[rt] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -495,15 +507,18 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
                          pack_bf16x2(keep[2] ? v[2] * inv_keep : 0.f, keep[3] ? v[3] * inv_keep : 0.f)};
       }
       // send the row tile this lane does NOT store, receive the neighbour's share of the one it does
-      const u32x2 sb = odd ? pb[0] : pb[1], sd = odd ? pd[0] : pd[1];
+      // (RT = 1: one row tile -- the even-g lane stores its four columns + its neighbour's, the odd-g lane's stores go out of range)
+      const u32x2 sb = (RT == 1 || odd) ? pb[0] : pb[RT - 1], sd = (RT == 1 || odd) ? pd[0] : pd[RT - 1];
       const u32x2 rb = {__float_as_uint(lane_xor16(__uint_as_float(sb[0]))), __float_as_uint(lane_xor16(__uint_as_float(sb[1])))};
       const u32x2 rd = {__float_as_uint(lane_xor16(__uint_as_float(sd[0]))), __float_as_uint(lane_xor16(__uint_as_float(sd[1])))};
-      const u32x2 mb = odd ? pb[1] : pb[0], md = odd ? pd[1] : pd[0];
-      const int row = row0 + rp * 32 + (odd ? 16 : 0) + li, n8 = n0c + 8 * (g >> 1);
-      const u32x4 ob = odd ? (u32x4){rb[0], rb[1], mb[0], mb[1]} : (u32x4){mb[0], mb[1], rb[0], rb[1]};
-      const u32x4 od = odd ? (u32x4){rd[0], rd[1], md[0], md[1]} : (u32x4){md[0], md[1], rd[0], rd[1]};
-      __builtin_amdgcn_raw_buffer_store_b128(ob, rs_cb, (unsigned int)row * (HL_D * 2) + n8 * 2, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(od, rs_d, (unsigned int)row * (HL_D * 2) + n8 * 2, 0, 0);
+      const u32x2 mb = (RT == 2 && odd) ? pb[RT - 1] : pb[0], md = (RT == 2 && odd) ? pd[RT - 1] : pd[0];
+      const int row = row0 + rp * (16 * RT) + ((RT == 2 && odd) ? 16 : 0) + li, n8 = n0c + 8 * (g >> 1);
+      const bool second = RT == 2 && odd;      // (this lane's own columns are the piece's second half)
+      const u32x4 ob = second ? (u32x4){rb[0], rb[1], mb[0], mb[1]} : (u32x4){mb[0], mb[1], rb[0], rb[1]};
+      const u32x4 od = second ? (u32x4){rd[0], rd[1], md[0], md[1]} : (u32x4){md[0], md[1], rd[0], rd[1]};
+      const unsigned int o16 = (RT == 1 && odd) ? OOB : (unsigned int)row * (HL_D * 2) + n8 * 2;
+      __builtin_amdgcn_raw_buffer_store_b128(ob, rs_cb, o16, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(od, rs_d, o16, 0, 0);
     }
   }
   __syncthreads();
@@ -515,11 +530,12 @@ __global__ __launch_bounds__(512) void heads_loss_kernel(HlParams p) {
 }  // namespace
 
 extern "C" size_t mfp_heads_loss_partials(int32_t T) { return (size_t)((T + HL_ROWS - 1) / HL_ROWS); }
+extern "C" size_t mfp_heads_loss_partials_half(int32_t T) { return (size_t)((T + 63) / 64); }
 
-extern "C" int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys,
-                                      int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits,
-                                      float* dx, void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p,
-                                      uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+static int heads_loss_impl(int rows, const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys,
+                           int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits,
+                           float* dx, void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p,
+                           uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
   MFP_CHECK_ARG(x && W && bias && keys && nvalid && part && dlogits && (dx || dx_bf16));
   MFP_CHECK_ARG(B > 0 && S > 0 && D == HL_D && U > 0 && U % 8 == 0 && U <= HL_MAXU && nkeys > 0 && nkeys <= MFP_MAX_LOSS_KEYS);
   MFP_CHECK_ARG((long long)B * S <= (1 << 20) && dropout_p >= 0.f && dropout_p < 1.f);
@@ -600,14 +616,41 @@ extern "C" int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float*
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_loss_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, HL_LDS);
     if (e != hipSuccess) {
       mfp_set_error("mfp_heads_loss_fwd_bwd: cannot raise dynamic LDS to %d: %s", HL_LDS, hipGetErrorString(e));
       return MFP_ELAUNCH;
     }
     attr_set = true;
   }
-  if (logits != nullptr) hipLaunchKernelGGL(heads_loss_kernel<true>, dim3((p.T + HL_ROWS - 1) / HL_ROWS), dim3(512), HL_LDS, reinterpret_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(heads_loss_kernel<false>, dim3((p.T + HL_ROWS - 1) / HL_ROWS), dim3(512), HL_LDS, reinterpret_cast<hipStream_t>(stream), p);
+  const dim3 grid((p.T + rows - 1) / rows);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (rows == 64) {
+    if (logits != nullptr) hipLaunchKernelGGL((heads_loss_kernel<true, 1>), grid, dim3(512), HL_LDS, st, p);
+    else hipLaunchKernelGGL((heads_loss_kernel<false, 1>), grid, dim3(512), HL_LDS, st, p);
+  } else {
+    if (logits != nullptr) hipLaunchKernelGGL((heads_loss_kernel<true, 2>), grid, dim3(512), HL_LDS, st, p);
+    else hipLaunchKernelGGL((heads_loss_kernel<false, 2>), grid, dim3(512), HL_LDS, st, p);
+  }
   MFP_CHECK_LAUNCH();
   return MFP_OK;
+}
+
+extern "C" int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys,
+                                      int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits,
+                                      float* dx, void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p,
+                                      uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  return heads_loss_impl(HL_ROWS, x, W, bias, U, keys, nkeys, nvalid, part, dlogits, logits, dx, dx_bf16, dx_drop, B, S, D, dropout_p, seed,
+                         offset, step_ptr, stream);
+}
+
+// The same launch on 64-row tiles (one eight-wave workgroup per 64 rows; `part` holds mfp_heads_loss_partials_half(B * S) rows):
+// batches with fewer 128-row tiles than CUs (BASELINE config c4: 128 documents per GPU).  logits / dlogits / dx bit-identical.
+extern "C" int mfp_heads_loss_fwd_bwd_half(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys,
+                                           int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits,
+                                           float* dx, void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p,
+                                           uint64_t seed, uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream) {
+  return heads_loss_impl(64, x, W, bias, U, keys, nkeys, nvalid, part, dlogits, logits, dx, dx_bf16, dx_drop, B, S, D, dropout_p, seed,
+                         offset, step_ptr, stream);
 }

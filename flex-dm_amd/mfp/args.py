@@ -34,7 +34,9 @@ _BASE_FLAGS = [
                      help="compute dtype of the HIP kernels (fp32 = exact-f32 MFMA parity path; fp8 = bf16 with "
                           "e4m3 QKV / FFN1 forward products)")),
     ("--device", dict(default="cuda", help="HIP device of this rank")),
-    ("--seq_len", dict(default=None, type=int, help="synthetic batches: padded sequence length")),
+    ("--seq_len", dict(default=None, type=int, help="padded sequence length of every batch.  Unset: bf16 / fp8 at --latent_dim 256 "
+                       "pad each batch to 64 positions (128 if a document is longer) so that it runs on the document-tile kernels "
+                       "(padding is inert); 0: pad each batch to its longest document as the reference does")),
     ("--use_graph", dict(action="store_true", help="capture the train step into hipGraphs")),
 ]
 

@@ -300,7 +300,9 @@ def parse_examples(records: List[bytes], schema, device: str = "cpu", include_de
     for _, lists in parsed:
         for steps in lists.values():
             S = max(S, len(steps))
-    if seq_len is not None:       # fixed-shape batches (hipGraph replay): pad every batch to seq_len
+    if isinstance(seq_len, (tuple, list)):      # buckets (mfp.train's default): the smallest that holds the batch, else its own length
+        S = next((b for b in sorted(seq_len) if b >= S), S)
+    elif seq_len is not None:       # fixed-shape batches (hipGraph replay): pad every batch to seq_len
         if S > seq_len:
             raise ValueError("document of %d elements does not fit seq_len=%d" % (S, seq_len))
         S = seq_len
@@ -476,8 +478,14 @@ class DataSpec(object):
     ``mfp.data.tfrecord``); otherwise batches are synthetic.
     """
 
-    def __init__(self, name, path, batch_size=8, seq_len: Optional[int] = None,
+    def __init__(self, name, path, batch_size=8, seq_len=None,
                  device: str = "cpu", ragged: bool = True):
+        # seq_len: None = pad each batch to its longest document (the reference, spec.py:255-276); an int = pad every batch to
+        # it; a tuple of buckets, e.g. (64, 128) = pad each batch to the smallest bucket that holds it (padding is inert: masked
+        # keys, masked losses) so that it lands on the document-tile kernels
+        buckets = tuple(seq_len) if isinstance(seq_len, (tuple, list)) else None
+        if buckets:
+            seq_len = None
         self._name = name
         self._path = path or "synthetic"
         self._batch_size = batch_size
@@ -500,8 +508,8 @@ class DataSpec(object):
             if os.path.exists(cpath):
                 with open(cpath) as f:
                     self._splits = json.load(f)
-        self._fixed_seq_len = seq_len      # None: pad each batch to its longest document (the reference)
-        self._seq_len = seq_len or 50
+        self._fixed_seq_len = buckets or seq_len      # None: pad each batch to its longest document (the reference)
+        self._seq_len = seq_len or (min(buckets) if buckets else 50)
         if not hasattr(self, "_splits"):
             docs = docs or 4 * batch_size
             self._splits = {"train": docs, "val": max(batch_size, docs // 4),

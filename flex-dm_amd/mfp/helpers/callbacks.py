@@ -90,7 +90,7 @@ class ProfileStep:
             base = os.path.join(self.log_dir, "profile_step%d" % self.profile_batch)
             self._prof.export_chrome_trace(base + ".trace.json")
             with open(base + ".kernels.txt", "w") as f:
-                f.write(self._prof.key_averages().table(sort_by="cuda_time_total", row_limit=60))
+                f.write(self._prof.key_averages().table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=200))
             logger.info("profile of train step %d written to %s.*", self.profile_batch, base)
         except Exception as exc:
             logger.warning("could not export the profile: %s", exc)

@@ -165,6 +165,10 @@ SIGNATURES = {
     "mfp_heads_loss_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
                                          c_uint64, c_uint64, c_void_p, c_void_p]),
+    "mfp_heads_loss_partials_half": (ctypes.c_size_t, [c_int32]),
+    "mfp_heads_loss_fwd_bwd_half": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
+                                              c_uint64, c_uint64, c_void_p, c_void_p]),
     "mfp_loss_fwd_bwd_acc": (c_int32, [c_void_p, c_void_p, c_int32, POINTER(LossKey), c_int32, c_void_p, c_void_p,
                                        c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "mfp_sample_tasks": (c_int32, [POINTER(c_float), c_int32, c_void_p, c_int32, c_uint64, c_uint64, c_void_p, c_void_p]),

@@ -537,7 +537,10 @@ class BlockFn(torch.autograd.Function):
             fctx.xhat = (xh1_5, xh2_5)
             fctx.saved = (x, y1, mean1, rstd1, qkv, a, lse, x1, y2, mean2, rstd2, h)
             return x2
-        if ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T):
+        # (the attention-half-only launch exists for documents of 128 positions; S = 64 is served by the whole-block forms above:
+        #  with MFP_BLOCK_FWD=0 such a batch takes the generic launches below)
+        attn_half = ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T) and S == 128
+        if attn_half:
             # the whole attention half in one launch
             x1, y1, mean1, rstd1, qkv, a, lse = ops.attn_block_fwd(
                 x, st.weight(p + "norm1/gamma"), st.weight(p + "norm1/beta"), st.cw(p + "attn/dense_query/kernel", rows=3 * D),
@@ -552,7 +555,7 @@ class BlockFn(torch.autograd.Function):
                                           st.cw(p + "attn/dense_query/kernel", rows=3 * D), T, 3 * D, D,
                                           st.span(st.w, p + "attn/dense_query/bias", 3 * D),
                                           w8=st.w8(p + "attn/dense_query/kernel", 3 * D) if st.fp8 else None)
-        if not (ATTN_BLOCK and _fused_ok(ctx, D) and not st.fp8 and _doc_tile_ok(B, S, T)):
+        if not attn_half:
             a, lse = ops.attention_fwd(qkv, ctx.nvalid, B, S, NUM_HEADS)
             x1 = ops.gemm(a, st.cw(p + "attn/combine_heads/kernel"), T, D, D, a_kmajor=True, b_kmajor=True,
                           bias=st.weight(p + "attn/combine_heads/bias"), residual=x,

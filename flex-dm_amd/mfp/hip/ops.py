@@ -987,9 +987,20 @@ def heads_loss_fused_ok(keys: Sequence[dict], U: int, D: int, T: int = 0, want_l
     return items <= 16 and chunks <= 40
 
 
+# heads + loss launch on 64-row tiles when the 128-row tiles do not fill the chip (c4: 128 documents per GPU); unset = by grid
+# size, "0" / "1" = A/B
+HEADS_HALF = os.environ.get("MFP_HEADS_HALF", "")
+
+
+def heads_half_on(T: int, device=None) -> bool:
+    if HEADS_HALF != "":
+        return HEADS_HALF == "1"
+    return 2 * ((T + 127) // 128) <= cu_count(device)
+
+
 def heads_loss_fused(x_c: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, keys: Sequence[dict], nvalid: torch.Tensor,
                      B: int, S: int, dlogits: Optional[torch.Tensor] = None, want_logits: bool = True,
-                     drop: Optional[tuple] = None, dx_dtype: torch.dtype = torch.float32):
+                     drop: Optional[tuple] = None, dx_dtype: torch.dtype = torch.float32, half_tiles: Optional[bool] = None):
     """Heads forward + LossLayer + heads input gradient in ONE launch (see mfp_heads_loss_fwd_bwd).  x_c bf16 [B*S,256],
     W bf16 [U,256], bias f32 [U].  Returns (part [P,48] per-workgroup partial sums, dlogits bf16 [T,U], logits f32 [T,U] or
     None, dx f32 [T,256], dx_drop bf16 [T,256] or None); ``drop`` = (p, seed, offset, step_ptr) as in :func:`dgrad_rows`.
@@ -999,7 +1010,8 @@ def heads_loss_fused(x_c: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, key
     U = W.shape[0]
     dev = x_c.device
     arr = _loss_key_array(keys)
-    P = lib.mfp_heads_loss_partials(T)
+    half = heads_half_on(T, dev) if half_tiles is None else half_tiles
+    P = lib.mfp_heads_loss_partials_half(T) if half else lib.mfp_heads_loss_partials(T)
     part = torch.empty((P, 48), dtype=torch.float32, device=dev)
     if dlogits is None:
         dlogits = torch.empty((T, U), dtype=torch.bfloat16, device=dev)
@@ -1009,10 +1021,11 @@ def heads_loss_fused(x_c: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, key
     p_, seed_, off_, sp_ = drop if drop is not None else (0.0, 0, 0, None)
     nb = T * (D * 2 + U * 2 + D * _esz(dx) + (D * 2 if drop is not None else 0) + (U * 4 if want_logits else 0)) + U * D * 2
     with _timed("heads_loss_kernel", 2 * 2 * T * U * D, nb):
-        check(lib.mfp_heads_loss_fwd_bwd(_ptr(x_c), _ptr(W), _ptr(bias), U, arr, len(keys), _ptr(nvalid), _ptr(part),
-                                         _ptr(dlogits), _ptr(logits), _ptr(dx) if dx_dtype == torch.float32 else None,
-                                         _ptr(dx) if dx_dtype == torch.bfloat16 else None, _ptr(dxd), B, S, D, float(p_), int(seed_),
-                                         int(off_), _ptr(sp_), _stream()), "mfp_heads_loss_fwd_bwd")
+        fn = lib.mfp_heads_loss_fwd_bwd_half if half else lib.mfp_heads_loss_fwd_bwd
+        check(fn(_ptr(x_c), _ptr(W), _ptr(bias), U, arr, len(keys), _ptr(nvalid), _ptr(part),
+                 _ptr(dlogits), _ptr(logits), _ptr(dx) if dx_dtype == torch.float32 else None,
+                 _ptr(dx) if dx_dtype == torch.bfloat16 else None, _ptr(dxd), B, S, D, float(p_), int(seed_),
+                 int(off_), _ptr(sp_), _stream()), "mfp_heads_loss_fwd_bwd")
     return part, dlogits, logits, dx, dxd
 
 

@@ -21,20 +21,36 @@ logger = logging.getLogger(__name__)
 def fused_path_hint(dtype, latent_dim, seq_len, docs_per_rank):
     """One line when the run will NOT take the document-tile / activation-stationary kernels (mfp/hip/functions.py), with
     the flag that puts it there; None when it will.  The datasets' sequences are at most 51 positions long (data/*-spec.yml:
-    length <= 50), so ``--seq_len 64`` (two documents per 128-row tile) costs 1.25x the padding of the longest batch and runs
-    the fused kernels; without ``--seq_len`` every batch has its own length and is stepped on the generic kernels."""
+    length <= 50), so 64 positions (two documents per 128-row tile) cost 1.25x the padding of the longest batch and run
+    the fused kernels: that is what an unset ``--seq_len`` resolves to (default_seq_len); ``--seq_len 0`` keeps the reference's
+    per-batch lengths, which are stepped on the generic kernels."""
     if dtype not in ("bf16", "fp8"):
         return None      # (the f32 parity path has no fused kernels)
     if latent_dim == 512:
         return None      # csrc/block_d512.hip takes any sequence length
     if latent_dim != 256:
         return ("latent_dim %d runs on the generic tile kernels (the fused kernels are built for --latent_dim 256 and 512)" % latent_dim)
+    if isinstance(seq_len, (tuple, list)):      # the default: every batch padded to 64 (128) positions
+        return None if docs_per_rank % 2 == 0 else ("batches of %d documents per GPU: 64-position documents go two to a tile, "
+                                                    "an odd batch runs on the generic kernels" % docs_per_rank)
     if seq_len == 128 or (seq_len == 64 and docs_per_rank % 2 == 0):
         return None
     if seq_len == 64:
         return "--seq_len 64 needs an even number of documents per GPU for the document-tile kernels (got %d)" % docs_per_rank
     return ("--seq_len %s falls off the document-tile kernels (generic attention / projection launches, ~1.3x slower per element); "
             "use --seq_len 64 (two documents per tile; sequences are at most 51 positions long) or --seq_len 128" % seq_len)
+
+
+def default_seq_len(dtype, latent_dim, seq_len):
+    """What ``--seq_len`` resolves to.  Unset (None): on the bf16 / fp8 path at d_model 256 every batch is padded to 64 positions
+    (128 when its longest document is longer; beyond that its own length) -- the reference pads a batch to its longest document
+    (src/mfp/mfp/data/spec.py:255-276), which lands every batch on the generic kernels; padding is inert (masked keys, masked
+    losses: tests/test_gpu_fullsize.py::test_padding_is_inert) and the datasets' documents are at most 51 positions long, so the
+    reference's own command line (bin/train_mfp.sh:16-20) steps on the document-tile kernels.  ``--seq_len 0`` = the reference's
+    ragged batches; any other value pads every batch to it."""
+    if seq_len is None:
+        return (64, 128) if dtype in ("bf16", "fp8") and latent_dim == 256 else None
+    return None if seq_len == 0 else seq_len
 
 
 def train(args):
@@ -59,11 +75,12 @@ def train(args):
     checkpoint_dir = os.path.join(args.job_dir, "checkpoints")
     checkpoint_path = os.path.join(checkpoint_dir, "best.ckpt")
 
-    hint = fused_path_hint(args.dtype, args.latent_dim, args.seq_len, args.batch_size // max(world, 1))
+    seq_len = default_seq_len(args.dtype, args.latent_dim, args.seq_len)
+    hint = fused_path_hint(args.dtype, args.latent_dim, seq_len, args.batch_size // max(world, 1))
     if hint and dp.rank() == 0:
         print("mfp.train: " + hint, flush=True)
     dataspec = DataSpec(args.dataset_name, args.data_dir, batch_size=args.batch_size,
-                        seq_len=args.seq_len, device=device)
+                        seq_len=seq_len, device=device)
     train_dataset = dataspec.make_dataset("train", shuffle=True, repeat=True, cache=True)
     val_dataset = dataspec.make_dataset("val", cache=True)
     test_dataset = dataspec.make_dataset("test", cache=True)

@@ -506,6 +506,15 @@ int mfp_heads_loss_fwd_bwd(const void* x, const void* W, const float* bias, int3
                            int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits, float* dx,
                            void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed,
                            uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
+/* The same launch on 64-row tiles (one eight-wave workgroup per 64 rows) for batches with fewer 128-row tiles than CUs
+ * (BASELINE config c4: 128 documents per GPU = 128 tiles on 256 CUs): part f32 [mfp_heads_loss_partials_half(B*S)][48];
+ * logits, dlogits, dx and its copies are bit-identical to mfp_heads_loss_fwd_bwd's, the per-key sums the same terms in
+ * twice as many partial rows. */
+size_t mfp_heads_loss_partials_half(int32_t T);
+int mfp_heads_loss_fwd_bwd_half(const void* x, const void* W, const float* bias, int32_t U, const mfp_loss_key* keys /*host*/,
+                                int32_t nkeys, const int32_t* nvalid, float* part, void* dlogits, float* logits, float* dx,
+                                void* dx_bf16, void* dx_drop, int32_t B, int32_t S, int32_t D, float dropout_p, uint64_t seed,
+                                uint64_t offset, const int32_t* step_ptr, mfp_stream_t stream);
 
 /* sort_inputs (reference models/tensor_utils.py:14-44) as a row map.  Per document b with flag[b]:
  *   priority(s) = sum_k v_k(s) * 100^(4-k) + [s >= nvalid[b]] * 100^5   (k over type, left, top,

@@ -77,6 +77,32 @@ def test_train_cli_on_tfrecord_directory(tmp_path, capsys):
     assert os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))
 
 
+def test_default_command_line_runs_the_document_tile_kernels(tmp_path, capsys):
+    """bin/train_mfp.sh as the reference documents it -- no --seq_len -- on a TFRecord directory (bin/train_mfp.sh:16-20,
+    src/mfp/mfp/data/spec.py:255-276): the batches are padded to 64 positions and stepped on the document-tile kernels
+    (attn_block_fwd_kernel with SDOC = 64: one launch per block forward), and ``--seq_len 0`` keeps the reference's per-batch
+    lengths on the generic kernels."""
+    from mfp.data.spec import write_synthetic_tfrecords
+    from mfp.main import main
+    data = str(tmp_path / "crello")
+    write_synthetic_tfrecords(data, "crello", {"train": 32, "val": 8, "test": 8}, seq_len=11, seed=5)
+
+    def run(job, *extra):
+        main(["--dataset_name", "crello", "--data_dir", data, "--job-dir", job, "--num_blocks", "1", "--batch_size", "8",
+              "--num_epochs", "1", "--validation_freq", "1", "--verbose", "0", "--enable_profile", *extra])
+        out = capsys.readouterr().out
+        assert "total_score" in out and os.path.exists(os.path.join(job, "checkpoints", "final.ckpt.safetensors"))
+        return out, open(os.path.join(job, "logs", "profile_step2.kernels.txt")).read()
+
+    out, kernels = run(str(tmp_path / "job_default"))      # latent_dim 256, bf16: the flags' defaults
+    assert "attn_block_fwd_kernel" in kernels and "mfp.train:" not in out, kernels[:3000]
+    import re
+    targs = [m.group(1).replace(" ", "").split(",") for m in re.finditer(r"attn_block_fwd_kernel<([^>]*)>", kernels)]
+    assert targs and all(len(a) >= 4 and a[3] == "64" for a in targs), targs      # <DROPOUT, MLP, STASH, SDOC, ...>
+    out, kernels = run(str(tmp_path / "job_ragged"), "--seq_len", "0")
+    assert "attn_block_fwd_kernel" not in kernels and "falls off the document-tile kernels" in out
+
+
 def test_weights_from_tensorflow_checkpoint(tmp_path, capsys):
     """--weights / load_weights on a TensorFlow checkpoint prefix (train.py:67-69): the bundle is
     read without TensorFlow and every variable lands where the Keras object graph says."""

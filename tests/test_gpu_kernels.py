@@ -1354,6 +1354,23 @@ def test_heads_loss_fused(dataset, B, S, want_logits, p):
         _, dxd_u = ops.dgrad_rows(dl, Wt, U, drop=drop)
         both = (dx != 0) & (ops.dgrad_rows(dl, Wt, U) != 0)
         assert torch.equal((dxd != 0) & both, (dxd_u != 0) & both)
+    # round 6: the same launch on 64-row tiles (mfp_heads_loss_fwd_bwd_half; c4's per-GPU shape) -- every row walks the same
+    # instructions: logits, d(logits), dx and its masked copy bit for bit, the per-key sums the same terms in twice as many rows
+    for bf in (False, True):      # (f32 dx, then the bf16 residual-gradient stream's form)
+        dt = torch.bfloat16 if bf else torch.float32
+        full = ops.heads_loss_fused(xd, Wd, bd, descr, nvalid, B, S, want_logits=want_logits, drop=drop, dx_dtype=dt, half_tiles=False)
+        half = ops.heads_loss_fused(xd, Wd, bd, descr, nvalid, B, S, want_logits=want_logits, drop=drop, dx_dtype=dt, half_tiles=True)
+        assert half[0].shape[0] == (T + 63) // 64 and full[0].shape[0] == (T + 127) // 128
+        for a_, b_, what in zip(full[1:], half[1:], ("dlogits", "logits", "dx", "dx_drop")):
+            assert (a_ is None) == (b_ is None), what
+            if a_ is not None:
+                assert torch.equal(a_, b_), what
+        sh = torch.zeros(len(descr) * 3, device=DEV)
+        ops.reduce_partials(half[0], sh, 3 * len(descr))
+        sh = sh.view(len(descr), 3).cpu().double()
+        for i, k in enumerate(lay.head_order):
+            assert abs(sh[i, 0] - sums[i, 0]) <= 1e-5 * max(1.0, abs(sums[i, 0])) and abs(sh[i, 1] - sums[i, 1]) <= 1e-5 * max(1.0, abs(sums[i, 1])), k
+            assert sh[i, 2] == sums[i, 2], k
 
 
 @pytest.mark.parametrize("B,S", [(1, 128), (5, 128), (2, 64), (6, 64)])

@@ -519,10 +519,12 @@ class _route:
     def __enter__(self):
         import os
         from mfp.hip import functions
-        self.old = (functions.ATTN_BLOCK_BWD, os.environ.get("MFP_FUSED_HALF"), functions.BLOCK_HALF, functions.MLP_BWD_HALF)
+        from mfp.hip import ops
+        self.old = (functions.ATTN_BLOCK_BWD, os.environ.get("MFP_FUSED_HALF"), functions.BLOCK_HALF, functions.MLP_BWD_HALF, ops.HEADS_HALF)
         functions.ATTN_BLOCK_BWD = self.bwd
         functions.BLOCK_HALF = self.fwd_half
         functions.MLP_BWD_HALF = self.fwd_half
+        ops.HEADS_HALF = self.fwd_half      # (round 6: the heads + loss launch on 64-row tiles rides with the half-tile route)
         if self.half is None:
             os.environ.pop("MFP_FUSED_HALF", None)
         else:
@@ -531,9 +533,11 @@ class _route:
     def __exit__(self, *exc):
         import os
         from mfp.hip import functions
+        from mfp.hip import ops
         functions.ATTN_BLOCK_BWD = self.old[0]
         functions.BLOCK_HALF = self.old[2]
         functions.MLP_BWD_HALF = self.old[3]
+        ops.HEADS_HALF = self.old[4]
         if self.old[1] is None:
             os.environ.pop("MFP_FUSED_HALF", None)
         else:

@@ -180,6 +180,34 @@ def test_fused_path_hint():
     assert "--seq_len 64" in fused_path_hint("bf16", 256, None, 256)
     assert "even" in fused_path_hint("bf16", 256, 64, 3)
     assert "latent_dim 128" in fused_path_hint("bf16", 128, 32, 8)
+    assert fused_path_hint("bf16", 256, (64, 128), 256) is None and "odd" in fused_path_hint("bf16", 256, (64, 128), 7)
+
+
+def test_default_seq_len_pads_onto_the_document_tiles(tmp_path):
+    """The reference's own command line (no --seq_len; bin/train_mfp.sh:16-20) must land on the document-tile kernels: unset ->
+    buckets (64, 128) on the bf16 / fp8 path at d_model 256, --seq_len 0 -> the reference's per-batch lengths
+    (src/mfp/mfp/data/spec.py:255-276), an explicit value -> itself; the TFRecord reader pads a batch to the smallest bucket that
+    holds its longest document and leaves longer batches alone."""
+    import torch
+    from mfp.data.spec import DataSpec, write_synthetic_tfrecords
+    from mfp.train import default_seq_len
+    assert default_seq_len("bf16", 256, None) == (64, 128) and default_seq_len("fp8", 256, None) == (64, 128)
+    assert default_seq_len("fp32", 256, None) is None and default_seq_len("bf16", 128, None) is None
+    assert default_seq_len("bf16", 512, None) is None      # (csrc/block_d512.hip takes any sequence length)
+    assert default_seq_len("bf16", 256, 0) is None and default_seq_len("bf16", 256, 50) == 50
+    data = str(tmp_path / "crello")
+    write_synthetic_tfrecords(data, "crello", {"train": 12, "val": 4, "test": 4}, seq_len=9, seed=3)
+    ragged = next(iter(DataSpec("crello", data, batch_size=4).make_dataset("train")))
+    padded = next(iter(DataSpec("crello", data, batch_size=4, seq_len=(64, 128)).make_dataset("train")))
+    S0 = ragged["left"].shape[1]
+    assert S0 <= 9 and padded["left"].shape[1] == 64 and torch.equal(padded["length"], ragged["length"])
+    for k, v in ragged.items():
+        if v.dim() >= 2 and v.shape[1] == S0 and k != "length":
+            assert torch.equal(padded[k][:, :S0], v), k
+            assert not padded[k][:, S0:].any(), k      # zero padding, as the batched TF parser pads
+    # a batch longer than every bucket keeps its own length
+    v0 = next(iter(DataSpec("crello", data, batch_size=4).make_dataset("val")))["left"].shape[1]
+    assert v0 > 2 and next(iter(DataSpec("crello", data, batch_size=4, seq_len=(2,)).make_dataset("val")))["left"].shape[1] == v0
 
 
 def test_half_tile_routing_predicates(monkeypatch):
