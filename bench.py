@@ -465,7 +465,12 @@ def main():
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)                      # a real collective on the data-path backend: counts the ranks
         dp_info = dp.describe_plan(model.model.layout, graphed)
-        dp_info.update({"backend": dist.get_backend(), "collective_ranks": int(ones.item()), "world_size": dist.get_world_size()})
+        launches = getattr(model, "dp_graph_launches_per_step", None) if graphed else None
+        dp_info.update({"backend": dist.get_backend(), "collective_ranks": int(ones.item()), "world_size": dist.get_world_size(),
+                        "graph_launches_per_step": launches,
+                        "graph_mode": ("one graph per step, bucket all-reduces captured inside it" if launches == 1 else
+                                       "segments: one graph per backward segment + Adam, eager all-reduces between them")
+                        if graphed else "eager"})
 
     value = world * B * S * args.steps / elapsed
     lay = model.model.layout

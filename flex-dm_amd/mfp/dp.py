@@ -26,6 +26,7 @@ def init_from_env(backend: Optional[str] = None) -> int:
     # the plan switches are read when the step is captured: a typo should fail here, not minutes into a run
     bucket_cut_blocks(2)
     BucketReducer()
+    graph_mode()
     if not dist.is_initialized():
         # MFP_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests of the multi-rank step logic);
         # production is "nccl" (= RCCL on ROCm), one rank per GPU over xGMI.
@@ -50,6 +51,27 @@ def reserve_cus_from_env() -> int:
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def active() -> bool:
+    """The step runs its data-parallel form: more than one rank -- or ONE rank of an initialised process group under
+    MFP_DP_FORCE=1 (tests: the bucketed step, its all-reduces and their hipGraph capture on the one GPU a test box has)."""
+    if world_size() > 1:
+        return True
+    return os.environ.get("MFP_DP_FORCE", "") == "1" and dist.is_available() and dist.is_initialized()
+
+
+def graph_mode() -> str:
+    """``MFP_DP_GRAPH``: how the N > 1 step is replayed.  "one" = the whole step, bucket all-reduces included, is ONE hipGraph
+    (the collectives are captured on the communication stream as branches that run beside the next segment of the backward
+    pass: one graph launch per step, no host between a segment and its all-reduce); "segments" = one graph per backward
+    segment + one for Adam with the all-reduces launched eagerly between them (L + 1 graph launches per step; rounds 2-5);
+    "auto" (default) = "one" on the nccl (= RCCL) backend, falling back to "segments" when the capture is refused, and
+    "segments" on gloo (host-side collectives cannot be captured)."""
+    m = os.environ.get("MFP_DP_GRAPH", "auto")
+    if m not in ("auto", "one", "segments"):
+        raise ValueError("MFP_DP_GRAPH=%r (auto | one | segments)" % m)
+    return m
 
 
 def rank() -> int:
@@ -139,7 +161,7 @@ class BucketReducer:
         self.pending = []
 
     def launch(self, bucket: torch.Tensor):
-        if world_size() == 1 or bucket.numel() == 0:
+        if not active() or bucket.numel() == 0:
             return
         if self.bf16:
             tmp = bucket.to(torch.bfloat16)

@@ -363,7 +363,25 @@ class MFP:
                 self._apply()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        multi = dp.world_size() > 1
+        multi = dp.active()
+        self.dp_graph_launches_per_step = 1
+        if multi and dp.graph_mode() != "segments" and torch.distributed.get_backend() == "nccl":
+            # ONE graph for the whole data-parallel step, collectives included (dp.graph_mode); a refused capture falls
+            # back to the per-segment graphs below
+            try:
+                return self._capture_dp_one_graph(static, side)
+            except Exception as exc:      # noqa: BLE001 -- whatever the capture raised: say so and use the segment graphs
+                if dp.graph_mode() == "one":
+                    raise
+                import sys
+                print("mfp: one-graph capture of the data-parallel step refused (%s: %s); per-segment graphs"
+                      % (type(exc).__name__, exc), file=sys.stderr)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):      # (a clean eager step: the interrupted capture left half a step behind)
+                    self._forward_backward(static)
+                    self._apply()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
         segs = []           # (graph, gradient bucket completed by it) in backward order; N > 1 only
         g3 = None
@@ -438,6 +456,60 @@ class MFP:
         self._graph = replay
         self._graph_objs = (g1, segs, g3, static, static_sums)
         self.static_batch = static   # a loader that writes the next batch here avoids the copy
+        self.dp_graph_launches_per_step = len(segs) + 1 if multi else 1
+        return replay
+
+    def _capture_dp_one_graph(self, static, side):
+        """The N > 1 step as ONE hipGraph: forward, the backward pass cut at the block inputs (dp.bucket_cut_blocks), each
+        segment's gradient bucket all-reduced ASYNCHRONOUSLY (the collective is captured on the process group's communication
+        stream: a branch of the graph that runs beside the next segment's kernels), the join, Adam.  One graph launch per
+        step instead of L + 1 with eager collectives between them (VERDICT r05 #8)."""
+        grad = self.model.store.g
+        layout = self.model.layout
+        g = torch.cuda.CUDAGraph()
+        reducer = dp.BucketReducer()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            loss, static_sums, ctx = self._forward(static)
+            cut_blocks = [i for i in dp.bucket_cut_blocks(layout.L) if ctx is not None and i in ctx.cuts]
+            slices = dp.bucket_slices([layout.block_offset(i) for i in cut_blocks], grad.numel())
+            if cut_blocks:
+                x_prev = ctx.cuts[cut_blocks[0]]
+                d_prev = torch.autograd.grad(loss, x_prev, grad_outputs=self._unit_grad(loss))[0]
+                ctx.flush_ln_jobs()   # the segment's LayerNorm gradients must be final before its all-reduce
+            else:
+                loss.backward(self._unit_grad(loss))
+            self._join_sides()
+            reducer.launch(grad[slices[0]])
+            for k in range(1, len(cut_blocks) + 1):
+                if k < len(cut_blocks):
+                    x_k = ctx.cuts[cut_blocks[k]]
+                    d_k = torch.autograd.grad(x_prev, x_k, grad_outputs=d_prev)[0]
+                    ctx.flush_ln_jobs()
+                    x_prev, d_prev = x_k, d_k
+                else:
+                    x_prev.backward(d_prev)
+                self._join_sides()
+                reducer.launch(grad[slices[k]])
+            reducer.finish()
+            self.optimizer.step(grad_scale=1.0 / dp.world_size())
+
+        def replay(batch):
+            if any(k in static and tuple(v.shape) != tuple(static[k].shape) for k, v in batch.items()):
+                sums = self._forward_backward(batch)      # (another shape: eagerly, as the per-segment form does)
+                self._apply()
+                self.last_sums = sums
+                return sums
+            for k, v in batch.items():
+                if k in static and v.data_ptr() != static[k].data_ptr():
+                    static[k].copy_(v, non_blocking=True)
+            g.replay()
+            self.last_sums = static_sums
+            return static_sums
+
+        self._graph = replay
+        self._graph_objs = (g, [], None, static, static_sums)
+        self.static_batch = static
+        self.dp_graph_launches_per_step = 1
         return replay
 
     def _capture_resident(self, example_batch, warmup: int, resident: int):

@@ -310,6 +310,66 @@ def test_two_rank_step_on_one_gpu_over_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
     assert d["params_in_sync"] is True
+    # gloo's host-side collectives cannot be captured: one graph per backward segment (4 blocks) + one for Adam
+    assert d["dp"]["graph_launches_per_step"] == 5 and d["dp"]["graph_mode"].startswith("segments"), d["dp"]
+
+
+_ONE_GRAPH_SCRIPT = r"""
+import json, os, sys
+import torch, torch.distributed as dist
+sys.path[:0] = [os.environ["MFP_ROOT"], os.path.join(os.environ["MFP_ROOT"], "flex-dm_amd")]
+from mfp import dp
+from mfp.data.spec import make_input_columns, synthetic_batch
+from mfp.models.mfp import MFP
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["MFP_PORT"], rank=0, world_size=1)
+ic = make_input_columns("crello")
+batch = synthetic_batch(ic, 4, 128, seed=3, ragged=True, device="cuda:0")
+out = {}
+for mode in ("plain", "segments", "one"):
+    os.environ["MFP_DP_FORCE"] = "0" if mode == "plain" else "1"
+    os.environ["MFP_DP_GRAPH"] = "one" if mode == "one" else "segments"
+    m = MFP(ic, num_blocks=4, latent_dim=256, dropout=0.1, l2=1e-2, masking_method="random", dtype="bf16", device="cuda:0", seed=0)
+    m.compile(learning_rate=1e-3)
+    m.capture_train_step(batch, warmup=1)
+    for _ in range(3):
+        m.train_step(batch)
+    torch.cuda.synchronize()
+    out[mode] = (m.model.store.w.clone(), m.dp_graph_launches_per_step, float(m.last_sums[:, 0].sum()))
+    del m
+res = {k: v[1] for k, v in out.items()}
+res["one_equals_segments"] = bool(torch.equal(out["one"][0], out["segments"][0]))
+res["one_equals_plain"] = bool(torch.equal(out["one"][0], out["plain"][0]))
+res["finite"] = bool(torch.isfinite(out["one"][0]).all())
+res["loss"] = {k: v[2] for k, v in out.items()}
+print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+"""
+
+
+def test_dp_step_as_one_graph_with_captured_allreduces(tmp_path):
+    """the N > 1 step as ONE hipGraph with the bucket all-reduces captured inside it (mfp.dp.graph_mode), on the
+    one GPU a test box has: a ONE-rank RCCL process group under MFP_DP_FORCE=1 (two ranks cannot share a GPU under RCCL).
+    The captured form must leave bit for bit the parameters of the per-segment graphs with eager all-reduces between them
+    (4 graph launches per step + Adam) and of the plain single-GPU step (a one-rank sum is the identity), in 1 launch."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MFP_ROOT=root, MFP_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MFP_DIST_BACKEND", None)
+    script = tmp_path / "one_graph.py"
+    script.write_text(_ONE_GRAPH_SCRIPT)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["plain"] == 1 and res["segments"] == 5 and res["one"] == 1, res      # graph launches per step (L = 4: 4 segments + Adam)
+    assert res["finite"] and res["one_equals_segments"] and res["one_equals_plain"], res
 
 
 @pytest.mark.parametrize("B,S,D,res16", [(8, 32, 128, True), (4, 128, 256, True), (4, 128, 256, False)])
