@@ -576,12 +576,20 @@ __global__ __launch_bounds__(512) void os512_kernel(Os512Params p) {
     __syncthreads();
     if (tid == 0) {
       __hip_atomic_store(&p.flags[tile * 2 + half], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(&p.flags[tile * 2 + (half ^ 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+      // (bounded: HIP promises no forward progress between workgroups of a plain launch -- the partner sits 8 workgroups away in
+      //  dispatch order, so it is resident whenever 16 slots are, but a masked-off / preempted partner must end in a loud
+      //  launch failure, not in a hung GPU: ~0.5 s of polling, then trap)
+      unsigned int spins = 0;
+      while (__hip_atomic_load(&p.flags[tile * 2 + (half ^ 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) __builtin_trap();
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(&p.flags[tile * 2 + (half ^ 1)], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
     }
     __syncthreads();
-    const u32x2 ov = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ex, lane < 16 ? exp_ : OOB, 0, 0));
+    // (sc1: the partner may sit on another XCD when the grid is not a multiple of 16 -- a coherent load beside the acquire fence)
+    const u32x2 ov = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ex, lane < 16 ? exp_ : OOB, 0, 16 /* sc1 */));
     const float t1 = (my1 + __uint_as_float(ov[0])) * (1.0f / O5_N), t2 = (my2 + __uint_as_float(ov[1])) * (1.0f / O5_N);
     // ---- pass 2: dx = dres + rstd (gy - mean(gy) - xhat mean(gy xhat)), its dropout-masked copy
     const unsigned long long rng_off = p.offset + (p.step_ptr ? (unsigned long long)(*p.step_ptr) * MFP_RNG_STEP_STRIDE : 0ull);

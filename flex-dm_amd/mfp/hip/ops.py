@@ -554,9 +554,11 @@ def dense_n512_lnb(A, W, xhat, gamma, rstd, dres, dgamma, dbeta, drop=None, jobs
     T, K = A.shape
     assert A.dtype == torch.bfloat16 and A.is_contiguous() and T % 128 == 0 and xhat.dtype == torch.bfloat16 and dres.dtype == torch.bfloat16
     dev = A.device
-    key = (dev.index, T)
+    # (per stream: two streams stepping models of the same token count must not share the flags / row sums)
+    key = (dev.index, T, int(torch.cuda.current_stream(dev).cuda_stream))
     if key not in _LNB_WS:
-        assert not torch.cuda.is_current_stream_capturing(), "dense_n512_lnb: first call inside a graph capture"
+        assert not torch.cuda.is_current_stream_capturing(), \
+            "dense_n512_lnb: first call inside a graph capture (run one warm-up step on the capture stream first: capture_train_step(warmup >= 1))"
         _LNB_WS[key] = (torch.empty((T // 128, 2, 128, 2), dtype=torch.float32, device=dev),
                         torch.zeros((T // 128, 2), dtype=torch.int32, device=dev))
     exch, flags = _LNB_WS[key]

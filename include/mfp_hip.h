@@ -272,7 +272,8 @@ int mfp_dense_n512_lnb(const void* A, const void* W, const void* xhat, const flo
 /* Inference form of mfp_block_fwd (what MFP.__call__(training=False), iterative_decode and eval.py run: reference
  * models/mfp.py:141-207, eval.py:35-118): the same single launch with nothing saved for a backward pass -- y1, qkv, a, lse,
  * y2 and h never reach memory (2 KB instead of 7.2 KB written per element); dropout off.  x1 f32 [T,256] is scratch (the
- * MLP half re-reads it as its residual), stats f32 [4 T] scratch for the LayerNorm statistics.  S = 128, d_model 256. */
+ * MLP half re-reads it as its residual), stats f32 [4 T] scratch for the LayerNorm statistics.  S = 128, or S = 64 with an
+ * even number of documents (two per 128-row tile); d_model 256. */
 int mfp_block_infer(const float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv,
                     const void* Wo, const float* bo, const int32_t* nvalid, const float* gamma2, const float* beta2,
                     const void* W1, const float* b1, const void* W2, const float* b2, float* x1, float* stats,

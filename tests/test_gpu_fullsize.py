@@ -254,3 +254,53 @@ def test_fused_masking_at_full_size():
     col = model.model.layout.idx_cols.index(("left", 0))
     keep = (seq_mask & ~masks["left"].bool()).reshape(-1)
     assert torch.equal(idx_all[:, col][keep].long(), batch["left"].reshape(-1)[keep].long())
+
+
+def test_c5_per_gpu_shape_with_reserved_cus_equals_its_halves_and_padding_is_inert():
+    """BASELINE config c5 at its full per-GPU size (64 documents x 256 positions, d_model 512, 8 blocks; bf16) with 8 CUs
+    reserved for RCCL (MFP_DP_RESERVE_CUS=8, what the driver's 8-GPU run may set): the d_model-512 kernels of
+    csrc/block_d512.hip, whose LayerNorm-backward epilogue exchanges row sums between PAIRED workgroups through global memory
+    (mfp_dense_n512_lnb: 128 row tiles = 256 workgroups, 16 launches per step).  Size-independent properties: the batch
+    equals its two halves (logits bit for bit, denominators exactly, losses / gradients by linearity of the batch mean), and
+    what sits in the padded positions changes nothing (VERDICT r05 #7)."""
+    from mfp.data.spec import make_input_columns
+    from mfp.hip import ops
+    from mfp.models.model import Model
+    global B, S
+    oldB, oldS = B, S
+    ic = make_input_columns("crello")
+    ops.set_reserved_cus(8)
+    try:
+        B, S = 64, 256
+        model = Model(ic, num_blocks=8, latent_dim=512, dropout=0.0, l2=1e-2, dtype="bf16", device=DEV, seed=5)
+        batch, modified, masks, seq_mask = _masked_batch(ic, seed=6, B=B)
+        sums, logits, g = _loss_grads(model, ic, batch, modified, masks)
+        assert torch.isfinite(logits).all() and torch.isfinite(g).all()
+        h = B // 2
+        parts = [_loss_grads(model, ic, _take(batch, sl), _take(modified, sl), _take(masks, sl)) for sl in (slice(0, h), slice(h, B))]
+        assert torch.equal(logits, torch.cat([p[1] for p in parts]))
+        assert torch.equal(sums[:, 2], parts[0][0][:, 2] + parts[1][0][:, 2])
+        assert torch.allclose(sums[:, 0], 0.5 * (parts[0][0][:, 0] + parts[1][0][:, 0]), rtol=2e-5, atol=1e-5)
+        want = 0.5 * (parts[0][2] + parts[1][2])
+        err, scale = (g - want).abs().max().item(), want.abs().max().item()
+        assert err <= 2e-2 * scale, (err, scale)
+        # padding: other values in the positions >= length (sequence columns only) -- same logits at the valid positions, same sums
+        gen = torch.Generator().manual_seed(9)
+        pad = ~seq_mask
+        noisy = dict(modified)
+        for k, c in ic.items():
+            if c.get("demo_only") or not c["is_sequence"]:
+                continue
+            v = modified[k].clone()
+            if c["type"] == "categorical":
+                v[pad] = torch.randint(0, c["input_dim"], v[pad].shape, generator=gen).to(v.dtype)
+            else:
+                v[pad] = torch.randn(v[pad].shape, generator=gen)
+            noisy[k] = v
+        sums2, logits2, g2 = _loss_grads(model, ic, batch, noisy, masks)
+        valid = seq_mask.reshape(-1).to(DEV)
+        assert torch.equal(logits[valid], logits2[valid])
+        assert torch.equal(sums[:, 2], sums2[:, 2]) and torch.allclose(sums[:, 0], sums2[:, 0], rtol=1e-6, atol=1e-6)
+    finally:
+        ops.set_reserved_cus(0)
+        B, S = oldB, oldS

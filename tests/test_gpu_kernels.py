@@ -1665,8 +1665,22 @@ def test_dense_n512(T, K):
     assert_close(out, A.double() @ W.double().t(), 2e-2, 8e-3, "out vs double")
 
 
-@pytest.mark.parametrize("T,K,p", [(1024, 1024, 0.1), (384, 1536, 0.0), (16384, 1536, 0.1), (2048, 1024, None)])
-def test_dense_n512_lnb(T, K, p):
+@pytest.mark.parametrize("reserve", [0, 8])
+@pytest.mark.parametrize("T,K,p", [(1024, 1024, 0.1), (384, 1536, 0.0), (16384, 1536, 0.1), (2048, 1024, None),
+                                   (128, 1024, 0.1), (896, 1536, 0.1), (1152, 1024, 0.0)])
+def test_dense_n512_lnb(T, K, p, reserve):
+    """(round 6, ADVICE r05: T / 128 = 1, 7 and 9 row tiles -- grids that are not multiples of 16, where the two workgroups of a
+    row tile are neighbours in dispatch order and sit on different XCDs -- and every shape again with 8 CUs reserved for
+    RCCL (MFP_DP_RESERVE_CUS): the flag exchange must not depend on the partner's placement.)"""
+    ops = _ops()
+    ops.set_reserved_cus(reserve)
+    try:
+        _dense_n512_lnb_body(T, K, p)
+    finally:
+        ops.set_reserved_cus(0)
+
+
+def _dense_n512_lnb_body(T, K, p):
     """mfp_dense_n512_lnb: dy = A W^T (the gradient of a LayerNorm output at d_model 512: dy2 = dh W1, dy1 = dqkv Wqkv) with the
     x-hat LayerNorm backward on the f32 result in the same launch -- the two workgroups of a row tile exchange their halves of the
     row sums through global memory.  Against a double restatement from the double product (dy is never rounded to bf16 here), and
@@ -1693,7 +1707,8 @@ def test_dense_n512_lnb(T, K, p):
         dx, dd = r if p is not None else (r, None)
         outs.append((dx.clone(), None if dd is None else dd.clone(), dg.clone(), db.clone(), cs.clone()))
     torch.cuda.synchronize()
-    _, flags = ops._LNB_WS[(torch.device(DEV).index if torch.device(DEV).index is not None else torch.cuda.current_device(), T)]
+    _, flags = ops._LNB_WS[(torch.device(DEV).index if torch.device(DEV).index is not None else torch.cuda.current_device(), T,
+                            int(torch.cuda.current_stream().cuda_stream))]
     assert int(flags.abs().sum().item()) == 0
     for o in outs[1:]:
         for a, b in zip(o, outs[0]):
