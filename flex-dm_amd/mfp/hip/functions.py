@@ -82,6 +82,16 @@ HEADS_FUSED = os.environ.get("MFP_HEADS_FUSED", "1") == "1"
 ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "")
 
 
+# the grouped weight-gradient launches of two consecutive blocks as ONE launch (single-rank step at d_model 256 with the deferred
+# reduction; the data-parallel step keeps one launch per block: its buckets end at block boundaries); "0" / "1" = A/B switch
+WGRAD_PAIR = os.environ.get("MFP_WGRAD_PAIR", "1") == "1"
+
+
+def _wgrad_pair_on(ctx, D) -> bool:
+    from mfp import dp
+    return WGRAD_PAIR and D == 256 and ctx.wgrad_pending is not None and not dp.active()
+
+
 def _attn_block_bwd_on(ctx) -> bool:
     if ATTN_BLOCK_BWD != "":
         return ATTN_BLOCK_BWD == "1"
@@ -251,6 +261,10 @@ class StepCtx:
         if self.ln_jobs:
             ops.reduce_partials_batch(self.ln_jobs)
             self.ln_jobs.clear()      # (in place: the context-token view of the step shares the list)
+        held = self.tail.get("wgrad_held")
+        if held is not None:      # (a block whose weight-gradient launch waited for a partner that did not come: a cut backward pass)
+            self.tail["wgrad_held"] = None
+            ops.wgrad_group(held[0], held[1], defer=self.wgrad_pending)
         if self.wgrad_pending:
             ops.wgrad_reduce(self.wgrad_pending)      # (clears the list in place)
 
@@ -699,14 +713,25 @@ class BlockFn(torch.autograd.Function):
         def wgrads_block():   # the four weight gradients (+ two bias gradients) of the block: one launch
             if ctx.wgrad_pending is not None and len(ctx.wgrad_pending) >= ops.WGRAD_MAX_PENDING - 2:
                 ops.wgrad_reduce(ctx.wgrad_pending)      # (more than 6 blocks: reduce what has accumulated)
-            ops.wgrad_group([
+            jobs = [
                 dict(A=dqkv, B=y1, out=st.span(st.g, p + "attn/dense_query/kernel", 3 * D * D, D), M=3 * D, N=D,
                      colsum=st.span(st.g, p + "attn/dense_query/bias", 3 * D), naffine=na1),
                 dict(A=dh, B=y2, out=st.grad(p + "mlp/dense_0/kernel"), M=2 * D, N=D,
                      colsum=st.grad(p + "mlp/dense_0/bias"), naffine=na2),
                 dict(A=d_o2, B=h, out=st.grad(p + "mlp/dense_1/kernel"), M=D, N=2 * D,
                      colsum=st.grad(p + "mlp/dense_1/bias") if i in ctx.tail["bias_wgg"] else None),
-                dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)], T, defer=ctx.wgrad_pending)
+                dict(A=d_o1, B=a, out=st.grad(p + "attn/combine_heads/kernel"), M=D, N=D)]
+            if _wgrad_pair_on(ctx, D):
+                # TWO blocks per grouped launch (round 6): 64 tiles instead of 32 fill the chip with half the k-slices, i.e. half
+                # the split-K slab bytes written here and read back by the end-of-backward reduction, and two launches fewer
+                # per step.  The operands of the held block stay alive through the job records.
+                held = ctx.tail.get("wgrad_held")
+                if held is None and i > 0:
+                    ctx.tail["wgrad_held"] = (jobs, T)
+                    return
+                if held is not None:
+                    jobs, ctx.tail["wgrad_held"] = held[0] + jobs, None
+            ops.wgrad_group(jobs, T, defer=ctx.wgrad_pending)
         if grouped:
             ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1, hold=True)
         else:

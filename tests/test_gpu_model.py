@@ -392,12 +392,15 @@ def test_split_backward_equals_single_backward(B, S, D, res16):
     model.compile(learning_rate=1e-3)
     g = model.model.store.g
     layout = model.model.layout
-    old16 = functions.RES_GRAD_BF16
+    old16, oldpair = functions.RES_GRAD_BF16, functions.WGRAD_PAIR
     functions.RES_GRAD_BF16 = res16
+    # (the data-parallel step this test plays through on one rank keeps one weight-gradient launch per block -- dp.active() --
+    #  so that a bucket is final when its segment ends; the single-rank step pairs the launches of two blocks)
+    functions.WGRAD_PAIR = False
     try:
         _split_backward_body(model, batch, g, layout)
     finally:
-        functions.RES_GRAD_BF16 = old16
+        functions.RES_GRAD_BF16, functions.WGRAD_PAIR = old16, oldpair
 
 
 def _split_backward_body(model, batch, g, layout):
