@@ -607,8 +607,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(MlpBwdParams p) {
   const unsigned int hoff = (unsigned int)((row0 + wl * (HP * 4) + (lane >> 4)) * 1024 + (((lane & 15) ^ (lane >> 4)) << 4));
   auto hload = [&](int q) {
     if (wv < 4) return;
+#ifndef MLPB_ABL_HP      // (timing experiment, tools/abl: how much of the launch is the saved h's read -- 1 = an eighth of its pieces; results wrong)
+#define MLPB_ABL_HP HP
+#endif
 #pragma unroll
-    for (int i = 0; i < HP; ++i)
+    for (int i = 0; i < MLPB_ABL_HP; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (lds_u8*)(Hm + wl * (HP * 1024) + i * 1024), 16, hoff ^ ((i & 3) << 6), q * 256 + i * 4096, 0, 0);
   };
   MLP_STAMP(0);

@@ -795,7 +795,10 @@ extern "C" int mfp_wgrad_group_partial(const mfp_wgrad_job* jobs, int32_t njobs,
 extern "C" int mfp_wgrad_reduce(const mfp_wgrad_pending* groups, int32_t ngroups, mfp_stream_t stream) {
   MFP_CHECK_ARG(groups != nullptr && ngroups >= 1 && ngroups <= MFP_MAX_WGRAD_PENDING);
   WgrParams p;
-  int unit0 = 0;
+  int unit0 = 0, job0 = 0;
+  for (int gi = 0; gi < ngroups; ++gi) job0 += groups[gi].njobs > 0 ? groups[gi].njobs : 0;
+  MFP_CHECK_ARG(job0 <= WGR_MAX_JOBS);      // (all groups' jobs of one launch; the caller reduces earlier otherwise)
+  job0 = 0;
   for (int gi = 0; gi < ngroups; ++gi) {
     const mfp_wgrad_pending& s = groups[gi];
     MFP_CHECK_ARG(s.jobs != nullptr && s.njobs >= 1 && s.njobs <= MFP_MAX_WGRAD_JOBS && (s.splitk == 1 || s.splitk == 2 || s.splitk == 4 || (s.splitk >= 8 && s.splitk % 8 == 0)));
@@ -805,20 +808,21 @@ extern "C" int mfp_wgrad_reduce(const mfp_wgrad_pending* groups, int32_t ngroups
     for (int i = 0; i < s.njobs; ++i) {
       const mfp_wgrad_job& j = s.jobs[i];
       MFP_CHECK_ARG(j.C && j.M > 0 && j.N > 0 && j.N % 8 == 0 && j.ldc % 4 == 0 && j.ldc >= j.N && ((uintptr_t)j.C % 16) == 0);
-      WgrJob& d = G.job[i];
+      WgrJob& d = p.job[job0 + i];
       MFP_CHECK_ARG(j.n_affine == nullptr || (j.colsum != nullptr && j.N % 4 == 0 && ((uintptr_t)j.n_affine % 16) == 0));
       d.C = j.C; d.colsum = j.colsum; d.nfix = j.n_affine; d.M = j.M; d.N = j.N; d.ldc = j.ldc;
       d.tiles_n = (j.N + 127) / 128; d.tile0 = tile0; d.pad_ = 0;
       tile0 += ((j.M + 127) / 128) * d.tiles_n;
     }
-    for (int i = s.njobs; i < WGG_MAX_JOBS; ++i) { G.job[i] = G.job[0]; G.job[i].tile0 = 0x7FFFFFFF; }
-    G.njobs = s.njobs; G.ntiles = tile0; G.splitk = s.splitk; G.unit0 = unit0;
+    G.njobs = s.njobs; G.ntiles = tile0; G.splitk = s.splitk; G.unit0 = unit0; G.job0 = job0; G.pad_ = 0;
+    job0 += s.njobs;
     G.zstride = (long long)tile0 * 128 * 128 + WGG_ZPAD;
     G.ws = reinterpret_cast<const float*>(s.workspace);
     G.ws_col = G.ws + (size_t)s.splitk * G.zstride;
     unit0 += tile0 * 8;
   }
   for (int gi = ngroups; gi < WGR_MAX_GROUPS; ++gi) { p.g[gi] = p.g[0]; p.g[gi].unit0 = 0x7FFFFFFF; }
+  for (int i = job0; i < WGR_MAX_JOBS; ++i) p.job[i] = p.job[0];
   p.ngroups = ngroups; p.nunits = unit0;
   hipLaunchKernelGGL(wgg_reduce_kernel, dim3(unit0), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   MFP_CHECK_LAUNCH();

@@ -29,7 +29,7 @@
 // back, neighbouring XCDs on neighbouring 32-64 KB blocks.
 #pragma once
 
-constexpr int WGG_MAX_JOBS = 8;
+constexpr int WGG_MAX_JOBS = 16;      // (round 6: 16 -- the four products of up to four blocks in one launch)
 #ifndef MFP_WGG_XD
 #define MFP_WGG_XD 4
 #endif
@@ -544,13 +544,14 @@ inline int launch_wgt(const WggParams& p, hipStream_t st) {
 // ------------------------------------------------------------------ deferred split-K reduction, all groups of a step
 constexpr int WGR_MAX_GROUPS = 8;
 struct WgrJob { float* C; float* colsum; const float* nfix; int M, N, ldc, tiles_n, tile0, pad_; };
+constexpr int WGR_MAX_JOBS = 56;      // jobs of all groups of one reduction launch (kernel arguments: 4 KB at most)
 struct WgrGroup {
   const float* ws; const float* ws_col;
   long long zstride;
-  int splitk, ntiles, unit0, njobs;
-  WgrJob job[WGG_MAX_JOBS];
+  int splitk, ntiles, unit0, njobs, job0, pad_;      // job0: the group's first entry of WgrParams::job
 };
-struct WgrParams { WgrGroup g[WGR_MAX_GROUPS]; int ngroups, nunits; };
+struct WgrParams { WgrGroup g[WGR_MAX_GROUPS]; WgrJob job[WGR_MAX_JOBS]; int ngroups, nunits; };
+static_assert(sizeof(WgrParams) <= 4000, "kernel arguments");
 
 // One workgroup per (tile, 16-row slice): 8 KB of the gradient = the sum of `splitk` slab pieces in FIXED order
 // kz = 0 .. splitk-1 (bit-identical to the in-launch last-arriver sum), all of a thread's loads in flight.
@@ -561,8 +562,8 @@ __global__ __launch_bounds__(256) void wgg_reduce_kernel(WgrParams p) {
   const WgrGroup& G = p.g[gi];
   const int local = unit - G.unit0, tile = local >> 3, slice = local & 7;
   int ji = 0;
-  for (int q = 1; q < G.njobs; ++q) ji = tile >= G.job[q].tile0 ? q : ji;
-  const WgrJob& jb = G.job[ji];
+  for (int q = 1; q < G.njobs; ++q) ji = tile >= p.job[G.job0 + q].tile0 ? q : ji;
+  const WgrJob& jb = p.job[G.job0 + ji];
   const int bid = tile - jb.tile0, tm = bid / jb.tiles_n, tn = bid % jb.tiles_n;
   const int m0 = tm * 128, n0 = tn * 128;
   // this thread's two float4 of the tile: slab offsets (floats) and the (row, column) they belong to

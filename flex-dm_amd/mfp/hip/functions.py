@@ -84,12 +84,14 @@ ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "")
 
 # the grouped weight-gradient launches of two consecutive blocks as ONE launch (single-rank step at d_model 256 with the deferred
 # reduction; the data-parallel step keeps one launch per block: its buckets end at block boundaries); "0" / "1" = A/B switch
-WGRAD_PAIR = os.environ.get("MFP_WGRAD_PAIR", "1") == "1"
+# MFP_WGRAD_PAIR = blocks per launch: 4 (default: 16 products, 128 tiles = 64 macro tiles x 4 k-slices fill the chip with a quarter
+# of the split-K slab bytes of one launch per block), 2 (the first form of round 6), 1 / 0 = one launch per block
+WGRAD_PAIR = int(os.environ.get("MFP_WGRAD_PAIR", "4") or 0)
 
 
 def _wgrad_pair_on(ctx, D) -> bool:
     from mfp import dp
-    return WGRAD_PAIR and D == 256 and ctx.wgrad_pending is not None and not dp.active()
+    return WGRAD_PAIR > 1 and D == 256 and ctx.wgrad_pending is not None and not dp.active()
 
 
 def _attn_block_bwd_on(ctx) -> bool:
@@ -726,11 +728,12 @@ class BlockFn(torch.autograd.Function):
                 # the split-K slab bytes written here and read back by the end-of-backward reduction, and two launches fewer
                 # per step.  The operands of the held block stay alive through the job records.
                 held = ctx.tail.get("wgrad_held")
-                if held is None and i > 0:
+                if held is not None:
+                    jobs = held[0] + jobs
+                if i > 0 and len(jobs) < 4 * min(WGRAD_PAIR, 4):      # (4 products per block; 16 per launch at most)
                     ctx.tail["wgrad_held"] = (jobs, T)
                     return
-                if held is not None:
-                    jobs, ctx.tail["wgrad_held"] = held[0] + jobs, None
+                ctx.tail["wgrad_held"] = None
             ops.wgrad_group(jobs, T, defer=ctx.wgrad_pending)
         if grouped:
             ctx.on_side(wgrads_block, d_o2, h, dh, y2, d_o1, a, dqkv, y1, hold=True)

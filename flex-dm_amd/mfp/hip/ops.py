@@ -289,6 +289,7 @@ def _deferred_workspace(nbytes: int, device, slot: int) -> torch.Tensor:
 
 
 WGRAD_MAX_PENDING = 8
+WGRAD_MAX_PENDING_JOBS = 56      # csrc/gemm_wgg.h: WGR_MAX_JOBS
 
 
 def _wgrad_jobs_array(jobs: Sequence[dict]):
@@ -345,6 +346,8 @@ def wgrad_group(jobs: Sequence[dict], K: int, splitk: Optional[int] = None, defe
     assert lib.mfp_wgrad_group_tiles(arr, n) <= WGRAD_MAX_TILES
     need = lib.mfp_wgrad_group_workspace_bytes(arr, n, splitk)
     if defer is not None:
+        if sum(r["n"] for r in defer) + n > WGRAD_MAX_PENDING_JOBS:      # (mfp_wgrad_reduce takes 56 jobs per launch)
+            wgrad_reduce(defer)
         assert len(defer) < WGRAD_MAX_PENDING, "flush the pending weight-gradient groups first (wgrad_reduce)"
         ws = _deferred_workspace(need, dev, len(defer))
         with _timed("gemm_wgg_kernel", flops, nbytes):

@@ -118,7 +118,7 @@ const char* mfp_gemm_kernel_family(const mfp_gemm_args* args /*host*/);
  *   tickets: uint32 [>= mfp_wgrad_group_tiles()] owned by the caller, ALL ZERO before the first
  *   launch that uses them; the launch leaves them zero.  Launches that may run concurrently (other
  *   streams) need their own workspace and tickets. */
-#define MFP_MAX_WGRAD_JOBS 8
+#define MFP_MAX_WGRAD_JOBS 16
 typedef struct mfp_wgrad_job {
   const void* A;
   const void* B;

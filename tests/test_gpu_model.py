@@ -321,6 +321,8 @@ sys.path[:0] = [os.environ["MFP_ROOT"], os.path.join(os.environ["MFP_ROOT"], "fl
 from mfp import dp
 from mfp.data.spec import make_input_columns, synthetic_batch
 from mfp.models.mfp import MFP
+from mfp.hip import functions
+functions.WGRAD_PAIR = 1      # (the plain step with one weight-gradient launch per block, as the data-parallel forms: same summation order)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["MFP_PORT"], rank=0, world_size=1)
 ic = make_input_columns("crello")
@@ -396,7 +398,7 @@ def test_split_backward_equals_single_backward(B, S, D, res16):
     functions.RES_GRAD_BF16 = res16
     # (the data-parallel step this test plays through on one rank keeps one weight-gradient launch per block -- dp.active() --
     #  so that a bucket is final when its segment ends; the single-rank step pairs the launches of two blocks)
-    functions.WGRAD_PAIR = False
+    functions.WGRAD_PAIR = 0
     try:
         _split_backward_body(model, batch, g, layout)
     finally:
