@@ -91,7 +91,7 @@ WGRAD_PAIR = int(os.environ.get("MFP_WGRAD_PAIR", "4") or 0)
 
 def _wgrad_pair_on(ctx, D) -> bool:
     from mfp import dp
-    return WGRAD_PAIR > 1 and D == 256 and ctx.wgrad_pending is not None and not dp.active()
+    return WGRAD_PAIR > 1 and D in (256, 512) and ctx.wgrad_pending is not None and not dp.active()
 
 
 def _attn_block_bwd_on(ctx) -> bool:
