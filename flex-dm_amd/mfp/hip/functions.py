@@ -82,16 +82,17 @@ HEADS_FUSED = os.environ.get("MFP_HEADS_FUSED", "1") == "1"
 ATTN_BLOCK_BWD = os.environ.get("MFP_ATTN_BLOCK_BWD", "")
 
 
-# the grouped weight-gradient launches of two consecutive blocks as ONE launch (single-rank step at d_model 256 with the deferred
-# reduction; the data-parallel step keeps one launch per block: its buckets end at block boundaries); "0" / "1" = A/B switch
+# the grouped weight-gradient launches of consecutive blocks as ONE launch (the step with the deferred reduction)
 # MFP_WGRAD_PAIR = blocks per launch: 4 (default: 16 products, 128 tiles = 64 macro tiles x 4 k-slices fill the chip with a quarter
 # of the split-K slab bytes of one launch per block), 2 (the first form of round 6), 1 / 0 = one launch per block
 WGRAD_PAIR = int(os.environ.get("MFP_WGRAD_PAIR", "4") or 0)
 
 
 def _wgrad_pair_on(ctx, D) -> bool:
-    from mfp import dp
-    return WGRAD_PAIR > 1 and D in (256, 512) and ctx.wgrad_pending is not None and not dp.active()
+    # (the data-parallel step flushes what is held at the end of every backward segment -- StepCtx.flush_ln_jobs, in front of the
+    #  bucket's all-reduce -- so a launch never straddles a bucket boundary: one launch per block under MFP_DP_BUCKETS=blocks,
+    #  the blocks of a half under "halves")
+    return WGRAD_PAIR > 1 and D in (256, 512) and ctx.wgrad_pending is not None
 
 
 def _attn_block_bwd_on(ctx) -> bool:

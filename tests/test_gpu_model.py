@@ -394,19 +394,23 @@ def test_split_backward_equals_single_backward(B, S, D, res16):
     model.compile(learning_rate=1e-3)
     g = model.model.store.g
     layout = model.model.layout
-    old16, oldpair = functions.RES_GRAD_BF16, functions.WGRAD_PAIR
+    old16 = functions.RES_GRAD_BF16
     functions.RES_GRAD_BF16 = res16
-    # (the data-parallel step this test plays through on one rank keeps one weight-gradient launch per block -- dp.active() --
-    #  so that a bucket is final when its segment ends; the single-rank step pairs the launches of two blocks)
-    functions.WGRAD_PAIR = 0
+    # (round 6: the weight-gradient launches of several blocks are grouped; what is held is launched by flush_ln_jobs at the end
+    #  of every segment, so a bucket is still final when its segment ends -- under "halves" two blocks share a launch)
+    oldpair = functions.WGRAD_PAIR
     try:
-        _split_backward_body(model, batch, g, layout)
+        functions.WGRAD_PAIR = 1      # one weight-gradient launch per block on both sides: the same summation order, bit for bit
+        _split_backward_body(model, batch, g, layout, exact=True)
+        functions.WGRAD_PAIR = 4      # grouped launches (the default): other k-slices per launch, equal to rounding
+        _split_backward_body(model, batch, g, layout, exact=False)
     finally:
         functions.RES_GRAD_BF16, functions.WGRAD_PAIR = old16, oldpair
 
 
-def _split_backward_body(model, batch, g, layout):
+def _split_backward_body(model, batch, g, layout, exact=True):
     from mfp import dp
+    same = torch.equal if exact else (lambda a, b: bool(torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max()))))
     g.fill_(float("nan"))
     loss, sums, ctx = model._forward(batch)     # the step counter does not move: same masks / dropout
     loss.backward(model._unit_grad(loss))
@@ -429,7 +433,7 @@ def _split_backward_body(model, batch, g, layout):
             torch.cuda.synchronize()
             # this segment's bucket is complete; the next one is still (almost) untouched -- only the bias gradient
             # that the fused LayerNorm backward of the cut block emits for the block below has landed
-            assert torch.equal(g[slices[k]], ref[slices[k]]), (mode, k)
+            assert same(g[slices[k]], ref[slices[k]]), (mode, k)
             assert torch.isnan(g[slices[k + 1]]).float().mean() > 0.98, (mode, k)
             if k + 1 < len(cuts):
                 x_k = ctx.cuts[cuts[k + 1]]
@@ -439,7 +443,7 @@ def _split_backward_body(model, batch, g, layout):
         model._join_sides()
         torch.cuda.synchronize()
         assert torch.allclose(sums, ref_sums, rtol=1e-5, atol=1e-5)   # loss sums: float atomics across workgroups
-        assert torch.equal(g, ref), mode
+        assert same(g, ref), mode
 
 
 def test_shuffled_set_position_token_parity_and_training():
