@@ -311,6 +311,9 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
   __builtin_amdgcn_s_barrier();       // chunks 0, 1 are in LDS (first memory operations of the kernel); the LN image has been read
   AB_TR(2);
 
+#ifdef AB_PRIO      // (experiment, tools/abl: static priority for the younger half of the workgroup -- MI355X_MICROARCH.md "two waves per SIMD" item 4)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(AB_PRIO);
+#endif
   int xs[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) xs[ks] = ((ks * 4 + g) ^ li) << 4;
