@@ -306,6 +306,11 @@ def _encoder_fwd(ctx: StepCtx, idx_all, codes, xs):
     return h
 
 
+# k-slices of the encoder / heads weight-gradient groups (experiment switches; unset = the library's cost model)
+_SPLITK_ENC = int(os.environ.get("MFP_WGRAD_SPLITK_ENC", "0") or 0) or None
+_SPLITK_HEADS = int(os.environ.get("MFP_WGRAD_SPLITK_HEADS", "0") or 0) or None
+
+
 def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
     st, L = ctx.store, ctx.store.layout
     T, D = ctx.T, L.D
@@ -328,7 +333,7 @@ def _encoder_bwd(ctx: StepCtx, idx_all, codes, xs, dh):
                          rowskip=codes[j], colsum=st.grad("encoder/input_%s/bias" % k))
                     for j, k in enumerate(L.num_keys)]
             jobs.append(dict(A=ctx.onehot, B=dh_c, out=st.tables_padded(st.g), M=L.table_rows_pad, N=D))
-            ops.wgrad_group(jobs, T, defer=ctx.wgrad_pending)
+            ops.wgrad_group(jobs, T, defer=ctx.wgrad_pending, splitk=_SPLITK_ENC)
             ctx.onehot = None
             ctx.join_side()
             ctx.flush_ln_jobs()      # the deferred split-K reductions of the whole backward pass: one launch
@@ -819,7 +824,7 @@ def _heads_wgrad(ctx: StepCtx, dl_c: torch.Tensor, h_c: torch.Tensor) -> None:
         if WGRAD_GROUP and dl_c.dtype == torch.bfloat16:
             ops.wgrad_group([dict(A=dl_c, B=h_c, out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
                                   M=U, N=D, colsum=st.span(st.g, "decoder/decoder_%s/bias" % first, U))], T,
-                            defer=ctx.wgrad_pending)
+                            defer=ctx.wgrad_pending, splitk=_SPLITK_HEADS)
             return
         ops.gemm(dl_c, h_c, U, D, T, a_kmajor=False, b_kmajor=False,
                  out=st.span(st.g, "decoder/decoder_%s/kernel" % first, U * D, D),
