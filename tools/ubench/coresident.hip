@@ -23,7 +23,7 @@ __device__ __forceinline__ unsigned int pk(float a, float b) { const f2 v = {a, 
 // ROWS rows per workgroup, CC columns per chunk, NW waves; wave (rp, nh): RT row tiles x NT column tiles of 16
 template <int ROWS, int CC, int NW>
 struct Cfg {
-  static constexpr int NRP = (ROWS == 128 || NW == 4) ? ROWS / 32 : ROWS / 16;      // row groups of waves
+  static constexpr int NRP = (ROWS == 128 || NW == 4) ? ROWS / 32 : ROWS / 16;      // row groups of waves (NW 16: 4 x 4 waves, one column tile each)
   static constexpr int RT = ROWS / (16 * NRP);                                       // row tiles per wave
   static constexpr int NNH = NW / NRP;                                               // column groups of waves
   static constexpr int NT = CC / (16 * NNH);                                         // column tiles per wave
@@ -158,6 +158,7 @@ int main() {
     run<64, 32, 4, 2>(W, nwbytes, out, obytes, 512, "B  TWO 4-wave workgroups per CU, 64 rows each, 32-column chunks, 60 KB LDS each");
     run<64, 32, 4, 2>(W, nwbytes, out, obytes, 256, "C  the same products by ONE such 4-wave workgroup per CU (no neighbour)");
     run<64, 64, 8, 1>(W, nwbytes, out, obytes, 256, "D  one 8-wave workgroup per CU, 64 rows, one row tile per wave (half tiles of r05), 64-column chunks");
+    run<128, 64, 16, 1>(W, nwbytes, out, obytes, 256, "F  one SIXTEEN-wave workgroup per CU, 128 rows, 64-column chunks (4 waves per SIMD, <= 128 registers)");
     run<64, 64, 4, 2>(W, nwbytes, out, obytes, 512, "E  TWO 4-wave workgroups per CU, 64 rows, 64-column chunks (108 KB LDS: does not co-reside)");
   }
   return 0;
