@@ -26,7 +26,18 @@ from mfp.models import masking  # noqa: E402
 from mfp.models.architecture.mask import get_seq_mask  # noqa: E402
 
 CONFIGS = [dict(name="crello_d8_l2", dataset="crello", B=3, S=5, D=8, L=2, seed=11),
-           dict(name="rico_d16_l1", dataset="rico", B=4, S=6, D=16, L=1, seed=12)]
+           dict(name="rico_d16_l1", dataset="rico", B=4, S=6, D=16, L=1, seed=12),
+           # round 6: a size the HIP path runs (d_model 128 is its smallest: 8 heads of 16), so that a `-m gpu` test reads a
+           # committed fixture too (tests/test_gpu_model.py::test_hip_f32_path_vs_committed_golden_fixture).  `summary`: the
+           # 230 k parameters are regenerated from the seed (np_ref.init_params) and pinned by per-variable sums; gradients and
+           # the Adam step are pinned by per-variable norms and projections on seeded +-1 vectors -- 60 KB instead of 3 MB
+           dict(name="rico_d128_l1_summary", dataset="rico", B=3, S=8, D=128, L=1, seed=13, summary=True)]
+
+
+def sign_vector(name, n):
+    """The +-1 vector a variable's gradient / Adam delta is projected on (seeded by the variable's name)."""
+    import zlib
+    return np.random.default_rng(zlib.crc32(name.encode())).integers(0, 2, n).astype(np.float64) * 2.0 - 1.0
 
 
 def main():
@@ -61,7 +72,16 @@ def main():
         assert abs(float(info["data_loss"]) - lt) < 1e-9 * abs(lt)
         torch_ref.apply_gradients(state, grads)
         arrays = {"meta": np.array(json.dumps(meta)), "reg_loss": np.array(np_ref.l2_loss(params, meta["l2"]))}
-        for k, v in params.items():
+        if cfg.get("summary"):
+            meta["param_seed"] = -cfg["seed"]
+            arrays["meta"] = np.array(json.dumps(meta))
+            for k, v in params.items():
+                g = grads[k].numpy().astype(np.float64).reshape(-1)
+                d = (state.p[k].detach().numpy().astype(np.float64) - v.astype(np.float64)).reshape(-1)
+                sv = sign_vector(k, g.size)
+                # [sum of the parameters, |g|, g . s, |adam delta|, delta . s]
+                arrays["summary:" + k] = np.array([v.astype(np.float64).sum(), np.linalg.norm(g), g @ sv, np.linalg.norm(d), d @ sv])
+        for k, v in ([] if cfg.get("summary") else params.items()):
             arrays["param:" + k] = v
             arrays["grad:" + k] = grads[k].numpy().astype(np.float32)          # f32 storage keeps the
             arrays["adam1:" + k] = state.p[k].detach().numpy().astype(np.float32)  # fixtures small

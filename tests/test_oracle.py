@@ -319,3 +319,45 @@ def test_context_token_numpy_vs_torch_and_known_answer():
         without = np_ref.model_fwd({k: v for k, v in inert.items() if "input_task" not in k}, ic, nb, 2, maxlen=7)
         for k in with_tok:
             assert np.abs(with_tok[k] - without[k]).max() < 1e-12, k
+
+
+def _load_summary_fixture(name="rico_d128_l1_summary"):
+    import importlib.util
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    spec = importlib.util.spec_from_file_location("make_fixtures", os.path.join(GOLDEN, "make_fixtures.py"))
+    mf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mf)
+    ic = _ic(meta["dataset"])
+    params = np_ref.init_params(ic, meta["D"], meta["L"], seed=meta["param_seed"])
+    for k, v in params.items():      # the regenerated parameters ARE the fixture's (per-variable sums)
+        assert abs(float(v.astype(np.float64).sum()) - float(z["summary:" + k][0])) <= 1e-9 * max(1.0, abs(float(z["summary:" + k][0]))), k
+    take = lambda pre: {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+    return z, meta, ic, params, take("batch:"), take("modified:"), take("mask:"), mf.sign_vector
+
+
+def test_golden_summary_fixture_at_a_size_the_device_runs():
+    """tests/golden/rico_d128_l1_summary.npz (d_model 128: the smallest width the HIP path takes): parameters regenerated from
+    the seed and pinned by per-variable sums, logits / losses in full, gradients and the Adam step as per-variable norms and
+    projections.  The same file is read by tests/test_gpu_model.py::test_hip_f32_path_vs_committed_golden_fixture, so the
+    chain committed data <-> oracle <-> device kernels closes on data that no code of this repository regenerates at test time."""
+    z, meta, ic, params, batch, modified, masks, sign_vector = _load_summary_fixture()
+    S, L = meta["S"], meta["L"]
+    out = np_ref.model_fwd(params, ic, modified, L, maxlen=S)
+    for k in out:
+        np.testing.assert_allclose(out[k], z["logits:" + k], rtol=1e-9, atol=1e-10)
+    lt, losses, _, _ = np_ref.loss_layer(ic, batch, out, masks, S)
+    for k in losses:
+        assert abs(losses[k] - float(z["loss:" + k])) < 1e-9 * max(1.0, abs(losses[k]))
+    state = torch_ref.TrainState(params, lr=meta["lr"], l2=meta["l2"], clipnorm=1.0, dtype=torch.float64)
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    info, grads = torch_ref.loss_and_grads(state, ic, t(batch), t(modified), t(masks), L, maxlen=S)
+    before = {k: v.detach().clone() for k, v in state.p.items()}
+    torch_ref.apply_gradients(state, grads)
+    for k in params:
+        g = grads[k].numpy().astype(np.float64).reshape(-1)
+        d = (state.p[k].detach() - before[k]).numpy().astype(np.float64).reshape(-1)
+        sv = sign_vector(k, g.size)
+        want = z["summary:" + k]
+        got = np.array([np.linalg.norm(g), g @ sv, np.linalg.norm(d), d @ sv])
+        np.testing.assert_allclose(got, want[1:], rtol=1e-7, atol=1e-10 * max(1.0, float(np.abs(want[1:]).max())), err_msg=k)
