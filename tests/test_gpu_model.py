@@ -1103,6 +1103,36 @@ def test_bf16_residual_gradient_stream_vs_f32(B, S, D, L):
     assert worst_cos > 0.9995 and worst_rel < 3e-2, (worst_cos, worst_rel)
 
 
+def test_transposed_heads_pad_columns_stay_zero_at_d512():
+    """the heads' input-gradient product at d_model 512 (mfp_dense_n512_lda) reads up to 127 bf16 values past each
+    d(logits) row and relies on the PAD columns [Upad, ldw) of the transposed heads being exactly zero.  They must survive every
+    refresh of the shadows behind an Adam step, at d_model 512 as at 256."""
+    from mfp.data.spec import make_input_columns, synthetic_batch
+    from mfp.models.mfp import MFP
+    ic = make_input_columns("crello")
+    for D, S in ((512, 32), (256, 64)):
+        m = MFP(ic, num_blocks=1, latent_dim=D, dropout=0.1, l2=1e-2, masking_method="random", dtype="bf16", device=DEV, seed=2)
+        m.compile(learning_rate=1e-2)
+        st = m.model.store
+        ht = st.heads_t()
+        if ht is None:
+            continue
+        U = st.layout.Upad
+        assert ht.shape[0] == D and ht.shape[1] % 128 == 0 and ht.shape[1] >= U
+        batch = synthetic_batch(ic, 4, S, seed=1, ragged=True, device=DEV)
+        before = ht[:, :U].clone()
+        for _ in range(3):
+            m.train_step(batch)
+        torch.cuda.synchronize()
+        ht = st.heads_t()
+        assert not ht[:, U:].any(), D                      # pad columns: still exactly zero
+        assert not torch.equal(ht[:, :U], before), D       # ... while the heads themselves moved (the shadow WAS refreshed)
+        # and the shadow is the transpose of the bf16 rounding of the f32 master
+        first = st.layout.head_order[0]
+        w = st.span(st.w, "decoder/decoder_%s/kernel" % first, U * D, D)
+        assert torch.equal(ht[:, :U], w.to(torch.bfloat16).t()), D
+
+
 # ------------------------------------------------------------------ BASELINE config c5 shape (D=512, 8 blocks, S=256)
 @pytest.mark.parametrize("dtype,route", [("fp32", "default"), ("bf16", "d512"), ("bf16", "generic")])
 def test_c5_shape_parity_vs_oracle(dtype, route):
