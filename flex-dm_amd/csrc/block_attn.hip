@@ -61,6 +61,14 @@ constexpr int AB_F = 512;
 #ifndef AB_RES_AT
 #define AB_RES_AT 13
 #endif
+// (round 6 experiment, -DAB_RES_FULL=1) the one-workgroup-per-tile forms can request the x1 epilogue's residual rows at the head of
+// the LAST chunk (o_3) -- the 64 registers of the LN1 fragments are dead behind the last q / k / v chunk, so all sixteen loads are
+// in flight through the chunk instead of four round trips of four in the epilogue; no spill, bit-identical.  Measured: nothing
+// (1.374 / 1.375 / 1.370 vs 1.372 / 1.377 / 1.369 ms per c2 step, tools/abl/r6_res_full.sh): the rows arrive when the memory path
+// delivers them, whoever asked first.  Off.
+#ifndef AB_RES_FULL
+#define AB_RES_FULL 0
+#endif
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
@@ -330,14 +338,16 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
   };
 
   f32x4 acc2[8][2];      // x1 accumulators: column tile T = (ct >> 2) * 8 + nh * 4 + (ct & 3), rows 32 rp + 16 rt + li
-  f32x4 resa[HALF ? 4 : 1][2][2];      // HALF: the x1 epilogue's sixteen residual loads, requested at the head of chunk AB_RES_AT
+  constexpr bool RESPF = HALF || AB_RES_FULL;      // the x1 epilogue's residual rows are requested inside the chunk loop
+  constexpr int RES_AT = HALF ? AB_RES_AT : AB_CHUNKS - 1;
+  f32x4 resa[RESPF ? 4 : 1][2][2];      // the x1 epilogue's sixteen residual loads, requested at the head of chunk RES_AT
   const float c2 = p.scale * LOG2E;
 
   auto chunk = [&](auto cc_) {
     constexpr int c = decltype(cc_)::value;
     constexpr int pr = c >> 2, t = c & 3;
     if (c + 2 < NCH) wload(c + 2);
-    if constexpr (HALF && c == AB_RES_AT) {
+    if constexpr (RESPF && c == RES_AT) {
       // behind this chunk's weight loads (fenced: the counted waits below assume that order).  Loads return in order, so the
       // weight chunk requested NEXT (head of chunk c + 1, needed at the end of chunk c + 2) waits for these rows: chunk 13 leaves
       // it the attention phase of pair 3 (~5 us; the rows take ~5 us to arrive while every CU asks at once)
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
       constexpr int at_prev = (c >= 1 && tp == 2) ? (H8 ? 1 : 2) : 0;
       constexpr int st_this = (t == 1 || t == 2) ? SI : t == 3 ? 2 * SI : 0;
       // (HALF: the sixteen residual loads at the head of chunk AB_RES_AT are younger than the loads this chunk and the next wait for)
-      constexpr int allowed = c == 0 ? 10 + LD : st_prev + at_prev + (c + 2 < NCH ? LD : 0) + st_this + ((HALF && (c == AB_RES_AT || c == AB_RES_AT + 1)) ? 8 * RT : 0);
+      constexpr int allowed = c == 0 ? 10 + LD : st_prev + at_prev + (c + 2 < NCH ? LD : 0) + st_this + ((RESPF && (c == RES_AT || c == RES_AT + 1)) ? 8 * RT : 0);
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(allowed) : "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(HALF == 1 ? 256 : 512) void attn_block_fwd_kernel(A
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row = row0 + rbase + rt * 16 + li, n = ((hf2 >> 1) * 8 + nh * 4 + (hf2 & 1) * 2 + q4) * 16 + 4 * g;
-          if constexpr (HALF) res[q4][rt] = resa[hf2][q4][rt];
+          if constexpr (RESPF) res[q4][rt] = resa[hf2][q4][rt];
           else res[q4][rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned int)row * (AB_D * 4) + n * 4, 0, 0));
         }
 #pragma unroll
